@@ -1,0 +1,114 @@
+"""Input systems for the AGBNP hot path: the reference test's 8-column structure format and the
+parameterisation its test program applies before AGBNPForce::addParticle
+(reference: platforms/reference/tests/TestReferenceAGBNPForce.cpp:47-70).
+
+Columns: id x y z radius charge gamma ishydrogen   (Angstrom, e, kcal/mol/A^2)
+"""
+import math
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+BUNDLED = {
+    "fixture264": "fixture264.dat",        # platforms/reference/tests/gaussvol.dat
+    "fixture264_ocl": "fixture264_ocl.dat",  # platforms/opencl/tests/gaussvol.dat (radii +0.5 A)
+    "trpcage": "trpcage.dat",              # example/trpcage_agbnp1.dms
+    "1dwc": "1dwc.dat",                    # example/1dwc_agbnp1.dms (thrombin)
+    "2clr": "2clr.dat",                    # example/2clr_agbnp1.dms
+}
+
+
+class AGBNPSystem:
+    """Plain container: positions (nm) + the five addParticle arguments per atom."""
+
+    def __init__(self, name, pos, radius, gamma, alpha, charge, ishydrogen):
+        self.name = name
+        self.pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        self.radius = np.ascontiguousarray(radius, dtype=np.float64)
+        self.gamma = np.ascontiguousarray(gamma, dtype=np.float64)
+        self.alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        self.charge = np.ascontiguousarray(charge, dtype=np.float64)
+        self.ishydrogen = np.ascontiguousarray(ishydrogen, dtype=np.int32)
+
+    @property
+    def n(self):
+        return len(self.radius)
+
+    @property
+    def nheavy(self):
+        return int((self.ishydrogen == 0).sum())
+
+    def params(self):
+        return self.radius, self.gamma, self.alpha, self.charge, self.ishydrogen
+
+    def jittered(self, step, sigma=0.002, seed=20261004):
+        """Per-step geometry for benchmarking: file coordinates + i.i.d. N(0, sigma nm) displacements
+        (SURVEY.md section 8d), so that the overlap tree is rebuilt from a new geometry every step."""
+        rng = np.random.Generator(np.random.MT19937(seed + step))
+        return self.pos + sigma * rng.standard_normal(self.pos.shape)
+
+    def permuted(self, perm):
+        perm = np.asarray(perm)
+        return AGBNPSystem(self.name + "_perm", self.pos[perm], self.radius[perm], self.gamma[perm], self.alpha[perm],
+                           self.charge[perm], self.ishydrogen[perm])
+
+    def subset(self, idx):
+        idx = np.asarray(idx)
+        return AGBNPSystem(self.name + "_sub", self.pos[idx], self.radius[idx], self.gamma[idx], self.alpha[idx],
+                           self.charge[idx], self.ishydrogen[idx])
+
+
+def vdw_alpha_from_radius(radius_nm):
+    """alpha_i = -16 pi rho_w eps_ij sigma_ij^6 / 3 with sigma_LJ = 2 R, TIP4P water constants
+    (TestReferenceAGBNPForce.cpp:51-68)."""
+    ang2nm = 0.1
+    kcalmol2kjmol = 4.184
+    sigmaw = 3.15365 * ang2nm
+    epsilonw = 0.155 * kcalmol2kjmol
+    rho = 0.033428 / math.pow(ang2nm, 3)
+    epsilon_lj = 0.155 * kcalmol2kjmol
+    out = np.empty(len(radius_nm))
+    for i, r in enumerate(radius_nm):
+        sigma_lj = 2.0 * r
+        sij = math.sqrt(sigmaw * sigma_lj)
+        eij = math.sqrt(epsilonw * epsilon_lj)
+        out[i] = -16.0 * math.pi * rho * eij * math.pow(sij, 6) / 3.0
+    return out
+
+
+def parse_structure(text, name="structure"):
+    toks = text.split()
+    n = int(toks[0])
+    vals = np.array(toks[1:1 + 8 * n], dtype=np.float64).reshape(n, 8)
+    ang2nm = 0.1
+    kcalmol2kjmol = 4.184
+    pos = vals[:, 1:4] * ang2nm
+    radius = vals[:, 4] * ang2nm
+    charge = vals[:, 5].copy()
+    gamma = vals[:, 6] * (kcalmol2kjmol / (ang2nm * ang2nm))
+    ish = (vals[:, 7] > 0).astype(np.int32)
+    alpha = vdw_alpha_from_radius(radius)
+    return AGBNPSystem(name, pos, radius, gamma, alpha, charge, ish)
+
+
+def load_system(name):
+    """Load one of the bundled structures by name, or any file in the 8-column format by path."""
+    path = os.path.join(GOLDEN_DIR, BUNDLED[name]) if name in BUNDLED else name
+    with open(path) as f:
+        return parse_structure(f.read(), name=os.path.splitext(os.path.basename(path))[0])
+
+
+def lattice(system, nx, ny, nz, pitch_nm):
+    """Synthetic larger system: nx*ny*nz translated copies (stand-in for the missing hivrt file,
+    SURVEY.md section 8d C4).  Copies do not overlap when pitch exceeds the molecule's extent + 2 nm... they still
+    interact through the all-pairs GB term."""
+    parts = []
+    for ix in range(nx):
+        for iy in range(ny):
+            for iz in range(nz):
+                parts.append(system.pos + np.array([ix, iy, iz], dtype=np.float64) * pitch_nm)
+    k = nx * ny * nz
+    return AGBNPSystem(f"{system.name}_x{k}", np.concatenate(parts), np.tile(system.radius, k), np.tile(system.gamma, k),
+                       np.tile(system.alpha, k), np.tile(system.charge, k), np.tile(system.ishydrogen, k))
