@@ -1,0 +1,107 @@
+/* ============================================================================================
+ * agbnp_hip.h -- C ABI of the MI355X (gfx950) AGBNP / GaussVol force engine (libagbnp_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Gallicchio-Lab/openmm_agbnp_plugin: the work
+ * behind  AGBNPPlugin::CalcAGBNPForceKernel  (reference: openmmapi/include/AGBNPKernels.h:19-47)
+ * for AGBNPForce version 0 (GaussVol/GVolSA) and version 1 (AGBNP1).  Each entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch/OpenMM types.
+ *
+ * Units: nm, kJ/mol, kJ/mol/nm, elementary charge -- the units of AGBNPForce::addParticle
+ * (reference: openmmapi/include/AGBNPForce.h:66-77).
+ *
+ * Every function returns AGBNP_HIP_OK (0) or an error code; the message is available from
+ * agbnp_hip_last_error().  No exception crosses this boundary.
+ * ============================================================================================ */
+#ifndef AGBNP_HIP_H_
+#define AGBNP_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agbnp_hip_context agbnp_hip_context;
+
+enum agbnp_hip_status {
+  AGBNP_HIP_OK = 0,
+  AGBNP_HIP_ERR_INVALID_ARGUMENT = 1, /* bad sizes / null pointers / illegal version                */
+  AGBNP_HIP_ERR_PARAMETERS = 2,       /* the reference would throw OpenMMException for these params  */
+  AGBNP_HIP_ERR_DEVICE = 3,           /* a HIP runtime call failed or no gfx950 device is available  */
+  AGBNP_HIP_ERR_CAPACITY = 4          /* an overlap subtree exceeded the largest supported capacity  */
+};
+
+/* nonbonded methods, values of AGBNPForce::NonbondedMethod (openmmapi/include/AGBNPForce.h:44-59) */
+enum agbnp_hip_nonbonded_method { AGBNP_HIP_NoCutoff = 0, AGBNP_HIP_CutoffNonPeriodic = 1, AGBNP_HIP_CutoffPeriodic = 2 };
+
+/* Replaces ReferenceCalcAGBNPForceKernel::initialize(system, force)
+ * (platforms/reference/src/ReferenceAGBNPKernels.cpp:58-137): takes the per-particle parameters of
+ * AGBNPForce::getParticleParameters (radius, gamma, vdw_alpha, charge, ishydrogen), the version
+ * (0 = GVolSA, 1 = AGBNP1; 2 = AGBNP2 is out of scope -> AGBNP_HIP_ERR_INVALID_ARGUMENT), the nonbonded method
+ * and cutoff (accepted and stored; like the Reference platform the engine evaluates all pairs --
+ * see DESIGN.md), builds the I4 tables and uploads everything to device `device`.
+ * Fails with AGBNP_HIP_ERR_PARAMETERS and the reference's message if heavy-atom gammas differ
+ * (ReferenceAGBNPKernels.cpp:109-116). */
+int agbnp_hip_create(agbnp_hip_context** out, int num_particles, const double* radius, const double* gamma,
+                     const double* vdw_alpha, const double* charge, const int* ishydrogen, int version,
+                     int nonbonded_method, double cutoff_distance, int device);
+
+/* Replaces ReferenceCalcAGBNPForceKernel::copyParametersToContext (ReferenceAGBNPKernels.cpp:1796-1815):
+ * gamma, alpha and charge may change; a changed particle count, radius (squared difference > 1e-6) or
+ * heavy->hydrogen flip fails with AGBNP_HIP_ERR_PARAMETERS and the reference's message. */
+int agbnp_hip_update_parameters(agbnp_hip_context* ctx, int num_particles, const double* radius, const double* gamma,
+                                const double* vdw_alpha, const double* charge, const int* ishydrogen);
+
+/* Replaces ReferenceCalcAGBNPForceKernel::execute (ReferenceAGBNPKernels.cpp:139-149) with the CPU
+ * platform's data conventions: positions[3N] in, forces ACCUMULATED into forces[3N] (+=), energy
+ * RETURNED in *energy.  Host buffers; synchronous.  Subtree-capacity overflow is handled inside
+ * (the evaluation is repeated with the next larger kernel variant). */
+int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, double* forces, double* energy);
+
+/* Device-resident variant for GPU platforms (the data convention of the reference's OpenCL platform,
+ * platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556: forces and energy are ADDED to device
+ * buffers, nothing is returned).  d_positions[3N], d_forces[3N], d_energy[1] are FP64 device
+ * pointers on the context's device; `stream` is a hipStream_t (NULL = the context's own stream).
+ * Asynchronous.  Call agbnp_hip_finish() before trusting the results. */
+int agbnp_hip_execute_device(agbnp_hip_context* ctx, const double* d_positions, double* d_forces, double* d_energy,
+                             void* stream);
+
+/* Waits for `stream`, then checks the overflow words of the last evaluation.  Returns AGBNP_HIP_OK if the
+ * results are valid.  If a capacity overflow happened, the context has switched to a larger
+ * variant, *must_repeat is set to 1 and AGBNP_HIP_OK is returned: the caller must discard the
+ * forces/energy of that evaluation and run it again (the analogue of the reference OpenCL
+ * platform's PanicButton protocol, OpenCLAGBNPKernels.cpp:3599-3634). */
+int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
+
+/* Diagnostics of the LAST completed evaluation (test support; mirrors the quantities the reference
+ * prints at verbose_level > 0, ReferenceAGBNPKernels.cpp:333-352,459-462,519).
+ * scalars: 0 E_vol1  1 E_vol2  2 E_atom (vdW + GB self)  3 E_GB pair  4 max subtree nodes
+ *          5 total tree nodes  6 kernel variant  7 max local atoms
+ * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
+ *          3 self volume (enlarged radii) */
+int agbnp_hip_get_scalar(agbnp_hip_context* ctx, int which, double* value);
+int agbnp_hip_get_vector(agbnp_hip_context* ctx, int which, double* out);
+
+/* I4 lookup tables as uploaded (test support): sizes, then y/y2 [nscreened*nscreener*16] and per-atom types. */
+int agbnp_hip_get_table_sizes(agbnp_hip_context* ctx, int* nscreened, int* nscreener);
+int agbnp_hip_get_tables(agbnp_hip_context* ctx, double* y, double* y2, int* type_screened, int* type_screener);
+
+/* Host-only table builder (no device needed; test support for the host logic): the radius typing and
+ * the 16-node spline tables of AGBNPI42DLookupTable (openmmapi/src/AGBNPUtils.cpp:134-214).  y/y2 must hold
+ * table_capacity doubles; fails with AGBNP_HIP_ERR_INVALID_ARGUMENT if nscreened*nscreener*16 exceeds it. */
+int agbnp_hip_host_tables(int num_particles, const double* radius, const int* ishydrogen, int* nscreened, int* nscreener,
+                          double* y, double* y2, int table_capacity, int* type_screened, int* type_screener);
+
+int agbnp_hip_num_particles(const agbnp_hip_context* ctx);
+int agbnp_hip_version(const agbnp_hip_context* ctx);
+
+/* Message of the last error on this context; with ctx == NULL, of the last failed agbnp_hip_create(). */
+const char* agbnp_hip_last_error(const agbnp_hip_context* ctx);
+
+void agbnp_hip_destroy(agbnp_hip_context* ctx);
+
+/* Number of HIP devices visible to this process (0 if none / runtime unavailable). */
+int agbnp_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGBNP_HIP_H_ */

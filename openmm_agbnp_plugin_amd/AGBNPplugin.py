@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's Python module `AGBNPplugin` (python/AGBNPPlugin.i:46-84) and of the
+plugin's kernel interface, on top of the gfx950 engine's C ABI.
+
+`AGBNPForce` keeps the reference's method names, argument order and meaning, defaults and error
+behaviour (openmmapi/include/AGBNPForce.h:39-155, openmmapi/src/AGBNPForce.cpp:15-78).
+`HipCalcAGBNPForceKernel` plays the role of a platform's `CalcAGBNPForceKernel`
+(openmmapi/include/AGBNPKernels.h:19-47): initialize / execute / copyParametersToContext.
+`AGBNPContext` is the small stand-in for the OpenMM Context + ForceImpl pair that the parity tests
+and benchmarks need (OpenMM itself is not part of this path): it owns positions and calls the kernel
+the way AGBNPForceImpl does (openmmapi/src/AGBNPForceImpl.cpp:27-46).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class OpenMMException(Exception):
+    """Same role as OpenMM::OpenMMException in the reference: every API error surfaces as this type."""
+
+
+class AGBNPForce:
+    # enum NonbondedMethod (openmmapi/include/AGBNPForce.h:44-59)
+    NoCutoff = 0
+    CutoffNonPeriodic = 1
+    CutoffPeriodic = 2
+
+    def __init__(self):
+        # defaults of AGBNPForce::AGBNPForce() (openmmapi/src/AGBNPForce.cpp:15)
+        self._particles = []
+        self._method = AGBNPForce.NoCutoff
+        self._cutoff = 1.0
+        self._version = 1
+        self._solvent_radius = 1.0 * float(np.float32(0.1))  # SOLVENT_RADIUS (1.0*ANG)
+        self._force_group = 0
+
+    def getNumParticles(self):
+        return len(self._particles)
+
+    def addParticle(self, radius, gamma, vdw_alpha, charge, ishydrogen):
+        """radius nm, gamma kJ/mol/nm^2, vdw_alpha kJ/mol nm^3... (as the reference), charge e. Returns the index."""
+        self._particles.append([float(radius), float(gamma), float(vdw_alpha), float(charge), bool(ishydrogen)])
+        return len(self._particles) - 1
+
+    def _check_index(self, index):
+        if index < 0 or index >= len(self._particles):
+            raise OpenMMException("Assertion failure: Index out of range")  # ASSERT_VALID_INDEX
+
+    def setParticleParameters(self, index, radius, gamma, vdw_alpha, charge, ishydrogen):
+        self._check_index(index)
+        self._particles[index] = [float(radius), float(gamma), float(vdw_alpha), float(charge), bool(ishydrogen)]
+
+    def getParticleParameters(self, index):
+        """Returns the tuple (radius, gamma, vdw_alpha, charge, ishydrogen), as the SWIG wrapper does."""
+        self._check_index(index)
+        return tuple(self._particles[index])
+
+    def getNonbondedMethod(self):
+        return self._method
+
+    def setNonbondedMethod(self, method):
+        self._method = int(method)
+
+    def getCutoffDistance(self):
+        return self._cutoff
+
+    def setCutoffDistance(self, distance):
+        self._cutoff = float(distance)
+
+    def getSolventRadius(self):
+        return self._solvent_radius
+
+    def setVersion(self, agbnp_version):
+        if 0 <= agbnp_version <= 2:
+            self._version = int(agbnp_version)
+        else:
+            raise OpenMMException("AGBNPForce::setVersion(): illegal version number")
+
+    def getVersion(self):
+        return self._version
+
+    def getForceGroup(self):
+        return self._force_group
+
+    def setForceGroup(self, group):
+        self._force_group = int(group)
+
+    def updateParametersInContext(self, context):
+        context._update_parameters(self)
+
+    # helpers for the engine boundary
+    def _arrays(self):
+        p = self._particles
+        f = lambda k: np.ascontiguousarray([x[k] for x in p], dtype=np.float64)
+        return f(0), f(1), f(2), f(3), np.ascontiguousarray([1 if x[4] else 0 for x in p], dtype=np.int32)
+
+    @classmethod
+    def from_arrays(cls, radius, gamma, vdw_alpha, charge, ishydrogen, version=1):
+        force = cls()
+        force.setVersion(version)
+        for r, g, a, q, h in zip(radius, gamma, vdw_alpha, charge, ishydrogen):
+            force.addParticle(r, g, a, q, bool(h))
+        return force
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class HipCalcAGBNPForceKernel:
+    """The 'HIP platform' implementation of CalcAGBNPForceKernel."""
+
+    @staticmethod
+    def Name():
+        return "CalcAGBNPForce"
+
+    def __init__(self, device=0):
+        self._h = None
+        self._device = device
+        self.numParticles = 0
+
+    def initialize(self, force):
+        lib = _lib.load()
+        self.release()
+        r, g, a, q, h = force._arrays()
+        self.numParticles = len(r)
+        handle = C.c_void_p()
+        rc = lib.agbnp_hip_create(C.byref(handle), len(r), _dp(r), _dp(g), _dp(a), _dp(q), _ip(h), force.getVersion(),
+                                  force.getNonbondedMethod(), force.getCutoffDistance(), self._device)
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(None))
+        self._h = handle
+
+    def _need(self):
+        if self._h is None:
+            raise OpenMMException("HipCalcAGBNPForceKernel: initialize() has not been called")
+
+    def execute(self, positions, forces, includeForces=True, includeEnergy=True):
+        """CPU-platform convention of the reference: forces (N x 3 float64 array) are accumulated in place,
+        the energy is returned.  includeForces/includeEnergy are accepted and ignored, as in the reference
+        (ReferenceAGBNPKernels.cpp:139-149 always computes both)."""
+        self._need()
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        if pos.size != 3 * self.numParticles:
+            raise OpenMMException("execute(): wrong number of positions")
+        if not (isinstance(forces, np.ndarray) and forces.dtype == np.float64 and forces.flags.c_contiguous
+                and forces.size == 3 * self.numParticles):
+            raise OpenMMException("execute(): forces must be a C-contiguous float64 array of 3N values")
+        e = C.c_double(0.0)
+        rc = _lib.load().agbnp_hip_execute_host(self._h, _dp(pos), _dp(forces), C.byref(e))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+        return e.value
+
+    def execute_device(self, d_positions, d_forces, d_energy, stream=None):
+        """GPU-platform convention (reference OpenCL platform): raw FP64 device pointers (ints), forces and
+        energy are ADDED on the device, nothing is returned.  Asynchronous; call finish()."""
+        self._need()
+        rc = _lib.load().agbnp_hip_execute_device(self._h, C.c_void_p(d_positions), C.c_void_p(d_forces), C.c_void_p(d_energy),
+                                                  C.c_void_p(stream or 0))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+
+    def finish(self, stream=None):
+        """Synchronise and validate the last device evaluation; returns True if it must be repeated."""
+        self._need()
+        rep = C.c_int(0)
+        rc = _lib.load().agbnp_hip_finish(self._h, C.c_void_p(stream or 0), C.byref(rep))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+        return bool(rep.value)
+
+    def copyParametersToContext(self, force):
+        self._need()
+        r, g, a, q, h = force._arrays()
+        rc = _lib.load().agbnp_hip_update_parameters(self._h, len(r), _dp(r), _dp(g), _dp(a), _dp(q), _ip(h))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+
+    # ---- diagnostics (test support) -------------------------------------------------------------
+    SCALARS = dict(e_vol1=0, e_vol2=1, e_atom=2, e_gb_pair=3, max_subtree_nodes=4, total_nodes=5, variant=6, max_local_atoms=7)
+    VECTORS = dict(selfvol_vdw=0, born=1, scale=2, selfvol_large=3)
+
+    def scalar(self, name):
+        self._need()
+        v = C.c_double(0)
+        rc = _lib.load().agbnp_hip_get_scalar(self._h, self.SCALARS[name], C.byref(v))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+        return v.value
+
+    def vector(self, name):
+        self._need()
+        out = np.zeros(self.numParticles)
+        rc = _lib.load().agbnp_hip_get_vector(self._h, self.VECTORS[name], _dp(out))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+        return out
+
+    def tables(self):
+        self._need()
+        lib = _lib.load()
+        ni, nj = C.c_int(0), C.c_int(0)
+        lib.agbnp_hip_get_table_sizes(self._h, C.byref(ni), C.byref(nj))
+        y = np.zeros(ni.value * nj.value * 16)
+        y2 = np.zeros_like(y)
+        ti = np.zeros(self.numParticles, dtype=np.int32)
+        tj = np.zeros(self.numParticles, dtype=np.int32)
+        lib.agbnp_hip_get_tables(self._h, _dp(y), _dp(y2), _ip(ti), _ip(tj))
+        return dict(y=y.reshape(ni.value, nj.value, 16), y2=y2.reshape(ni.value, nj.value, 16), type_screened=ti, type_screener=tj)
+
+    def release(self):
+        if self._h is not None:
+            _lib.load().agbnp_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def host_tables(radius, ishydrogen):
+    """I4 tables from the engine's host code (no device needed)."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(radius, dtype=np.float64)
+    h = np.ascontiguousarray(ishydrogen, dtype=np.int32)
+    n = len(r)
+    cap = 64 * 64 * 16
+    y, y2 = np.zeros(cap), np.zeros(cap)
+    ti, tj = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    ni, nj = C.c_int(0), C.c_int(0)
+    rc = lib.agbnp_hip_host_tables(n, _dp(r), _ip(h), C.byref(ni), C.byref(nj), _dp(y), _dp(y2), cap, _ip(ti), _ip(tj))
+    if rc != _lib.OK:
+        raise OpenMMException(_lib.last_error(None))
+    k = ni.value * nj.value * 16
+    return dict(y=y[:k].reshape(ni.value, nj.value, 16), y2=y2[:k].reshape(ni.value, nj.value, 16), type_screened=ti,
+                type_screener=tj)
+
+
+class AGBNPContext:
+    """Minimal Context + ForceImpl stand-in: positions in, (energy, forces) out, through the kernel."""
+
+    def __init__(self, force, device=0):
+        self._force = force
+        self._kernel = HipCalcAGBNPForceKernel(device)
+        self._kernel.initialize(force)  # AGBNPForceImpl::initialize
+        self._positions = None
+
+    @property
+    def kernel(self):
+        return self._kernel
+
+    def setPositions(self, positions):
+        self._positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+
+    def getState(self, groups=-1):
+        """Returns (potential energy, forces[N,3]).  Honours the force-group mask like
+        AGBNPForceImpl::calcForcesAndEnergy (openmmapi/src/AGBNPForceImpl.cpp:32-36)."""
+        if self._positions is None:
+            raise OpenMMException("Particle positions have not been set")
+        forces = np.zeros((self._kernel.numParticles, 3))
+        if (groups & (1 << self._force.getForceGroup())) == 0:
+            return 0.0, forces
+        e = self._kernel.execute(self._positions, forces, True, True)
+        return e, forces
+
+    def _update_parameters(self, force):
+        self._kernel.copyParametersToContext(force)

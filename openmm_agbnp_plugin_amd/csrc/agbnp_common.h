@@ -1,0 +1,52 @@
+// Shared definitions for the gfx950 AGBNP engine (device + host).
+//
+// Model constants follow the reference's macros bit-for-bit: float literals promoted to double
+// (gaussvol/gaussvol.h:46-63, openmmapi/include/AGBNPForce.h:14-33, openmmapi/include/AGBNPUtils.h:124-126).
+#pragma once
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+namespace agbnp {
+
+constexpr double kKFC = (2.2269859253f);            // gaussvol.h:46
+constexpr double kMinGvol = FLT_MIN;                // gaussvol.h:52
+constexpr int kMaxOrder = 8;                        // gaussvol.h:55
+constexpr double kVolMinA = (0.01f * (0.001f));     // gaussvol.h:62  (float product)
+constexpr double kVolMinB = (0.1f * (0.001f));      // gaussvol.h:63
+constexpr double kRadiusIncrement = (0.5f * (0.1f));  // AGBNPForce.h:25
+constexpr double kHBRadius = (1.4 * (0.1f));        // AGBNPForce.h:33
+constexpr double kSolventRadius = (1.0 * (0.1f));   // AGBNPForce.h:30
+constexpr double kI4MaxA = 2.0;                     // AGBNPUtils.h:124
+constexpr int kI4Nodes = 16;                        // AGBNPUtils.h:126
+constexpr long kRadiusPrecision = 10000;            // AGBNPUtils.h:155
+constexpr double kPi = 3.14159265358979323846;
+
+// GB prefactor (ReferenceAGBNPKernels.cpp:465-468)
+constexpr double kToKjMol = 4.184 * 332.0 / 10.0;
+constexpr double kDielFactor = kToKjMol * (-0.5) * (1. / 1.0 - 1. / 80.0);
+
+// Per-subtree header of the stored overlap-tree topology (written by the build kernel,
+// consumed by the pseudo-volume pass).
+struct SubtreeHeader {
+  int nnodes;      // nodes in the subtree including the level-1 root
+  int natoms;      // local atoms (root + its level-2 partners)
+  int pool_off;    // offset (in nodes) of the topology records in the node pool
+  int atom_off;    // offset (in ints) of the local->heavy index map in the atom pool
+  int lvl[10];     // lvl[L] = first node of level L (L = 1..8), lvl[9] = nnodes sentinel; lvl[0] unused
+};
+
+// status/overflow word indices (device int array)
+enum StatusWord {
+  kStatNodeOverflow = 0,   // a subtree needed more than NCAP nodes
+  kStatAtomOverflow = 1,   // a node had more than ACAP children / level-2 partners
+  kStatPoolOverflow = 2,   // topology pool exhausted
+  kStatMaxNodes = 3,       // max nodes of any subtree (diagnostic)
+  kStatMaxAtoms = 4,       // max local atoms of any subtree (diagnostic)
+  kStatPoolUsed = 5,       // nodes allocated from the pool
+  kStatAtomPoolUsed = 6,   // ints allocated from the atom pool
+  kStatTotalNodes = 7,     // total nodes (all subtrees)
+  kStatWords = 16
+};
+
+}  // namespace agbnp

@@ -1,0 +1,603 @@
+// Host engine + C ABI (include/agbnp_hip.h) of the gfx950 AGBNP force path.
+//
+// Mirrors the life cycle of the reference's platform kernel
+// (platforms/reference/src/ReferenceAGBNPKernels.cpp): initialize() :58-137 -> agbnp_hip_create,
+// execute() :139-149 -> agbnp_hip_execute_{host,device}, copyParametersToContext() :1796-1815 ->
+// agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
+//
+//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_pairs -> k_gb_finish
+//          -> k_dborn_pairs -> k_dborn_finish -> k_tree_pseudo] -> k_forces_out -> k_energy_out
+//
+// (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
+// point that computes fails with AGBNP_HIP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/agbnp_hip.h"
+#include "agbnp_common.h"
+#include "i4_tables.h"
+#include "pair_kernels.h"
+#include "tree_kernels.h"
+
+namespace agbnp {
+size_t tree_variant_lds_bytes(int variant);
+size_t tree_variant_scratch_bytes(int variant);
+int tree_variant_node_cap(int variant);
+hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
+hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
+}  // namespace agbnp
+
+using namespace agbnp;
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t count = 0;
+  hipError_t alloc(size_t n) {
+    release();
+    count = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+constexpr int kGlobalVariant = 3;
+constexpr int kGlobalGrid = 256;  // persistent workgroups of the global-scratch variant
+
+}  // namespace
+
+struct agbnp_hip_context {
+  int n = 0, nh = 0, version = 1, method = 0, device = 0;
+  double cutoff = 1.0;
+  std::string err;
+  // host copies of the parameters (reference: ReferenceAGBNPKernels.h:60-91)
+  std::vector<double> r_vdw, gamma, alpha, charge;
+  std::vector<int> ish, a2h, h2a;
+  I4TableSet lut;
+  int variant = 0;
+  hipStream_t stream = nullptr;
+
+  // static device data
+  DevBuf<int> d_a2h, d_h2a, d_status;
+  DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
+  DevBuf<int2> d_ameta, d_hmeta;
+  DevBuf<double2> d_lut;
+  // per-evaluation device data
+  DevBuf<double> d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
+  DevBuf<double4> d_aposq, d_hposs;
+  DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
+  DevBuf<double2> d_bws;
+  DevBuf<SubtreeHeader> d_hdr;
+  DevBuf<ushort4> d_node_pool;
+  DevBuf<int> d_atom_pool;
+  DevBuf<char> d_scratch;
+  // host-API staging
+  DevBuf<double> d_pos_in, d_force_tmp, d_energy_tmp;
+  std::vector<double> h_force_tmp;
+
+  PairArgs P{};
+  TreeArgs T{};
+  int last_status[kStatWords] = {0};
+  double last_components[4] = {0, 0, 0, 0};
+  bool have_results = false;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  int hipfail(hipError_t e, const char* what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return AGBNP_HIP_ERR_DEVICE;
+  }
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                  \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return (ctx)->hipfail(e__, #call); \
+  } while (0)
+
+// Conservative squared cutoff of the 2-body overlap search: beyond it no pair of heavy atoms can have
+// an unswitched overlap volume above VOLMINA (gaussvol.cpp:60-93 solved for d^2), so the pruned pairs
+// would have been rejected by the volume test anyway.
+double overlap_search_cutoff2(const std::vector<double>& a_large, const std::vector<double>& v_large) {
+  std::vector<std::pair<double, double>> kinds;
+  for (size_t i = 0; i < a_large.size(); i++) {
+    std::pair<double, double> k(a_large[i], v_large[i]);
+    if (std::find(kinds.begin(), kinds.end(), k) == kinds.end()) kinds.push_back(k);
+  }
+  double best = 0.0;
+  for (auto& k1 : kinds)
+    for (auto& k2 : kinds) {
+      const double df = k1.first * k2.first / (k1.first + k2.first);
+      const double pref = k1.second * k2.second * pow(df / kPi, 1.5);
+      if (pref > kVolMinA) best = std::max(best, log(pref / kVolMinA) / df);
+    }
+  return best * (1.0 + 1e-6) + 1e-9;
+}
+
+int upload_parameters(agbnp_hip_context* c) {
+  const int n = c->n, nh = c->nh;
+  std::vector<double> inv_rvdw(n), inv_vol_h(nh), gam_cav(nh), a_large(nh), v_large(nh), a_vdw(nh), v_vdw(nh);
+  const double roffset = kRadiusIncrement;  // versions 0 and 1 (ReferenceAGBNPKernels.cpp:67-70)
+  for (int i = 0; i < n; i++) inv_rvdw[i] = 1. / c->r_vdw[i];
+  for (int h = 0; h < nh; h++) {
+    const int i = c->h2a[h];
+    const double rv = c->r_vdw[i];
+    const double rl = rv + roffset;
+    a_large[h] = kKFC / (rl * rl);
+    v_large[h] = 4. * M_PI * pow(rl, 3) / 3.;
+    a_vdw[h] = kKFC / (rv * rv);
+    v_vdw[h] = 4. * M_PI * pow(rv, 3) / 3.;
+    inv_vol_h[h] = 1.0 / v_vdw[h];
+    gam_cav[h] = c->gamma[i] / roffset;
+  }
+  HIP_TRY(c, c->d_charge.upload(c->charge));
+  HIP_TRY(c, c->d_alpha.upload(c->alpha));
+  HIP_TRY(c, c->d_inv_rvdw.upload(inv_rvdw));
+  HIP_TRY(c, c->d_inv_vol_h.upload(inv_vol_h));
+  HIP_TRY(c, c->d_gam_cav.upload(gam_cav));
+  HIP_TRY(c, c->d_a_large.upload(a_large));
+  HIP_TRY(c, c->d_v_large.upload(v_large));
+  HIP_TRY(c, c->d_a_vdw.upload(a_vdw));
+  HIP_TRY(c, c->d_v_vdw.upload(v_vdw));
+  c->T.rcut2 = overlap_search_cutoff2(a_large, v_large);
+  return AGBNP_HIP_OK;
+}
+
+int ensure_scratch(agbnp_hip_context* c) {
+  if (c->variant != kGlobalVariant) return AGBNP_HIP_OK;
+  const size_t stride = tree_variant_scratch_bytes(kGlobalVariant);
+  const size_t need = stride * (size_t)std::min(kGlobalGrid, std::max(c->nh, 1));
+  if (c->d_scratch.count < need) HIP_TRY(c, c->d_scratch.alloc(need));
+  c->T.scratch = c->d_scratch.p;
+  c->T.scratch_stride = stride;
+  return AGBNP_HIP_OK;
+}
+
+void wire_args(agbnp_hip_context* c) {
+  PairArgs& P = c->P;
+  P.n = c->n;
+  P.nh = c->nh;
+  P.a2h = c->d_a2h.p;
+  P.h2a = c->d_h2a.p;
+  P.charge = c->d_charge.p;
+  P.alpha = c->d_alpha.p;
+  P.inv_rvdw = c->d_inv_rvdw.p;
+  P.inv_vol_h = c->d_inv_vol_h.p;
+  P.gam_cav = c->d_gam_cav.p;
+  P.ameta = c->d_ameta.p;
+  P.hmeta = c->d_hmeta.p;
+  P.lut = c->d_lut.p;
+  P.nti = c->lut.nscreened;
+  P.ntj = c->lut.nscreener;
+  P.lut_entries = c->lut.nscreened * c->lut.nscreener * kI4Nodes;
+  P.hx = c->d_hx.p;
+  P.hy = c->d_hy.p;
+  P.hz = c->d_hz.p;
+  P.aposq = c->d_aposq.p;
+  P.hposs = c->d_hposs.p;
+  P.gx = c->d_gx.p;
+  P.gy = c->d_gy.p;
+  P.gz = c->d_gz.p;
+  P.sv_vdw = c->d_sv_vdw.p;
+  P.sv_large = c->d_sv_large.p;
+  P.gam = c->d_gam.p;
+  P.epart = c->d_epart.p;
+  P.status = c->d_status.p;
+  P.born_part = c->d_born_part.p;
+  P.born = c->d_born.p;
+  P.born_fp = c->d_born_fp.p;
+  P.brw = c->d_brw.p;
+  P.e_atom = c->d_e_atom.p;
+  P.bws = c->d_bws.p;
+  const size_t row = (size_t)P.asplits * c->n;
+  P.gb_fx = c->d_gbf.p;
+  P.gb_fy = c->d_gbf.p + row;
+  P.gb_fz = c->d_gbf.p + 2 * row;
+  P.gb_y = c->d_gbf.p + 3 * row;
+  P.db_fx = c->d_dbf.p;
+  P.db_fy = c->d_dbf.p + row;
+  P.db_fz = c->d_dbf.p + 2 * row;
+  P.db_wu = c->d_dbf.p + 3 * row;
+  P.egb_part = c->d_egb_part.p;
+
+  TreeArgs& T = c->T;
+  T.nh = c->nh;
+  T.hx = c->d_hx.p;
+  T.hy = c->d_hy.p;
+  T.hz = c->d_hz.p;
+  T.a_large = c->d_a_large.p;
+  T.v_large = c->d_v_large.p;
+  T.a_vdw = c->d_a_vdw.p;
+  T.v_vdw = c->d_v_vdw.p;
+  T.gam = c->d_gam.p;
+  T.gx = c->d_gx.p;
+  T.gy = c->d_gy.p;
+  T.gz = c->d_gz.p;
+  T.sv_large = c->d_sv_large.p;
+  T.sv_vdw = c->d_sv_vdw.p;
+  T.epart = c->d_epart.p;
+  T.hdr = c->d_hdr.p;
+  T.node_pool = c->d_node_pool.p;
+  T.pool_cap = (int)c->d_node_pool.count;
+  T.atom_pool = c->d_atom_pool.p;
+  T.atom_pool_cap = (int)c->d_atom_pool.count;
+  T.status = c->d_status.p;
+  T.scratch = c->d_scratch.p;
+  T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
+}
+
+int allocate_work(agbnp_hip_context* c) {
+  const int n = c->n, nh = c->nh;
+  const size_t nhp = std::max(nh, 1);
+  // j-range splits: aim at ~2048 wavefronts per pair launch (256 CUs x 8)
+  const int nblk = (n + 63) / 64;
+  const int want = std::min(64, std::max(1, (2048 + nblk - 1) / nblk));
+  c->P.achunk = std::max(16, (n + want - 1) / want);
+  c->P.asplits = (n + c->P.achunk - 1) / c->P.achunk;
+  c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);
+  c->P.hsplits = std::max(1, (nh + c->P.hchunk - 1) / c->P.hchunk);
+  c->P.egb_parts = nblk * c->P.asplits;
+
+  HIP_TRY(c, c->d_status.alloc(kStatWords));
+  HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatWords));
+  HIP_TRY(c, c->d_hx.alloc(nhp));
+  HIP_TRY(c, c->d_hy.alloc(nhp));
+  HIP_TRY(c, c->d_hz.alloc(nhp));
+  HIP_TRY(c, c->d_gx.alloc(nhp));
+  HIP_TRY(c, c->d_gy.alloc(nhp));
+  HIP_TRY(c, c->d_gz.alloc(nhp));
+  HIP_TRY(c, c->d_sv_vdw.alloc(nhp));
+  HIP_TRY(c, c->d_sv_large.alloc(nhp));
+  HIP_TRY(c, c->d_gam.alloc(nhp));
+  HIP_TRY(c, c->d_epart.alloc(2 * nhp));
+  HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
+  HIP_TRY(c, c->d_aposq.alloc(n));
+  HIP_TRY(c, c->d_hposs.alloc(nhp));
+  HIP_TRY(c, c->d_born_part.alloc((size_t)c->P.hsplits * n));
+  HIP_TRY(c, c->d_born.alloc(n));
+  HIP_TRY(c, c->d_born_fp.alloc(n));
+  HIP_TRY(c, c->d_brw.alloc(n));
+  HIP_TRY(c, c->d_e_atom.alloc(n));
+  HIP_TRY(c, c->d_bws.alloc(n));
+  HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)c->P.asplits * n));
+  HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)c->P.asplits * n));
+  HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
+  HIP_TRY(c, c->d_components.alloc(4));
+  HIP_TRY(c, c->d_hdr.alloc(nhp));
+  HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nhp));
+  HIP_TRY(c, c->d_node_pool.alloc(std::max<size_t>(4096, nhp * 192)));
+  HIP_TRY(c, c->d_atom_pool.alloc(std::max<size_t>(1024, nhp * 64)));
+  HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
+  HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
+  HIP_TRY(c, c->d_energy_tmp.alloc(1));
+  c->h_force_tmp.resize(3 * (size_t)n);
+  return AGBNP_HIP_OK;
+}
+
+int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* d_energy, hipStream_t st) {
+  int rc = ensure_scratch(c);
+  if (rc != AGBNP_HIP_OK) return rc;
+  c->P.pos = d_pos;
+  HIP_TRY(c, launch_prep(c->P, st));
+  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->T, st));
+  if (c->version == 1) {
+    HIP_TRY(c, launch_pair_stages(c->P, st));
+    HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->T, st));
+  }
+  HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st));
+  return AGBNP_HIP_OK;
+}
+
+// after the stream is idle: read status + components; react to overflow.  *repeat = 1 if the caller must re-run.
+int harvest(agbnp_hip_context* c, int* repeat) {
+  *repeat = 0;
+  HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatWords, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
+  const int* s = c->last_status;
+  if (s[kStatNodeOverflow] || s[kStatAtomOverflow]) {
+    if (c->variant >= kGlobalVariant)
+      return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 1024 partners per heavy atom)");
+    c->variant++;
+    *repeat = 1;
+    return AGBNP_HIP_OK;
+  }
+  if (s[kStatPoolOverflow]) {
+    const size_t need_nodes = (size_t)s[kStatPoolUsed] + (size_t)s[kStatPoolUsed] / 4 + 1024;
+    const size_t need_atoms = (size_t)s[kStatAtomPoolUsed] + (size_t)s[kStatAtomPoolUsed] / 4 + 1024;
+    if (need_nodes > c->d_node_pool.count) HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
+    if (need_atoms > c->d_atom_pool.count) HIP_TRY(c, c->d_atom_pool.alloc(need_atoms));
+    wire_args(c);
+    *repeat = 1;
+    return AGBNP_HIP_OK;
+  }
+  c->have_results = true;
+  return AGBNP_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int agbnp_hip_device_count(void) {
+  int k = 0;
+  if (hipGetDeviceCount(&k) != hipSuccess) return 0;
+  return k;
+}
+
+const char* agbnp_hip_last_error(const agbnp_hip_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const double* gamma, const double* vdw_alpha,
+                     const double* charge, const int* ishydrogen, int version, int nonbonded_method, double cutoff, int device) {
+  auto bail = [&](int code, const std::string& msg, agbnp_hip_context* c) {
+    g_create_error = msg;
+    delete c;
+    if (out) *out = nullptr;
+    return code;
+  };
+  if (!out || n <= 0 || !radius || !gamma || !vdw_alpha || !charge || !ishydrogen)
+    return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_create: null pointer or non-positive particle count", nullptr);
+  if (version < 0 || version > 2) return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "AGBNPForce::setVersion(): illegal version number", nullptr);
+  if (version == 2)
+    return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_create: AGBNP version 2 is outside this engine's scope (versions 0 and 1 only)", nullptr);
+  if (nonbonded_method < 0 || nonbonded_method > 2)
+    return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_create: illegal nonbonded method", nullptr);
+
+  agbnp_hip_context* c = new agbnp_hip_context();
+  c->n = n;
+  c->version = version;
+  c->method = nonbonded_method;
+  c->cutoff = cutoff;
+  c->device = device;
+  c->r_vdw.assign(radius, radius + n);
+  c->gamma.resize(n);
+  c->alpha.assign(vdw_alpha, vdw_alpha + n);
+  c->charge.assign(charge, charge + n);
+  c->ish.resize(n);
+  c->a2h.assign(n, -1);
+  // parameter checks of ReferenceAGBNPKernels.cpp:96-117
+  double common_gamma = -1;
+  for (int i = 0; i < n; i++) {
+    const bool h = ishydrogen[i] != 0;
+    c->ish[i] = h ? 1 : 0;
+    c->gamma[i] = h ? 0.0 : gamma[i];
+    if (!(radius[i] > 0.0)) return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_create: particle radius must be positive", c);
+    if (common_gamma < 0 && !h) {
+      common_gamma = gamma[i];
+    } else if (!h && pow(common_gamma - gamma[i], 2) > FLT_MIN) {
+      return bail(AGBNP_HIP_ERR_PARAMETERS, "initialize(): AGBNP does not support multiple gamma values.", c);
+    }
+    if (!h) {
+      c->a2h[i] = (int)c->h2a.size();
+      c->h2a.push_back(i);
+    }
+  }
+  c->nh = (int)c->h2a.size();
+  c->lut.build(c->r_vdw, c->ish);
+
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev <= 0)
+    return bail(AGBNP_HIP_ERR_DEVICE, "agbnp_hip_create: no HIP device available (this engine has no CPU fallback)", c);
+  if (device < 0 || device >= ndev) return bail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_create: device index out of range", c);
+#define CREATE_TRY(call)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) return bail(AGBNP_HIP_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__), c); \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  CREATE_TRY(c->d_a2h.upload(c->a2h));
+  std::vector<int> h2a_pad = c->h2a;
+  if (h2a_pad.empty()) h2a_pad.push_back(0);
+  CREATE_TRY(c->d_h2a.upload(h2a_pad));
+  std::vector<int2> ameta(n), hmeta(std::max(c->nh, 1));
+  for (int i = 0; i < n; i++) ameta[i] = make_int2(c->lut.type_screened[i], c->lut.type_screener[i]);
+  for (int h = 0; h < c->nh; h++) hmeta[h] = make_int2(c->h2a[h], c->lut.type_screener[c->h2a[h]]);
+  CREATE_TRY(c->d_ameta.upload(ameta));
+  CREATE_TRY(c->d_hmeta.upload(hmeta));
+  const double dr = kI4MaxA / (kI4Nodes - 1);
+  std::vector<double2> lut(std::max<size_t>(1, c->lut.y.size()));
+  for (size_t k = 0; k < c->lut.y.size(); k++) lut[k] = make_double2(c->lut.y[k], c->lut.y2[k] * dr * dr / 6.0);
+  CREATE_TRY(c->d_lut.upload(lut));
+  if ((size_t)c->lut.y.size() * sizeof(double2) > 150 * 1024)
+    return bail(AGBNP_HIP_ERR_CAPACITY, "agbnp_hip_create: too many distinct radius pairs for the LDS-resident I4 tables", c);
+
+  int rc = upload_parameters(c);
+  if (rc != AGBNP_HIP_OK) return bail(rc, c->err, c);
+  rc = allocate_work(c);
+  if (rc != AGBNP_HIP_OK) return bail(rc, c->err, c);
+  wire_args(c);
+  *out = c;
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radius, const double* gamma, const double* vdw_alpha,
+                                const double* charge, const int* ishydrogen) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!radius || !gamma || !vdw_alpha || !charge || !ishydrogen) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n != c->n) return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: The number of AGBNP particles has changed");
+  for (int i = 0; i < n; i++) {
+    if (pow(c->r_vdw[i] - radius[i], 2) > 1.e-6)
+      return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: AGBNP plugin does not support changing atomic radii.");
+    if (ishydrogen[i] && c->ish[i] == 0)
+      return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: AGBNP plugin does not support changing heavy/hydrogen atoms.");
+  }
+  for (int i = 0; i < n; i++) {
+    c->gamma[i] = ishydrogen[i] ? 0.0 : gamma[i];
+    c->alpha[i] = vdw_alpha[i];
+    c->charge[i] = charge[i];
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = upload_parameters(c);
+  if (rc != AGBNP_HIP_OK) return rc;
+  wire_args(c);
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_execute_device(agbnp_hip_context* c, const double* d_pos, double* d_force, double* d_energy, void* stream) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!d_pos || !d_force || !d_energy) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_device: null pointer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  return enqueue(c, d_pos, d_force, d_energy, st);
+}
+
+int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  int dummy = 0;
+  if (!must_repeat) must_repeat = &dummy;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIP_TRY(c, hipStreamSynchronize(st));
+  return harvest(c, must_repeat);
+}
+
+int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forces, double* energy) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!pos || !forces || !energy) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_host: null pointer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, pos, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_force_tmp.p, 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_energy_tmp.p, 0, sizeof(double), c->stream));
+    int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, c->stream);
+    if (rc != AGBNP_HIP_OK) return rc;
+    double e = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(c->h_force_tmp.data(), c->d_force_tmp.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&e, c->d_energy_tmp.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int repeat = 0;
+    rc = harvest(c, &repeat);
+    if (rc != AGBNP_HIP_OK) return rc;
+    if (repeat) continue;
+    for (size_t k = 0; k < 3 * (size_t)c->n; k++) forces[k] += c->h_force_tmp[k];
+    *energy = e;
+    return AGBNP_HIP_OK;
+  }
+  return c->fail(AGBNP_HIP_ERR_CAPACITY, "agbnp_hip_execute_host: capacity negotiation did not converge");
+}
+
+int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
+  if (!c || !value) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");
+  switch (which) {
+    case 0: *value = c->last_components[0]; break;
+    case 1: *value = c->last_components[1]; break;
+    case 2: *value = c->last_components[2]; break;
+    case 3: *value = c->last_components[3]; break;
+    case 4: *value = c->last_status[kStatMaxNodes]; break;
+    case 5: *value = c->last_status[kStatTotalNodes]; break;
+    case 6: *value = c->variant; break;
+    case 7: *value = c->last_status[kStatMaxAtoms]; break;
+    default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
+  }
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
+  if (!c || !out) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int n = c->n, nh = c->nh;
+  std::vector<double> tmp(std::max(n, std::max(nh, 1)));
+  auto heavy_to_atoms = [&](const double* dsrc, double scale_by_inv_vol) -> int {
+    HIP_TRY(c, hipMemcpy(tmp.data(), dsrc, sizeof(double) * std::max(nh, 1), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) out[i] = 0.0;
+    for (int h = 0; h < nh; h++) {
+      double v = tmp[h];
+      if (scale_by_inv_vol != 0.0) v /= (4. * M_PI * pow(c->r_vdw[c->h2a[h]], 3) / 3.);
+      out[c->h2a[h]] = v;
+    }
+    return AGBNP_HIP_OK;
+  };
+  switch (which) {
+    case 0: return heavy_to_atoms(c->d_sv_vdw.p, 0.0);
+    case 1:
+      if (c->version != 1) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "Born radii exist for version 1 only");
+      HIP_TRY(c, hipMemcpy(out, c->d_born.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+      return AGBNP_HIP_OK;
+    case 2: return heavy_to_atoms(c->d_sv_vdw.p, 1.0);
+    case 3: return heavy_to_atoms(c->d_sv_large.p, 0.0);
+    default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown vector id");
+  }
+}
+
+int agbnp_hip_get_table_sizes(agbnp_hip_context* c, int* nscreened, int* nscreener) {
+  if (!c || !nscreened || !nscreener) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  *nscreened = c->lut.nscreened;
+  *nscreener = c->lut.nscreener;
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_screened, int* type_screener) {
+  if (!c || !y || !y2 || !type_screened || !type_screener) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  memcpy(y, c->lut.y.data(), sizeof(double) * c->lut.y.size());
+  memcpy(y2, c->lut.y2.data(), sizeof(double) * c->lut.y2.size());
+  memcpy(type_screened, c->lut.type_screened.data(), sizeof(int) * c->n);
+  memcpy(type_screener, c->lut.type_screener.data(), sizeof(int) * c->n);
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_host_tables(int n, const double* radius, const int* ishydrogen, int* nscreened, int* nscreener, double* y,
+                          double* y2, int table_capacity, int* type_screened, int* type_screener) {
+  if (n <= 0 || !radius || !ishydrogen || !nscreened || !nscreener || !y || !y2 || !type_screened || !type_screener) {
+    g_create_error = "agbnp_hip_host_tables: null pointer or non-positive particle count";
+    return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  }
+  I4TableSet t;
+  t.build(std::vector<double>(radius, radius + n), std::vector<int>(ishydrogen, ishydrogen + n));
+  *nscreened = t.nscreened;
+  *nscreener = t.nscreener;
+  if ((int)t.y.size() > table_capacity) {
+    g_create_error = "agbnp_hip_host_tables: table_capacity too small";
+    return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  }
+  memcpy(y, t.y.data(), sizeof(double) * t.y.size());
+  memcpy(y2, t.y2.data(), sizeof(double) * t.y2.size());
+  memcpy(type_screened, t.type_screened.data(), sizeof(int) * n);
+  memcpy(type_screener, t.type_screener.data(), sizeof(int) * n);
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_num_particles(const agbnp_hip_context* c) { return c ? c->n : -1; }
+int agbnp_hip_version(const agbnp_hip_context* c) { return c ? c->version : -1; }
+
+void agbnp_hip_destroy(agbnp_hip_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+}  // extern "C"

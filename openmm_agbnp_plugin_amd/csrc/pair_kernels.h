@@ -1,0 +1,51 @@
+// Argument block and launchers of the pair stages (see pair_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "agbnp_common.h"
+
+namespace agbnp {
+
+struct PairArgs {
+  int n, nh;
+  // ---- per-evaluation input
+  const double* pos;  // [3n] caller's positions (nm), atom order
+  // ---- static per-atom / per-heavy-atom parameters
+  const int* a2h;      // [n] atom -> heavy index or -1
+  const int* h2a;      // [nh]
+  const double* charge;    // [n]
+  const double* alpha;     // [n]
+  const double* inv_rvdw;  // [n] 1/R_i
+  const double* inv_vol_h;  // [nh] 1/(4 pi R^3/3), vdW radius
+  const double* gam_cav;   // [nh] gamma/roffset
+  const int2* ameta;       // [n] {screened type, screener type or -1}
+  const int2* hmeta;       // [nh] {atom index, screener type}
+  const double2* lut;      // [nti*ntj*16] {y, y2*dr^2/6}
+  int nti, ntj, lut_entries;
+  // ---- geometry (SoA for the tree, packed records for the pair loops)
+  double *hx, *hy, *hz;    // [nh]
+  double4* aposq;          // [n] {x,y,z,q}
+  double4* hposs;          // [nh] {x,y,z,s_j}
+  // ---- tree accumulators / outputs
+  double *gx, *gy, *gz;    // [nh]
+  double *sv_vdw, *sv_large;  // [nh]
+  double* gam;             // [nh] nu of the current tree pass
+  double* epart;           // [2nh]
+  int* status;
+  // ---- pair-stage intermediates
+  double* born_part;       // [hsplits][n]
+  double *born, *born_fp, *brw, *e_atom;  // [n]
+  double2* bws;            // [n] {brw+bru, scale}
+  double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [asplits][n]
+  double *db_fx, *db_fy, *db_fz, *db_wu;  // [asplits][n]
+  double* egb_part;        // [egb_parts]
+  int hsplits, hchunk;     // split of the heavy-atom j range (Born)
+  int asplits, achunk;     // split of the all-atom j range (GB, dBorn)
+  int egb_parts;
+};
+
+hipError_t launch_prep(const PairArgs& P, hipStream_t st);
+hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st);
+hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st);
+
+}  // namespace agbnp

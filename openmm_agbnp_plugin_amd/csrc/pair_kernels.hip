@@ -1,0 +1,371 @@
+// Pair stages of AGBNP1 on gfx950: inverse Born radii, GB pair energy/forces, Born-radius chain-rule
+// forces, plus the per-atom glue between them.
+//
+// Reference semantics (platforms/reference/src/ReferenceAGBNPKernels.cpp, restated in oracle run_v1()):
+//   :420-433  volume scaling factors s_i = selfvol_i / (4 pi R_i^3 / 3)
+//   :435-454  beta_i = 1/R_i - (1/4pi) sum_{j heavy, j!=i, d<2nm} s_j Q(d; type_i, type_j);  B_i, f'_i (:41-55)
+//   :464-504  GB pair energy, direct pair force, Y_i                         (ALL pairs, no cutoff)
+//   :513-542  van der Waals energy, brw_i, bru_i
+//   :555-586  chain-rule forces through the Born radii and the U_j / W_j sums
+//
+// Machine mapping: "row form".  A wavefront owns 64 consecutive i-atoms (one per lane, everything in
+// registers) and walks a contiguous range of j-atoms whose records are wave-uniform, so they arrive
+// through the scalar cache (s_load) and cost no vector memory traffic or LDS; the j range is split
+// over blockIdx.y to fill the chip, each split writes its own partial row and the next per-atom kernel
+// adds the partial rows in a fixed order (no atomics -> bit-reproducible).  Every pair is evaluated
+// from both ends instead of scattering the reaction force; the I4 spline tables sit in LDS.
+#include <hip/hip_runtime.h>
+
+#include "agbnp_common.h"
+#include "pair_kernels.h"
+
+namespace agbnp {
+
+// ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, y2_k*dr^2/6}) ------------------
+__device__ __forceinline__ double spline_value(const double2* __restrict__ tab, int base, double d) {
+  const double t = d * ((kI4Nodes - 1) / kI4MaxA);
+  int k = (int)t;
+  k = k > kI4Nodes - 2 ? kI4Nodes - 2 : k;
+  const double a = (double)(k + 1) - t;
+  const double b = 1.0 - a;
+  const double2 lo = tab[base + k], hi = tab[base + k + 1];
+  return a * lo.x + b * hi.x + (a * a * a - a) * lo.y + (b * b * b - b) * hi.y;
+}
+__device__ __forceinline__ void spline_value_deriv(const double2* __restrict__ tab, int base, double d, double& val, double& der) {
+  const double invdr = (kI4Nodes - 1) / kI4MaxA;
+  const double t = d * invdr;
+  int k = (int)t;
+  k = k > kI4Nodes - 2 ? kI4Nodes - 2 : k;
+  const double a = (double)(k + 1) - t;
+  const double b = 1.0 - a;
+  const double2 lo = tab[base + k], hi = tab[base + k + 1];
+  val = a * lo.x + b * hi.x + (a * a * a - a) * lo.y + (b * b * b - b) * hi.y;
+  der = ((hi.x - lo.x) + (1.0 - 3.0 * a * a) * lo.y + (3.0 * b * b - 1.0) * hi.y) * invdr;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- geometry in, accumulators cleared -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(PairArgs P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kStatWords && blockIdx.x == 0) P.status[i] = 0;
+  if (i >= P.n) return;
+  const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
+  P.aposq[i] = make_double4(x, y, z, P.charge[i]);
+  const int h = P.a2h[i];
+  if (h >= 0) {
+    P.hx[h] = x;
+    P.hy[h] = y;
+    P.hz[h] = z;
+    P.gx[h] = 0.0;
+    P.gy[h] = 0.0;
+    P.gz[h] = 0.0;
+    P.sv_vdw[h] = 0.0;
+    P.sv_large[h] = 0.0;
+    P.gam[h] = P.gam_cav[h];
+  }
+}
+
+// ---- volume scaling factors (ReferenceAGBNPKernels.cpp:420-433) packed with the heavy positions ---------
+__global__ __launch_bounds__(256) void k_scale(PairArgs P) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= P.nh) return;
+  P.hposs[h] = make_double4(P.hx[h], P.hy[h], P.hz[h], P.sv_vdw[h] * P.inv_vol_h[h]);
+}
+
+// ---- inverse Born radii: partial sums over a j range ---------------------------------------------------
+__global__ __launch_bounds__(64) void k_born_pairs(int n, int nh, int hchunk, int ntj, int lut_entries,
+                                                   const double4* __restrict__ aposq, const int2* __restrict__ ameta,
+                                                   const double4* __restrict__ hposs, const int2* __restrict__ hmeta,
+                                                   const double2* __restrict__ lut, double* __restrict__ born_part) {
+  extern __shared__ double2 s_lut[];
+  const int lane = threadIdx.x;
+  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
+  __syncthreads();
+  const int i = blockIdx.x * 64 + lane;
+  const bool valid = i < n;
+  const int ii = valid ? i : n - 1;
+  const double4 pi = aposq[ii];
+  const int tbase = ameta[ii].x * ntj;
+  const int j0 = blockIdx.y * hchunk;
+  const int j1 = min(nh, j0 + hchunk);
+  double sum = 0.0;
+  for (int j = j0; j < j1; j++) {
+    const double4 pj = hposs[j];  // wave-uniform -> scalar loads
+    const int2 mj = hmeta[j];
+    const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < kI4MaxA * kI4MaxA && mj.x != i) {
+      const double d = sqrt(d2);
+      sum += pj.w * spline_value(s_lut, (tbase + mj.y) * kI4Nodes, d);
+    }
+  }
+  if (valid) born_part[(size_t)blockIdx.y * n + i] = sum;
+}
+
+// ---- per atom: beta -> B, f', vdW energy, GB self energy, brw, scale factor -----------------------------
+__global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const double pifac = 1. / (4. * kPi);
+  double s = 0.0;
+  for (int js = 0; js < P.hsplits; js++) s += P.born_part[(size_t)js * P.n + i];
+  const double beta = P.inv_rvdw[i] - pifac * s;
+  // ReferenceAGBNPKernels.cpp:41-55
+  const double amin = 1. / kI4MaxA;
+  const double a2 = 1. / (kI4MaxA * kI4MaxA);
+  double t, fp;
+  if (beta < 0.0) {
+    t = amin;
+    fp = 0.0;
+  } else {
+    t = sqrt(a2 + beta * beta);
+    fp = beta / t;
+  }
+  const double br = 1. / t;
+  P.born[i] = br;
+  P.born_fp[i] = fp;
+  const double q = P.charge[i], alpha = P.alpha[i];
+  const double bh = br + kHBRadius;
+  const double bh3 = bh * bh * bh;
+  P.e_atom[i] = alpha / bh3 + kDielFactor * q * q / br;
+  P.brw[i] = -pifac * 3. * alpha * br * br * fp / (bh3 * bh);
+}
+
+// ---- GB pairs: every i against a j range (all atoms, no cutoff) ----------------------------------------
+__global__ __launch_bounds__(64) void k_gb_pairs(int n, int achunk, const double4* __restrict__ aposq,
+                                                 const double* __restrict__ born, double* __restrict__ gb_fx,
+                                                 double* __restrict__ gb_fy, double* __restrict__ gb_fz,
+                                                 double* __restrict__ gb_y, double* __restrict__ egb_part) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  const bool valid = i < n;
+  const int ii = valid ? i : n - 1;
+  const double4 pi = aposq[ii];
+  const double bi = born[ii];
+  const int j0 = blockIdx.y * achunk;
+  const int j1 = min(n, j0 + achunk);
+  double fx = 0, fy = 0, fz = 0, yacc = 0, eacc = 0;
+  for (int j = j0; j < j1; j++) {
+    const double4 pj = aposq[j];  // wave-uniform -> scalar loads
+    const double bj = born[j];
+    const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    const double qqf = pi.w * pj.w;
+    const double bb = bi * bj;
+    const double et = exp(-0.25 * d2 / bb);
+    const double fgb = rsqrt(d2 + bb * et);
+    const double fgb3 = fgb * fgb * fgb;
+    if (j != i) {
+      const double qq = kDielFactor * qqf;
+      eacc += qq * fgb;  // each unordered pair is met twice: 2*qq*fgb in total
+      const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
+      fx += dx * mw;
+      fy += dy * mw;
+      fz += dz * mw;
+      yacc += qqf * (bb + 0.25 * d2) * et * fgb3;
+    }
+  }
+  if (valid) {
+    const size_t o = (size_t)blockIdx.y * n + i;
+    gb_fx[o] = fx;
+    gb_fy[o] = fy;
+    gb_fz[o] = fz;
+    gb_y[o] = yacc;
+  } else {
+    eacc = 0.0;
+  }
+  const double e = wave_sum(eacc);
+  if (lane == 0) egb_part[blockIdx.y * gridDim.x + blockIdx.x] = e;
+}
+
+// ---- per atom: Y -> bru, bw = brw + bru ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const double pifac = 1. / (4. * kPi);
+  double y = 0.0;
+  for (int js = 0; js < P.asplits; js++) y += P.gb_y[(size_t)js * P.n + i];
+  const double q = P.charge[i], br = P.born[i];
+  const double bru = -pifac * kDielFactor * (q * q + y * br) * P.born_fp[i];
+  const int h = P.a2h[i];
+  P.bws[i] = make_double2(P.brw[i] + bru, h >= 0 ? P.hposs[h].w : 0.0);
+}
+
+// ---- Born-radius chain rule: forces + (W+U) sums ---------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, int lut_entries,
+                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
+                                                    const double2* __restrict__ bws, const double2* __restrict__ lut,
+                                                    double* __restrict__ db_fx, double* __restrict__ db_fy,
+                                                    double* __restrict__ db_fz, double* __restrict__ db_wu) {
+  extern __shared__ double2 s_lut[];
+  const int lane = threadIdx.x;
+  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
+  __syncthreads();
+  const int a = blockIdx.x * 64 + lane;
+  const bool valid = a < n;
+  const int aa = valid ? a : n - 1;
+  const double4 pa = aposq[aa];
+  const double2 wa = bws[aa];  // {bw_a, s_a}
+  const int2 ma = ameta[aa];   // {screened type, screener type}
+  const int j0 = blockIdx.y * achunk;
+  const int j1 = min(n, j0 + achunk);
+  double fx = 0, fy = 0, fz = 0, wu = 0;
+  for (int b = j0; b < j1; b++) {
+    const double4 pb = aposq[b];  // wave-uniform -> scalar loads
+    const double2 wb = bws[b];
+    const int2 mb = ameta[b];
+    const double dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < kI4MaxA * kI4MaxA && b != a) {
+      const double d = sqrt(d2);
+      double t = 0.0;
+      if (mb.y >= 0) {  // b descreens a
+        double q1, dq1;
+        spline_value_deriv(s_lut, (ma.x * ntj + mb.y) * kI4Nodes, d, q1, dq1);
+        t += wa.x * wb.y * dq1;
+      }
+      if (ma.y >= 0) {  // a descreens b
+        double q2, dq2;
+        spline_value_deriv(s_lut, (mb.x * ntj + ma.y) * kI4Nodes, d, q2, dq2);
+        wu += wb.x * q2;
+        t += wb.x * wa.y * dq2;
+      }
+      t /= d;
+      fx += dx * t;
+      fy += dy * t;
+      fz += dz * t;
+    }
+  }
+  if (valid) {
+    const size_t o = (size_t)blockIdx.y * n + a;
+    db_fx[o] = fx;
+    db_fy[o] = fy;
+    db_fz[o] = fz;
+    db_wu[o] = wu;
+  }
+}
+
+// ---- per heavy atom: nu_i = (W_i + U_i) / V_i for the pseudo-volume pass --------------------------------
+__global__ __launch_bounds__(256) void k_dborn_finish(PairArgs P) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= P.nh) return;
+  const int a = P.h2a[h];
+  double wu = 0.0;
+  for (int js = 0; js < P.asplits; js++) wu += P.db_wu[(size_t)js * P.n + a];
+  P.gam[h] = wu * P.inv_vol_h[h];
+}
+
+// ---- forces out (accumulated into the caller's buffer) -------------------------------------------------
+__global__ __launch_bounds__(256) void k_forces_out(PairArgs P, int version, double* __restrict__ force_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  double fx = 0, fy = 0, fz = 0;
+  const int h = P.a2h[i];
+  if (h >= 0) {  // cavity + pseudo-volume gradients -> force
+    fx = -P.gx[h];
+    fy = -P.gy[h];
+    fz = -P.gz[h];
+  }
+  if (version == 1) {
+    for (int js = 0; js < P.asplits; js++) {
+      const size_t o = (size_t)js * P.n + i;
+      fx += P.gb_fx[o] + P.db_fx[o];
+      fy += P.gb_fy[o] + P.db_fy[o];
+      fz += P.gb_fz[o] + P.db_fz[o];
+    }
+  }
+  force_out[3 * i] += fx;
+  force_out[3 * i + 1] += fy;
+  force_out[3 * i + 2] += fz;
+}
+
+// ---- energy: fixed-order sum of all partials -----------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_energy_out(PairArgs P, int version, double* __restrict__ energy_out,
+                                                     double* __restrict__ components) {
+  __shared__ double red[1024];
+  const int t = threadIdx.x;
+  double ecav1 = 0, ecav2 = 0, eatom = 0, egb = 0;
+  for (int h = t; h < P.nh; h += 1024) {
+    ecav1 += P.epart[2 * h];
+    ecav2 += P.epart[2 * h + 1];
+  }
+  if (version == 1) {
+    for (int i = t; i < P.n; i += 1024) eatom += P.e_atom[i];
+    for (int k = t; k < P.egb_parts; k += 1024) egb += P.egb_part[k];
+  }
+  double vals[4] = {ecav1, ecav2, eatom, egb};
+  double out[4];
+  for (int c = 0; c < 4; c++) {
+    red[t] = vals[c];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) red[t] += red[t + s];
+      __syncthreads();
+    }
+    out[c] = red[0];
+    __syncthreads();
+  }
+  if (t == 0) {
+    components[0] = out[0];
+    components[1] = out[1];
+    components[2] = out[2];
+    components[3] = out[3];
+    energy_out[0] += out[0] + out[1] + out[2] + out[3];
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------
+#define AGBNP_CHECK_LAUNCH()             \
+  do {                                   \
+    hipError_t e__ = hipGetLastError();  \
+    if (e__ != hipSuccess) return e__;   \
+  } while (0)
+
+hipError_t launch_prep(const PairArgs& P, hipStream_t st) {
+  const int n = P.n > kStatWords ? P.n : kStatWords;
+  hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st) {
+  const int nblk = (P.n + 63) / 64;
+  const size_t lds = (size_t)P.lut_entries * sizeof(double2);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_scale, dim3((P.nh + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(64), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
+                     (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_born_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(64), 0, st, P.n, P.achunk, (const double4*)P.aposq,
+                     (const double*)P.born, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_dborn_pairs, dim3(nblk, P.asplits), dim3(64), lds, st, P.n, P.achunk, P.ntj, P.lut_entries,
+                     (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_dborn_finish, dim3((P.nh + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_CHECK_LAUNCH();
+  return hipSuccess;
+}
+
+hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st) {
+  hipLaunchKernelGGL(k_forces_out, dim3((P.n + 255) / 256), dim3(256), 0, st, P, version, force_out);
+  AGBNP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_energy_out, dim3(1), dim3(1024), 0, st, P, version, energy_out, components);
+  AGBNP_CHECK_LAUNCH();
+  return hipSuccess;
+}
+
+}  // namespace agbnp
