@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the one hot path: AGBNP1 energy+force evaluation of thrombin (1dwc, 4152 atoms) on MI355X.
+
+A "step" = one complete AGBNP1 evaluation (positions resident in HBM -> forces and energy resident in
+HBM) of one replica on a new jittered geometry (file coordinates + N(0, 0.002 nm), so
+the overlap tree is rebuilt from a different geometry every step, as in MD).
+
+metric / value : aggregate AGBNP-force-limited ns/day over all replicas at the 1 fs step of the
+                 reference's example/1dwc_benchmark.py:20  ( ns/day = 86.4 / ms_per_eval per replica ).
+multi-GPU      : replicas only (the force evaluation does not shard).  One process per
+                 GPU, independent geometries, no data-path collective; RCCL carries only the timing
+                 reduction (MAX of the elapsed time) and the throughput gather.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import openmm_agbnp_plugin_amd as P  # noqa: E402  (loads the HIP runtime shared with torch)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(n_atoms, slots):
+    """SURVEY.md s.8d:  B_alg = S*128*8 + T*4096*4 + N*104  per AGBNP1 evaluation, and its split over the
+    kernels: tree sweeps 6 (cavity kernel) + 2 (pseudo-volume kernel); one 64x64 pair-tile
+    pass each for the 2-body search (cavity kernel), Born, GB and dBorn; per-atom I/O in prep/forces_out."""
+    nb = (n_atoms + 63) // 64
+    tiles = nb * (nb + 1) // 2
+    node, tile, atom = slots * 128, tiles * 4096, n_atoms * 104
+    per_kernel = {
+        "k_tree_cavity": 6 * node + tile,
+        "k_tree_pseudo": 2 * node,
+        "k_born_pairs": tile,
+        "k_gb_pairs": tile,
+        "k_dborn_pairs": tile,
+        "k_prep": atom // 2,
+        "k_forces_out": atom - atom // 2,
+    }
+    return 8 * node + 4 * tile + atom, per_kernel
+
+
+def gather_throughput(dist, local_ns_day, local_ms, device):
+    """All-gather of the per-replica {ns/day, ms/eval} records (2 doubles per rank); backend nccl (= RCCL over
+    xGMI) on GPUs, gloo in the CPU tests.  Returns a list of (ns_day, ms) per rank."""
+    import torch
+    rec = torch.tensor([local_ns_day, local_ms], dtype=torch.float64, device=device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [(float(rec[0]), float(rec[1]))]
+    out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, rec)
+    return [(float(t[0]), float(t[1])) for t in out]
+
+
+def max_over_ranks(dist, seconds, device):
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def cpu_baseline_leg(system, geometries, gpu_results, evals):
+    """The ONLY place bench.py touches the oracle: the CPU restatement timed on one host core over a bounded
+    sample of the same geometries.  As a by-product the sample's GPU results are compared with it."""
+    from oracle import Oracle
+    o = Oracle(*system.params(), version=1)
+    o.execute(geometries[0])  # warm caches / page in
+    t0 = time.perf_counter()
+    outs = [o.execute(geometries[k]) for k in range(evals)]
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / evals
+    de = max(abs(outs[k][0] - gpu_results[k][0]) for k in range(min(evals, len(gpu_results))))
+    df = max(float(np.abs(outs[k][1] - gpu_results[k][1]).max()) for k in range(min(evals, len(gpu_results))))
+    return ms, de, df
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--system", default="1dwc")
+    ap.add_argument("--cpu-evals", type=int, default=20, help="size of the CPU-baseline sample (0 disables the leg)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    K, W = args.steps, args.warmup
+    system = P.load_system(args.system)
+    n = system.n
+    force = P.AGBNPForce.from_arrays(*system.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)  # as example/1dwc_benchmark.py:10 (inert: Reference semantics)
+    force.setCutoffDistance(1.0)
+    kernel = P.HipCalcAGBNPForceKernel(device=local_rank)
+    kernel.initialize(force)
+
+    # synthetic geometries, different per replica; resident in HBM before the timed region
+    total = K + W
+    geoms = np.stack([system.jittered(1000 * rank + s) for s in range(total)])
+    d_pos = torch.tensor(geoms, dtype=torch.float64, device=device).contiguous()
+    d_force = torch.zeros((n, 3), dtype=torch.float64, device=device)
+    d_energy = torch.zeros((1,), dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    step_bytes = n * 3 * 8
+
+    def run_steps(first, count):
+        base = d_pos.data_ptr()
+        for s in range(first, first + count):
+            kernel.execute_device(base + s * step_bytes, d_force.data_ptr(), d_energy.data_ptr(), stream)
+
+    # warm-up (also settles the tree-capacity variant: repeat until no evaluation asks for a re-run)
+    for _ in range(4):
+        run_steps(0, max(W, 1))
+        if not kernel.finish(stream):
+            break
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    elapsed = None
+    for _ in range(3):
+        d_force.zero_()
+        d_energy.zero_()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(W, K)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        if not kernel.finish(stream):  # True = a capacity overflow invalidated the run: time it again
+            elapsed = t1 - t0
+            break
+    if elapsed is None:
+        raise SystemExit("bench: tree capacity did not settle")
+    elapsed = max_over_ranks(dist if world > 1 else None, elapsed, device)
+    ms_per_step = 1e3 * elapsed / K
+    local_ns_day = 86.4 / ms_per_step
+    per_rank = gather_throughput(dist if world > 1 else None, local_ns_day, ms_per_step, device)
+    value = world * 86.4 / ms_per_step  # whole job: all replicas' steps / max-over-ranks time
+
+    result = None
+    if rank == 0:
+        slots = int(kernel.scalar("total_nodes")) + (n - system.nheavy) + 1  # + hydrogen slots + root, as the reference counts
+        b_eval, b_kernel = algorithmic_bytes(n, slots)
+        result = {
+            "metric": "AGBNP1 force-eval-limited ns/day (1 fs step), thrombin 1dwc, independent replicas",
+            "value": value, "unit": "ns/day", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "force_eval_ms": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.system} (thrombin, {n} atoms, {system.nheavy} heavy) AGBNP1 version=1, "
+                                   "CutoffNonPeriodic 1.0 nm (Reference semantics: all pairs), one jittered geometry per step "
+                                   "(sigma 0.002 nm), positions/forces/energy resident in HBM",
+                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant"))},
+            "per_replica_ns_day": [round(r[0], 4) for r in per_rank],
+            "algorithmic_bytes_per_eval": b_eval,
+            "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
+        }
+
+    # ---- per-kernel durations: same K steps again with a hipEvent in front of every kernel (separate pass so
+    #      that the events do not sit inside the timed region above)
+    if rank == 0:
+        kernel.set_profiling(True)
+        run_steps(W, K)
+        kernel.finish(stream)
+        times = kernel.kernel_times()
+        kernel.set_profiling(False)
+        avg_us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in times.items() if v[1] > 0}
+        dominant = max(avg_us, key=avg_us.get)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_pmc.json")
+        if os.path.exists(tfile):
+            try:
+                rec = json.load(open(tfile))
+                if rec.get("kernel") == dominant and rec.get("system") == args.system:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = b_kernel.get(dominant, 0) / (avg_us[dominant] * 1e-6) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
+        result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
+        result["kernel_sum_us"] = round(sum(avg_us.values()), 2)
+
+    # ---- CPU baseline (rank 0, single replica only)
+    if rank == 0 and world == 1 and args.cpu_evals > 0:
+        evals = min(args.cpu_evals, K)
+        gpu_results = []
+        for k in range(evals):
+            f = np.zeros((n, 3))
+            e = kernel.execute(geoms[W + k], f)
+            gpu_results.append((e, f))
+        cpu_ms, de, df = cpu_baseline_leg(system, geoms[W:], gpu_results, evals)
+        result["cpu_baseline"] = {"value": 86.4 / cpu_ms, "unit": "ns/day", "ms_per_eval": cpu_ms, "cores": 1, "kind": "port",
+                                  "sample": f"first {evals} of the {K} timed geometries, single-threaded FP64 oracle (oracle/agbnp_oracle.cpp, g++ -O2)"}
+        result["parity_on_sample"] = {"max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df, "tolerance": 1e-4}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,14 @@ int agbnp_hip_get_tables(agbnp_hip_context* ctx, double* y, double* y2, int* typ
 int agbnp_hip_host_tables(int num_particles, const double* radius, const int* ishydrogen, int* nscreened, int* nscreener,
                           double* y, double* y2, int table_capacity, int* type_screened, int* type_screener);
 
+/* Per-kernel timing (bench support).  When enabled, a hipEvent is recorded on the evaluation's stream in front
+ * of every kernel; agbnp_hip_finish()/execute_host() turn them into accumulated milliseconds per kernel.
+ * Enabling or disabling resets the accumulators.  total_ms / launches must hold agbnp_hip_num_kernels() items. */
+int agbnp_hip_set_profiling(agbnp_hip_context* ctx, int enabled);
+int agbnp_hip_num_kernels(void);
+const char* agbnp_hip_kernel_name(int index);
+int agbnp_hip_get_kernel_times(agbnp_hip_context* ctx, double* total_ms, long* launches);
+
 int agbnp_hip_num_particles(const agbnp_hip_context* ctx);
 int agbnp_hip_version(const agbnp_hip_context* ctx);
 

@@ -214,6 +214,20 @@ class HipCalcAGBNPForceKernel:
         lib.agbnp_hip_get_tables(self._h, _dp(y), _dp(y2), _ip(ti), _ip(tj))
         return dict(y=y.reshape(ni.value, nj.value, 16), y2=y2.reshape(ni.value, nj.value, 16), type_screened=ti, type_screener=tj)
 
+    def set_profiling(self, enabled):
+        self._need()
+        _lib.load().agbnp_hip_set_profiling(self._h, 1 if enabled else 0)
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} accumulated since set_profiling(True)."""
+        self._need()
+        lib = _lib.load()
+        k = lib.agbnp_hip_num_kernels()
+        ms = np.zeros(k)
+        cnt = np.zeros(k, dtype=np.int64)
+        lib.agbnp_hip_get_kernel_times(self._h, _dp(ms), cnt.ctypes.data_as(C.POINTER(C.c_long)))
+        return {lib.agbnp_hip_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
+
     def release(self):
         if self._h is not None:
             _lib.load().agbnp_hip_destroy(self._h)

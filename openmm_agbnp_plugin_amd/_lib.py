@@ -1,7 +1,9 @@
 """ctypes binding of libagbnp_hip.so (C ABI: include/agbnp_hip.h).  There is no fallback: if the shared
 library is missing the import of any compute entry point raises, loudly."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libagbnp_hip.so")
@@ -14,15 +16,36 @@ SYMBOLS = [
     "agbnp_hip_finish", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
     "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
+    "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own libamdhip64.so
+    (SONAME libamdhip64.so.7) and asks for it by file name, so if this library pulled in /opt/rocm's copy
+    first, a later `import torch` would load a second runtime and find no GPU.  Loading torch's copy first
+    (without importing torch) makes both resolve to the same object.  Set AGBNP_HIP_SYSTEM_RUNTIME=1 to
+    keep the system runtime (processes that never import torch)."""
+    if os.environ.get("AGBNP_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def load():
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -46,6 +69,11 @@ def load():
     lib.agbnp_hip_destroy.argtypes = [vp]
     lib.agbnp_hip_destroy.restype = None
     lib.agbnp_hip_device_count.argtypes = []
+    lib.agbnp_hip_set_profiling.argtypes = [vp, C.c_int]
+    lib.agbnp_hip_num_kernels.argtypes = []
+    lib.agbnp_hip_kernel_name.argtypes = [C.c_int]
+    lib.agbnp_hip_kernel_name.restype = C.c_char_p
+    lib.agbnp_hip_get_kernel_times.argtypes = [vp, dp, C.POINTER(C.c_long)]
     for name in SYMBOLS:
         getattr(lib, name)  # AttributeError if the library does not export it
     _lib = lib

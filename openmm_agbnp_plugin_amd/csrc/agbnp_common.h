@@ -49,4 +49,10 @@ enum StatusWord {
   kStatWords = 16
 };
 
+// kernel ids of one evaluation, in launch order (bench/profiling support)
+enum KernelId {
+  kKPrep = 0, kKTreeCavity, kKScale, kKBornPairs, kKBornFinish, kKGbPairs, kKGbFinish, kKDbornPairs, kKDbornFinish,
+  kKTreePseudo, kKForcesOut, kKEnergyOut, kKernelCount
+};
+
 }  // namespace agbnp

@@ -98,6 +98,9 @@ struct agbnp_hip_context {
 
   PairArgs P{};
   TreeArgs T{};
+  Timeline timeline;
+  double kernel_ms[kKernelCount] = {0};
+  long kernel_launches[kKernelCount] = {0};
   int last_status[kStatWords] = {0};
   double last_components[4] = {0, 0, 0, 0};
   bool have_results = false;
@@ -303,19 +306,33 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   int rc = ensure_scratch(c);
   if (rc != AGBNP_HIP_OK) return rc;
   c->P.pos = d_pos;
-  HIP_TRY(c, launch_prep(c->P, st));
+  Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
+  HIP_TRY(c, launch_prep(c->P, st, tl));
+  if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
   HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->T, st));
   if (c->version == 1) {
-    HIP_TRY(c, launch_pair_stages(c->P, st));
+    HIP_TRY(c, launch_pair_stages(c->P, st, tl));
+    if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
     HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->T, st));
   }
-  HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st));
+  HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
   return AGBNP_HIP_OK;
 }
 
 // after the stream is idle: read status + components; react to overflow.  *repeat = 1 if the caller must re-run.
 int harvest(agbnp_hip_context* c, int* repeat) {
   *repeat = 0;
+  // per-kernel durations of everything enqueued since the last harvest
+  Timeline& tl = c->timeline;
+  for (size_t k = 0; k + 1 < tl.used; k++) {
+    const int id = tl.ids[k];
+    if (id < 0) continue;
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, tl.events[k], tl.events[k + 1]));
+    c->kernel_ms[id] += ms;
+    c->kernel_launches[id]++;
+  }
+  tl.used = 0;
   HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
@@ -566,6 +583,35 @@ int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_
   return AGBNP_HIP_OK;
 }
 
+int agbnp_hip_set_profiling(agbnp_hip_context* c, int enabled) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  c->timeline.enabled = enabled != 0;
+  c->timeline.used = 0;
+  for (int k = 0; k < kKernelCount; k++) {
+    c->kernel_ms[k] = 0.0;
+    c->kernel_launches[k] = 0;
+  }
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_num_kernels(void) { return kKernelCount; }
+
+const char* agbnp_hip_kernel_name(int index) {
+  static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_scale",       "k_born_pairs",
+                                            "k_born_finish", "k_gb_pairs",    "k_gb_finish",   "k_dborn_pairs",
+                                            "k_dborn_finish", "k_tree_pseudo", "k_forces_out",  "k_energy_out"};
+  return (index >= 0 && index < kKernelCount) ? names[index] : "";
+}
+
+int agbnp_hip_get_kernel_times(agbnp_hip_context* c, double* total_ms, long* launches) {
+  if (!c || !total_ms || !launches) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < kKernelCount; k++) {
+    total_ms[k] = c->kernel_ms[k];
+    launches[k] = c->kernel_launches[k];
+  }
+  return AGBNP_HIP_OK;
+}
+
 int agbnp_hip_host_tables(int n, const double* radius, const int* ishydrogen, int* nscreened, int* nscreener, double* y,
                           double* y2, int table_capacity, int* type_screened, int* type_screener) {
   if (n <= 0 || !radius || !ishydrogen || !nscreened || !nscreener || !y || !y2 || !type_screened || !type_screener) {
@@ -597,6 +643,7 @@ void agbnp_hip_destroy(agbnp_hip_context* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
+  for (hipEvent_t e : c->timeline.events) (void)hipEventDestroy(e);
   delete c;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "agbnp_common.h"
 
 namespace agbnp {
@@ -44,8 +46,30 @@ struct PairArgs {
   int egb_parts;
 };
 
-hipError_t launch_prep(const PairArgs& P, hipStream_t st);
-hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st);
-hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st);
+// Optional per-kernel timing: an event is recorded on the evaluation's stream in front of every kernel
+// (and one after the last); durations are read back after the stream has been synchronised.
+struct Timeline {
+  bool enabled = false;
+  std::vector<hipEvent_t> events;
+  std::vector<int> ids;  // kernel id that FOLLOWS events[k]; -1 = end of an evaluation
+  size_t used = 0;
+  hipError_t mark(int kernel_id, hipStream_t st) {
+    if (!enabled) return hipSuccess;
+    if (used == events.size()) {
+      hipEvent_t e;
+      hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      events.push_back(e);
+      ids.push_back(-1);
+    }
+    ids[used] = kernel_id;
+    return hipEventRecord(events[used++], st);
+  }
+};
+
+hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
+hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl);
+hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
+                          Timeline* tl);
 
 }  // namespace agbnp

@@ -325,13 +325,22 @@ __global__ __launch_bounds__(1024) void k_energy_out(PairArgs P, int version, do
     if (e__ != hipSuccess) return e__;   \
   } while (0)
 
-hipError_t launch_prep(const PairArgs& P, hipStream_t st) {
+#define AGBNP_MARK(id)                               \
+  do {                                               \
+    if (tl) {                                        \
+      hipError_t m__ = tl->mark(id, st);             \
+      if (m__ != hipSuccess) return m__;             \
+    }                                                \
+  } while (0)
+
+hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
+  AGBNP_MARK(kKPrep);
   const int n = P.n > kStatWords ? P.n : kStatWords;
   hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 
-hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st) {
+hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   const int nblk = (P.n + 63) / 64;
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
   if (lds > 48 * 1024) {
@@ -340,31 +349,42 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_scale, dim3((P.nh + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_MARK(kKScale);
+  hipLaunchKernelGGL(k_scale, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKBornPairs);
   hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(64), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
                      (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKBornFinish);
   hipLaunchKernelGGL(k_born_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKGbPairs);
   hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(64), 0, st, P.n, P.achunk, (const double4*)P.aposq,
                      (const double*)P.born, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKGbFinish);
   hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKDbornPairs);
   hipLaunchKernelGGL(k_dborn_pairs, dim3(nblk, P.asplits), dim3(64), lds, st, P.n, P.achunk, P.ntj, P.lut_entries,
                      (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
   AGBNP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_dborn_finish, dim3((P.nh + 255) / 256), dim3(256), 0, st, P);
+  AGBNP_MARK(kKDbornFinish);
+  hipLaunchKernelGGL(k_dborn_finish, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }
 
-hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st) {
+hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
+                          Timeline* tl) {
+  AGBNP_MARK(kKForcesOut);
   hipLaunchKernelGGL(k_forces_out, dim3((P.n + 255) / 256), dim3(256), 0, st, P, version, force_out);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(kKEnergyOut);
   hipLaunchKernelGGL(k_energy_out, dim3(1), dim3(1024), 0, st, P, version, energy_out, components);
   AGBNP_CHECK_LAUNCH();
+  AGBNP_MARK(-1);
   return hipSuccess;
 }
 

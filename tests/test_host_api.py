@@ -1,0 +1,114 @@
+"""CPU: host logic of the product (AGBNPForce mirror, C-ABI surface, host-side I4 tables).  No compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import openmm_agbnp_plugin_amd as P
+from openmm_agbnp_plugin_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "agbnp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(agbnp_hip_[a-z_]+)\s*\(", header)))
+    assert declared, "no declarations found in include/agbnp_hip.h"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"libagbnp_hip.so does not export {name}"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_force_defaults_match_reference():
+    f = P.AGBNPForce()
+    # AGBNPForce::AGBNPForce(): NoCutoff, cutoff 1.0, version 1, solvent radius 1.0*ANG (AGBNPForce.cpp:15)
+    assert f.getNonbondedMethod() == P.AGBNPForce.NoCutoff == 0
+    assert f.getCutoffDistance() == 1.0
+    assert f.getVersion() == 1
+    assert f.getSolventRadius() == pytest.approx(0.1, rel=1e-7)
+    assert f.getNumParticles() == 0
+    assert (P.AGBNPForce.CutoffNonPeriodic, P.AGBNPForce.CutoffPeriodic) == (1, 2)
+
+
+def test_particle_accessors_and_errors():
+    f = P.AGBNPForce()
+    assert f.addParticle(0.17, 48.9, -1.2, 0.3, False) == 0
+    assert f.addParticle(0.12, 0.0, 0.0, 0.1, True) == 1
+    assert f.getNumParticles() == 2
+    assert f.getParticleParameters(0) == (0.17, 48.9, -1.2, 0.3, False)
+    f.setParticleParameters(1, 0.125, 0.0, 0.0, -0.1, True)
+    assert f.getParticleParameters(1) == (0.125, 0.0, 0.0, -0.1, True)
+    with pytest.raises(P.OpenMMException):
+        f.getParticleParameters(2)
+    with pytest.raises(P.OpenMMException):
+        f.setParticleParameters(-1, 0.1, 0, 0, 0, False)
+    for v in (0, 1, 2):
+        f.setVersion(v)
+        assert f.getVersion() == v
+    for bad in (-1, 3):
+        with pytest.raises(P.OpenMMException, match="illegal version number"):
+            f.setVersion(bad)
+    f.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    f.setCutoffDistance(1.2)
+    assert f.getNonbondedMethod() == 1 and f.getCutoffDistance() == 1.2
+
+
+def test_create_reports_parameter_errors_before_touching_the_device(systems):
+    s = systems("fixture264")
+    g = s.gamma.copy()
+    g[np.flatnonzero(s.ishydrogen == 0)[5]] += 1.0
+    force = P.AGBNPForce.from_arrays(s.radius, g, s.alpha, s.charge, s.ishydrogen)
+    with pytest.raises(P.OpenMMException, match="does not support multiple gamma values"):
+        P.AGBNPContext(force)
+    force2 = P.AGBNPForce.from_arrays(*s.params())
+    force2.setVersion(2)
+    with pytest.raises(P.OpenMMException, match="version 2"):
+        P.AGBNPContext(force2)
+
+
+def test_no_cpu_fallback_without_device(systems):
+    if _lib.load().agbnp_hip_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    s = systems("fixture264")
+    with pytest.raises(P.OpenMMException, match="no HIP device"):
+        P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params()))
+
+
+@pytest.mark.parametrize("name", ["fixture264", "trpcage", "1dwc"])
+def test_host_i4_tables_match_oracle(systems, name):
+    from oracle import Oracle
+    s = systems(name)
+    t = P.host_tables(s.radius, s.ishydrogen)
+    o = Oracle(*s.params(), version=1).tables()
+    assert t["y"].shape == o["y"].shape
+    np.testing.assert_array_equal(t["type_screened"], o["type_screened"])
+    np.testing.assert_array_equal(t["type_screener"], o["type_screener"])
+    np.testing.assert_allclose(t["y"], o["y"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(t["y2"], o["y2"], rtol=1e-11, atol=1e-13)
+    # tables vanish at the 2.0 nm end (C2 switch, AGBNPUtils.cpp:102-130)
+    assert np.abs(t["y"][:, :, -1]).max() < 1e-12
+
+
+def test_radius_typing_truncates_to_1e4(systems):
+    r = np.array([0.17, 0.170004, 0.1701, 0.12, 0.12])
+    h = np.array([0, 0, 0, 1, 1], dtype=np.int32)
+    t = P.host_tables(r, h)
+    # long(r*10000): 0.17 and 0.170004 share a class; 0.1701 is its own; hydrogens never screen
+    assert t["type_screened"][0] == t["type_screened"][1] != t["type_screened"][2]
+    assert list(t["type_screener"][3:]) == [-1, -1]
+    assert t["y"].shape[:2] == (3, 2)
+
+
+def test_structure_parser_units(systems):
+    s = systems("fixture264")
+    # TestReferenceAGBNPForce.cpp:57-69: A -> nm, kcal/mol/A^2 -> kJ/mol/nm^2
+    assert s.n == 264 and s.nheavy == 136
+    assert s.pos[0, 0] == pytest.approx(-0.7364)
+    assert s.radius[1] == pytest.approx(0.165)
+    assert s.gamma[1] == pytest.approx(0.117 * 418.4)
+    assert s.alpha[1] < 0
+    j = s.jittered(3)
+    assert j.shape == s.pos.shape and 0 < np.abs(j - s.pos).max() < 0.02
+    np.testing.assert_array_equal(j, s.jittered(3))
