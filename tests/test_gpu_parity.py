@@ -131,7 +131,7 @@ def test_forces_accumulate_and_energy_is_returned(gpu_required, systems):
     e0 = k.execute(s.pos, f0)
     f1 = np.full((s.n, 3), -2.5)
     e1 = k.execute(s.pos, f1, includeForces=False, includeEnergy=False)  # flags are ignored, as in the reference
-    assert e1 == e0
+    assert abs(e1 - e0) < 1e-9  # FP64 atomics: summation order may differ in the last bits between runs
     np.testing.assert_allclose(f1 + 2.5, f0, rtol=0, atol=1e-9)
 
 
