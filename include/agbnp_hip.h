@@ -77,6 +77,7 @@ int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
  *          5 total tree nodes  6 kernel variant  7 max local atoms
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii) */
+int agbnp_hip_set_diagnostics(agbnp_hip_context* ctx, int enabled); /* vector 3 is only collected when enabled */
 int agbnp_hip_get_scalar(agbnp_hip_context* ctx, int which, double* value);
 int agbnp_hip_get_vector(agbnp_hip_context* ctx, int which, double* out);
 

@@ -214,6 +214,11 @@ class HipCalcAGBNPForceKernel:
         lib.agbnp_hip_get_tables(self._h, _dp(y), _dp(y2), _ip(ti), _ip(tj))
         return dict(y=y.reshape(ni.value, nj.value, 16), y2=y2.reshape(ni.value, nj.value, 16), type_screened=ti, type_screener=tj)
 
+    def set_diagnostics(self, enabled):
+        """Collect the pass-1 (enlarged radii) self volumes too (vector 'selfvol_large')."""
+        self._need()
+        _lib.load().agbnp_hip_set_diagnostics(self._h, 1 if enabled else 0)
+
     def set_profiling(self, enabled):
         self._need()
         _lib.load().agbnp_hip_set_profiling(self._h, 1 if enabled else 0)

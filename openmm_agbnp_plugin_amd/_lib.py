@@ -6,7 +6,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagbnp_hip.so")
+LIB_PATH = os.environ.get("AGBNP_HIP_LIBRARY") or os.path.join(_HERE, "libagbnp_hip.so")  # override: diagnostic builds only
 
 OK, ERR_INVALID_ARGUMENT, ERR_PARAMETERS, ERR_DEVICE, ERR_CAPACITY = 0, 1, 2, 3, 4
 
@@ -16,7 +16,7 @@ SYMBOLS = [
     "agbnp_hip_finish", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
     "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
-    "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
+    "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
 ]
 
 _lib = None
@@ -69,6 +69,7 @@ def load():
     lib.agbnp_hip_destroy.argtypes = [vp]
     lib.agbnp_hip_destroy.restype = None
     lib.agbnp_hip_device_count.argtypes = []
+    lib.agbnp_hip_set_diagnostics.argtypes = [vp, C.c_int]
     lib.agbnp_hip_set_profiling.argtypes = [vp, C.c_int]
     lib.agbnp_hip_num_kernels.argtypes = []
     lib.agbnp_hip_kernel_name.argtypes = [C.c_int]

@@ -29,6 +29,7 @@ namespace agbnp {
 size_t tree_variant_lds_bytes(int variant);
 size_t tree_variant_scratch_bytes(int variant);
 int tree_variant_node_cap(int variant);
+int tree_variant_atom_cap(int variant);
 hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
 hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
@@ -104,6 +105,7 @@ struct agbnp_hip_context {
   int last_status[kStatWords] = {0};
   double last_components[4] = {0, 0, 0, 0};
   bool have_results = false;
+  bool diagnostics = false;
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -172,6 +174,18 @@ int upload_parameters(agbnp_hip_context* c) {
 }
 
 int ensure_scratch(agbnp_hip_context* c) {
+  // topology store: fixed stride per subtree, sized for the current variant
+  const size_t nhp = std::max(c->nh, 1);
+  const size_t need_nodes = nhp * (size_t)tree_variant_node_cap(c->variant);
+  const size_t need_atoms = nhp * (size_t)tree_variant_atom_cap(c->variant);
+  if (c->d_node_pool.count < need_nodes) {
+    HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
+    c->T.node_pool = c->d_node_pool.p;
+  }
+  if (c->d_atom_pool.count < need_atoms) {
+    HIP_TRY(c, c->d_atom_pool.alloc(need_atoms));
+    c->T.atom_pool = c->d_atom_pool.p;
+  }
   if (c->variant != kGlobalVariant) return AGBNP_HIP_OK;
   const size_t stride = tree_variant_scratch_bytes(kGlobalVariant);
   const size_t need = stride * (size_t)std::min(kGlobalGrid, std::max(c->nh, 1));
@@ -241,14 +255,13 @@ void wire_args(agbnp_hip_context* c) {
   T.gx = c->d_gx.p;
   T.gy = c->d_gy.p;
   T.gz = c->d_gz.p;
-  T.sv_large = c->d_sv_large.p;
+  T.sv_large = c->diagnostics ? c->d_sv_large.p : nullptr;  // pass-1 self volumes cost extra HBM atomics: opt-in
   T.sv_vdw = c->d_sv_vdw.p;
   T.epart = c->d_epart.p;
   T.hdr = c->d_hdr.p;
   T.node_pool = c->d_node_pool.p;
-  T.pool_cap = (int)c->d_node_pool.count;
   T.atom_pool = c->d_atom_pool.p;
-  T.atom_pool_cap = (int)c->d_atom_pool.count;
+  P.hdr = c->d_hdr.p;
   T.status = c->d_status.p;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
@@ -293,8 +306,6 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_components.alloc(4));
   HIP_TRY(c, c->d_hdr.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nhp));
-  HIP_TRY(c, c->d_node_pool.alloc(std::max<size_t>(4096, nhp * 192)));
-  HIP_TRY(c, c->d_atom_pool.alloc(std::max<size_t>(1024, nhp * 64)));
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
@@ -340,15 +351,6 @@ int harvest(agbnp_hip_context* c, int* repeat) {
     if (c->variant >= kGlobalVariant)
       return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 1024 partners per heavy atom)");
     c->variant++;
-    *repeat = 1;
-    return AGBNP_HIP_OK;
-  }
-  if (s[kStatPoolOverflow]) {
-    const size_t need_nodes = (size_t)s[kStatPoolUsed] + (size_t)s[kStatPoolUsed] / 4 + 1024;
-    const size_t need_atoms = (size_t)s[kStatAtomPoolUsed] + (size_t)s[kStatAtomPoolUsed] / 4 + 1024;
-    if (need_nodes > c->d_node_pool.count) HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
-    if (need_atoms > c->d_atom_pool.count) HIP_TRY(c, c->d_atom_pool.alloc(need_atoms));
-    wire_args(c);
     *repeat = 1;
     return AGBNP_HIP_OK;
   }
@@ -562,7 +564,9 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
       HIP_TRY(c, hipMemcpy(out, c->d_born.p, sizeof(double) * n, hipMemcpyDeviceToHost));
       return AGBNP_HIP_OK;
     case 2: return heavy_to_atoms(c->d_sv_vdw.p, 1.0);
-    case 3: return heavy_to_atoms(c->d_sv_large.p, 0.0);
+    case 3:
+      if (!c->diagnostics) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "enlarged-radius self volumes need agbnp_hip_set_diagnostics(ctx, 1) before the evaluation");
+      return heavy_to_atoms(c->d_sv_large.p, 0.0);
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown vector id");
   }
 }
@@ -580,6 +584,13 @@ int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_
   memcpy(y2, c->lut.y2.data(), sizeof(double) * c->lut.y2.size());
   memcpy(type_screened, c->lut.type_screened.data(), sizeof(int) * c->n);
   memcpy(type_screener, c->lut.type_screener.data(), sizeof(int) * c->n);
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_set_diagnostics(agbnp_hip_context* c, int enabled) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  c->diagnostics = enabled != 0;
+  wire_args(c);
   return AGBNP_HIP_OK;
 }
 

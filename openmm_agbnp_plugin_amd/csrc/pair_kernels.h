@@ -33,6 +33,7 @@ struct PairArgs {
   double *sv_vdw, *sv_large;  // [nh]
   double* gam;             // [nh] nu of the current tree pass
   double* epart;           // [2nh]
+  const SubtreeHeader* hdr;  // [nh] written by the tree kernel (node counts for the statistics words)
   int* status;
   // ---- pair-stage intermediates
   double* born_part;       // [hsplits][n]

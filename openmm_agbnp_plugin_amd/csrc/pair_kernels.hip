@@ -309,7 +309,30 @@ __global__ __launch_bounds__(1024) void k_energy_out(PairArgs P, int version, do
     out[c] = red[0];
     __syncthreads();
   }
+  // tree statistics of this evaluation (diagnostics): total / max nodes, max local atoms
+  __shared__ int ired[1024];
+  int tot = 0, mx = 0, ma = 0;
+  for (int h = t; h < P.nh; h += 1024) {
+    const int nn = P.hdr[h].nnodes, na = P.hdr[h].natoms;
+    tot += nn;
+    mx = nn > mx ? nn : mx;
+    ma = na > ma ? na : ma;
+  }
+  int ivals[3] = {tot, mx, ma};
+  for (int c = 0; c < 3; c++) {
+    ired[t] = ivals[c];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) ired[t] = c == 0 ? ired[t] + ired[t + s] : (ired[t] > ired[t + s] ? ired[t] : ired[t + s]);
+      __syncthreads();
+    }
+    ivals[c] = ired[0];
+    __syncthreads();
+  }
   if (t == 0) {
+    P.status[kStatTotalNodes] = ivals[0];
+    P.status[kStatMaxNodes] = ivals[1];
+    P.status[kStatMaxAtoms] = ivals[2];
     components[0] = out[0];
     components[1] = out[1];
     components[2] = out[2];

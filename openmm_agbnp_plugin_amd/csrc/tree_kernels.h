@@ -1,7 +1,7 @@
 // GaussVol overlap-tree kernels for gfx950 (MI355X).
 //
-// One 64-lane wavefront owns the complete overlap subtree rooted at one heavy atom and keeps it in
-// LDS for its whole life: build (large radii) -> bottom-up volume pass -> top-down rescan with vdW
+// One workgroup (BS = 64..256 lanes) owns the complete overlap subtree rooted at one heavy atom and keeps
+// it in LDS for its whole life: build (large radii) -> bottom-up volume pass -> top-down rescan with vdW
 // radii -> second bottom-up pass, all inside one launch.  Only per-atom sums (gradients, self
 // volumes), one energy pair per subtree and the 8-byte/node topology leave the CU.
 //
@@ -14,12 +14,13 @@
 //   rescan     : gaussvol/gaussvol.cpp:254-327 (volumes) and :330-372 (gammas only)
 //
 // Design differences from the reference (same numbers, different machine):
-//   * breadth-first node order inside a subtree (levels contiguous) so that both sweeps are
+//   * breadth-first node order inside a subtree (levels contiguous) so that expansion and both sweeps are
 //     lane-parallel over a level; the reference is depth-first recursive.
+//   * level-synchronous expansion: every (node, younger sibling) pair of a level is one task = one lane;
+//     tasks -> switched volumes in LDS -> per-node child counts (prefix sum) -> per-task rank inside its
+//     node's kept set -> children written directly at their sorted position.
 //   * per-node derived quantities (switched volume, sfp, dv1, dvv1) are recomputed from
 //     (parent Gaussian, atom Gaussian) in the sweep instead of being stored: 7 doubles/node in LDS.
-//   * child compaction = wave ballot + mbcnt prefix; child ordering = in-register rank sort with
-//     v_readlane broadcasts (no LDS traffic, no barrier) for up to 64 candidates.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,30 +41,42 @@ struct TreeArgs {
   double* sv_vdw;     // [nh] self volumes with vdW radii
   double* epart;      // [2*nh] cavity energies E1,E2 per subtree
   SubtreeHeader* hdr;  // [nh]
-  ushort4* node_pool;
-  int pool_cap;
-  int* atom_pool;
-  int atom_pool_cap;
+  ushort4* node_pool;  // [nh][NCAP] topology records, fixed stride per subtree (variant-dependent)
+  int* atom_pool;      // [nh][ACAP] local atom -> heavy index
   int* status;  // [kStatWords]
   char* scratch;  // GLOBAL variant: per-workgroup slab
   size_t scratch_stride;
 };
 
+constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of the BS template parameter)
+
 // ---- LDS / scratch carve-out -----------------------------------------------------------------
 template <int NCAP, int ACAP>
 struct TreeStore {
-  double* nd[7];   // node slots: 0-2 centre, 3 exponent, 4 unswitched volume, 5 gamma_1..i, 6 spare
+  static constexpr int TCAP = 8 * ACAP;  // tasks per expansion batch (tmap bytes live in cand_vol, volumes in nd[6])
+  static_assert(TCAP <= NCAP, "task volumes are staged in the spare node slot");
+  static_assert(2 * ACAP <= NCAP, "level-2 staging slots must not collide with the level-2 nodes");
+  double* nd[7];   // node slots: 0-2 centre, 3 exponent, 4 unswitched volume, 5 gamma_1..i, 6 scratch (task volumes)
                    // after the bottom-up sweep of a node: 0 psi', 1 E, 2 F_E, 3-5 P_E
   double* at[10];  // local atoms: 0-2 centre, 3 exponent, 4 volume, 5 gamma, 6-8 gradient acc, 9 self-volume acc
-  double* cand_vol;
-  double* misc;    // [4]: 0 energy accumulator
-  int* cand_idx;
-  int* at_gidx;
-  int* lvl;        // [12]
-  unsigned short *nla, *npar, *ncs, *ncc;
+  double* cand_vol;  // [ACAP] level-2 candidate volumes; reused as the task->node byte map of a batch
+  double* misc;      // [4]: 0 energy accumulator
+  int* cand_idx;     // [ACAP]
+  int* at_gidx;      // [ACAP]
+  int* lvl;          // [12]
+  int* ctl;          // [12] workgroup control words (counters, scan partials)
+  unsigned short *nla, *npar, *ncs, *ncc;  // [NCAP]
+  unsigned short *tstart, *cbase;          // [kTreeBlock + 2] per-batch task start / child base
+#ifdef AGBNP_STAMPS
+  unsigned long long* stamps;  // [16] diagnostic build only
+  static constexpr size_t kStampBytes = 16 * sizeof(unsigned long long) + 8;
+#else
+  static constexpr size_t kStampBytes = 0;
+#endif
 
   static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 4) +
-                                   sizeof(int) * (2 * (size_t)ACAP + 12) + sizeof(unsigned short) * 4 * (size_t)NCAP;
+                                   sizeof(int) * (2 * (size_t)ACAP + 24) +
+                                   sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + kStampBytes;
 
   __device__ __forceinline__ void carve(char* base) {
     double* d = reinterpret_cast<double*>(base);
@@ -82,11 +95,18 @@ struct TreeStore {
     ip += ACAP;
     lvl = ip;
     ip += 12;
+    ctl = ip;
+    ip += 12;
     unsigned short* sp = reinterpret_cast<unsigned short*>(ip);
     nla = sp;
     npar = sp + NCAP;
     ncs = sp + 2 * (size_t)NCAP;
     ncc = sp + 3 * (size_t)NCAP;
+    tstart = sp + 4 * (size_t)NCAP;
+    cbase = tstart + (kTreeBlock + 2);
+#ifdef AGBNP_STAMPS
+    stamps = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(cbase + (kTreeBlock + 2)) + 7) & ~(uintptr_t)7);
+#endif
   }
 };
 
@@ -98,6 +118,14 @@ struct Merged {
   double dvx, dvy, dvz;  // dv1 = (c2-c1) * (-dVdr)
   double dvv1;           // dV/dV1 (unswitched)
 };
+
+// 1/x to ~1 ulp: hardware seed + two Newton steps (an IEEE divide costs ~4x as many instructions)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 
 __device__ __forceinline__ double dev_switch(double gvol, double& sp) {
   // gaussvol.cpp:18-41 with volmina/volminb = VOLMINA/VOLMINB
@@ -119,16 +147,29 @@ __device__ __forceinline__ double dev_switch(double gvol, double& sp) {
   return s;
 }
 
+// switched overlap volume only (the keep test and the sort key of the expansion)
+__device__ __forceinline__ double dev_merge_volume(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
+                                                   double z2, double a2, double v2) {
+  const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  const double df = a1 * a2 * fast_rcp(a1 + a2);
+  const double q = df * (1.0 / kPi);
+  const double gvol = v1 * (v2 * (q * sqrt(q)) * exp(-df * d2));  // same association as dev_merge
+  double sp;
+  return dev_switch(gvol, sp) * gvol;
+}
+
 __device__ __forceinline__ void dev_merge(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
                                           double z2, double a2, double v2, Merged& m) {
   const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
   const double d2 = dx * dx + dy * dy + dz * dz;
   const double a12 = a1 + a2;
-  const double deltai = 1.0 / a12;
+  const double deltai = fast_rcp(a12);
   const double df = a1 * a2 * deltai;
   const double ef = exp(-df * d2);
   const double q = df * (1.0 / kPi);
-  const double gvol = (v1 * v2) * (q * sqrt(q)) * ef;
+  const double per_v1 = v2 * (q * sqrt(q)) * ef;  // dV12/dV1 (unswitched); the reference forms gvol/v1
+  const double gvol = v1 * per_v1;
   const double mdVdr = 2.0 * df * gvol;  // -(dV/dr)/r
   m.x = (x1 * a1 + x2 * a2) * deltai;
   m.y = (y1 * a1 + y2 * a2) * deltai;
@@ -142,95 +183,77 @@ __device__ __forceinline__ void dev_merge(double x1, double y1, double z1, doubl
   m.dvx = dx * mdVdr;
   m.dvy = dy * mdVdr;
   m.dvz = dz * mdVdr;
-  m.dvv1 = v1 > 0 ? gvol / v1 : 0.0;
+  m.dvv1 = v1 > 0 ? per_v1 : 0.0;
 }
 
-// ---- wave helpers --------------------------------------------------------------------------------
+// ---- wave / workgroup helpers -------------------------------------------------------------------
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int k) {
-  unsigned long long u = __double_as_longlong(v);
-  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, k);
-  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), k);
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
 __device__ __forceinline__ void lds_add(double* p, double v) {
-  // LDS / global FP64 add; with -munsafe-fp-atomics this is ds_add_f64 / global_atomic_add_f64
+  // LDS FP64 add; with -munsafe-fp-atomics this is ds_add_f64
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void glb_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
-
-// ---- rank + append a candidate list held in S.cand_vol / S.cand_idx --------------------------------
-// FROM_GLOBAL: candidates are heavy-atom indices (level-2 search); they also become local atoms.
-// otherwise  : candidates are sibling node slots.
-template <int NCAP, int ACAP, bool FROM_GLOBAL>
-__device__ __forceinline__ void append_ranked(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int lane, int head, int ncand,
-                                              int tail, double x1, double y1, double z1, double a1, double v1, double gam1i) {
-  for (int c = lane; c < ncand; c += 64) {
-    const double my = S.cand_vol[c];
-    int rank = 0;
-    for (int k = 0; k < ncand; k++) {
-      const double vk = S.cand_vol[k];
-      rank += (vk > my || (vk == my && k < c)) ? 1 : 0;
-    }
-    const int slot = tail + rank;
-    int la;
-    double x2, y2, z2, a2, v2, g2;
-    if (FROM_GLOBAL) {
-      const int hj = S.cand_idx[c];
-      la = slot;  // level-2 node k <-> local atom k
-      x2 = A.hx[hj];
-      y2 = A.hy[hj];
-      z2 = A.hz[hj];
-      a2 = A.a_large[hj];
-      v2 = A.v_large[hj];
-      g2 = A.gam[hj];
-      S.at[0][la] = x2;
-      S.at[1][la] = y2;
-      S.at[2][la] = z2;
-      S.at[3][la] = a2;
-      S.at[4][la] = v2;
-      S.at[5][la] = g2;
-      S.at_gidx[la] = hj;
-    } else {
-      la = S.nla[S.cand_idx[c]];
-      x2 = S.at[0][la];
-      y2 = S.at[1][la];
-      z2 = S.at[2][la];
-      a2 = S.at[3][la];
-      v2 = S.at[4][la];
-      g2 = S.at[5][la];
-    }
-    Merged m;
-    dev_merge(x1, y1, z1, a1, v1, x2, y2, z2, a2, v2, m);
-    S.nd[0][slot] = m.x;
-    S.nd[1][slot] = m.y;
-    S.nd[2][slot] = m.z;
-    S.nd[3][slot] = m.a;
-    S.nd[4][slot] = m.v;
-    S.nd[5][slot] = gam1i + g2;
-    S.nla[slot] = (unsigned short)la;
-    S.npar[slot] = (unsigned short)head;
-    S.ncs[slot] = 0;
-    S.ncc[slot] = 0;
+// inclusive scan of one int per thread over the workgroup; *total = sum over all threads.
+// `part` = BS/64 ints of LDS.  Contains two barriers.
+template <int BS>
+__device__ __forceinline__ int block_inclusive_scan(int v, int tid, int* part, int* total) {
+  const int lane = tid & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
   }
+  if (BS == 64) {
+    *total = __shfl(v, 63, 64);
+    return v;
+  }
+  const int w = tid >> 6;
+  if (lane == 63) part[w] = v;
+  __syncthreads();
+  int add = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < BS / 64; i++) {
+    const int s = part[i];
+    if (i < w) add += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return v + add;
 }
 
+#ifdef AGBNP_STAMPS
+#define AGBNP_BUILD_STAMP(i)                                         \
+  do {                                                               \
+    if (tid == 0) {                                                  \
+      const unsigned long long t_now__ = __builtin_readcyclecounter(); \
+      S.stamps[i] += t_now__ - tb_prev__;                            \
+      tb_prev__ = t_now__;                                           \
+    }                                                                \
+  } while (0)
+#define AGBNP_BUILD_STAMP_BEGIN() unsigned long long tb_prev__ = __builtin_readcyclecounter()
+#else
+#define AGBNP_BUILD_STAMP(i)
+#define AGBNP_BUILD_STAMP_BEGIN()
+#endif
+
+enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
+
 // ---- build the subtree of heavy atom `hi` (large radii) ---------------------------------------------
-// returns BuildResult; on success *nnodes_out / *natoms_out are set (wave-uniform)
-template <int NCAP, int ACAP>
-__device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int lane, int hi, int* nnodes_out,
+// returns BuildResult (workgroup-uniform); on success *nnodes_out / *natoms_out are set
+template <int NCAP, int ACAP, int BS>
+__device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, int hi, int* nnodes_out,
                              int* natoms_out) {
+  constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
+  AGBNP_BUILD_STAMP_BEGIN();
   const double rx = A.hx[hi], ry = A.hy[hi], rz = A.hz[hi];
   const double ra = A.a_large[hi], rv = A.v_large[hi], rg = A.gam[hi];
-  if (lane == 0) {
+  if (tid == 0) {
     S.at[0][0] = rx;
     S.at[1][0] = ry;
     S.at[2][0] = rz;
@@ -249,40 +272,89 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     S.ncs[0] = 1;
     S.ncc[0] = 0;
     S.misc[0] = 0.0;
+    S.ctl[0] = 0;  // level-2 candidate counter
   }
-  // ---- level 2: all heavy atoms with a larger index whose overlap with the root survives the switch
-  int ncand = 0;
-  for (int base = hi + 1; base < A.nh; base += 64) {
-    const int hj = base + lane;
+  __syncthreads();
+
+  // ---- level 2: all heavy atoms with a larger index whose overlap with the root survives the switch.
+  // Each wave compacts its hits (ballot + mbcnt) and reserves room with one LDS add; a hit parks its atom
+  // record in the (still unused) upper node slots so that ranking never goes back to HBM.
+  for (int base = hi + 1; base < A.nh; base += BS) {
+    const int hj = base + tid;
     bool keep = false;
-    double sv = 0.0;
+    double sv = 0.0, xj = 0, yj = 0, zj = 0, aj = 0, vj = 0;
     if (hj < A.nh) {
-      const double xj = A.hx[hj], yj = A.hy[hj], zj = A.hz[hj];
+      xj = A.hx[hj];
+      yj = A.hy[hj];
+      zj = A.hz[hj];
       const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
       const double d2 = dx * dx + dy * dy + dz * dz;
       if (d2 < A.rcut2) {
-        Merged m;
-        dev_merge(rx, ry, rz, ra, rv, xj, yj, zj, A.a_large[hj], A.v_large[hj], m);
-        sv = m.vol;
+        aj = A.a_large[hj];
+        vj = A.v_large[hj];
+        sv = dev_merge_volume(rx, ry, rz, ra, rv, xj, yj, zj, aj, vj);
         keep = sv > kMinGvol;
       }
     }
     const unsigned long long mask = __ballot(keep);
     if (mask) {
-      const int cnt = __popcll(mask);
-      if (ncand + cnt > ACAP - 1) return kBuildAtomOverflow;
+      int wbase = 0;
+      if ((tid & 63) == 0) wbase = atomicAdd(&S.ctl[0], __popcll(mask));
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
       if (keep) {
-        const int p = ncand + lane_prefix(mask);
-        S.cand_vol[p] = sv;
-        S.cand_idx[p] = hj;
+        const int p = wbase + lane_prefix(mask);
+        if (p < ACAP - 1) {
+          S.cand_vol[p] = sv;
+          S.cand_idx[p] = hj;
+          const int st = NCAP - 1 - p;  // staging slot (level-2 nodes land in 1..ncand <= ACAP-1 < NCAP-ACAP)
+          S.nd[0][st] = xj;
+          S.nd[1][st] = yj;
+          S.nd[2][st] = zj;
+          S.nd[3][st] = aj;
+          S.nd[4][st] = vj;
+          S.nd[5][st] = A.gam[hj];
+        }
       }
-      ncand += cnt;
     }
   }
-  if (1 + ncand > NCAP) return kBuildNodeOverflow;
   __syncthreads();
-  append_ranked<NCAP, ACAP, true>(S, A, lane, 0, ncand, 1, rx, ry, rz, ra, rv, rg);
-  if (lane == 0) {
+  AGBNP_BUILD_STAMP(8);
+  const int ncand = S.ctl[0];
+  if (ncand > ACAP - 1) return kBuildAtomOverflow;
+  if (1 + ncand > NCAP) return kBuildNodeOverflow;
+  // rank by switched volume (descending; exact ties by atom index) and create local atoms + level-2 nodes
+  for (int c = tid; c < ncand; c += BS) {
+    const double my = S.cand_vol[c];
+    const int hj = S.cand_idx[c];
+    int rank = 0;
+    for (int k = 0; k < ncand; k++) {
+      const double vk = S.cand_vol[k];
+      rank += (vk > my || (vk == my && S.cand_idx[k] < hj)) ? 1 : 0;
+    }
+    const int slot = 1 + rank;  // level-2 node k <-> local atom k
+    const int st = NCAP - 1 - c;
+    const double x2 = S.nd[0][st], y2 = S.nd[1][st], z2 = S.nd[2][st], a2 = S.nd[3][st], v2 = S.nd[4][st], g2 = S.nd[5][st];
+    S.at[0][slot] = x2;
+    S.at[1][slot] = y2;
+    S.at[2][slot] = z2;
+    S.at[3][slot] = a2;
+    S.at[4][slot] = v2;
+    S.at[5][slot] = g2;
+    S.at_gidx[slot] = hj;
+    Merged m;
+    dev_merge(rx, ry, rz, ra, rv, x2, y2, z2, a2, v2, m);
+    S.nd[0][slot] = m.x;
+    S.nd[1][slot] = m.y;
+    S.nd[2][slot] = m.z;
+    S.nd[3][slot] = m.a;
+    S.nd[4][slot] = m.v;
+    S.nd[5][slot] = rg + g2;
+    S.nla[slot] = (unsigned short)slot;
+    S.npar[slot] = 0;
+    S.ncs[slot] = 0;
+    S.ncc[slot] = 0;
+  }
+  if (tid == 0) {
     S.ncc[0] = (unsigned short)ncand;
     S.lvl[1] = 0;
     S.lvl[2] = 1;
@@ -290,98 +362,116 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   }
   __syncthreads();
 
-  // ---- levels 3..8: breadth-first expansion, one head node at a time
+  AGBNP_BUILD_STAMP(9);
+  // ---- levels 3..8: level-synchronous expansion in batches of <= BS nodes / <= TCAP tasks
+  unsigned char* tmap = reinterpret_cast<unsigned char*>(S.cand_vol);  // task -> node (index inside the batch)
+  double* tvol = S.nd[6];                                                // task -> switched volume (0 = rejected)
   int tail = 1 + ncand;
-  int cur = 2;            // level of the head node
-  int lvl_next = tail;    // first node of level cur+1
-  for (int head = 1; head < tail; ++head) {
-    if (head == lvl_next) {
-      cur++;
-      lvl_next = tail;
-      if (lane == 0) S.lvl[cur + 1] = tail;
-      if (cur >= kMaxOrder) break;
-    }
-    const int par = S.npar[head];
-    const int sib_end = (int)S.ncs[par] + (int)S.ncc[par];
-    const int nsib = sib_end - head - 1;
-    if (nsib <= 0) continue;
-    const double x1 = S.nd[0][head], y1 = S.nd[1][head], z1 = S.nd[2][head];
-    const double a1 = S.nd[3][head], v1 = S.nd[4][head], g1 = S.nd[5][head];
-    if (nsib <= 64) {
-      // fast path: one candidate per lane, rank by register broadcasts
-      const bool valid = lane < nsib;
-      const int la = valid ? (int)S.nla[head + 1 + lane] : 0;
-      Merged m;
-      dev_merge(x1, y1, z1, a1, v1, S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la], m);
-      const bool keep = valid && (m.vol > kMinGvol);
-      const unsigned long long mask = __ballot(keep);
-      if (mask == 0) continue;
-      const int cnt = __popcll(mask);
-      if (tail + cnt > NCAP) return kBuildNodeOverflow;
-      int rank = 0;
-      for (unsigned long long bits = mask; bits; bits &= bits - 1) {
-        const int k = __builtin_ctzll(bits);
-        const double vk = readlane_f64(m.vol, k);
-        rank += (vk > m.vol || (vk == m.vol && k < lane)) ? 1 : 0;
+  int L = 2;
+  for (; L < kMaxOrder; L++) {
+    const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
+    if (lb >= le) break;
+    for (int nb = lb; nb < le;) {
+      // phase 0: one node per lane -> number of younger siblings = tasks
+      const int k = nb + tid;
+      int cnt = 0;
+      if (k < le) {
+        const int par = S.npar[k];
+        cnt = (int)S.ncs[par] + (int)S.ncc[par] - k - 1;
       }
-      if (keep) {
-        const int slot = tail + rank;
-        S.nd[0][slot] = m.x;
-        S.nd[1][slot] = m.y;
-        S.nd[2][slot] = m.z;
-        S.nd[3][slot] = m.a;
-        S.nd[4][slot] = m.v;
-        S.nd[5][slot] = g1 + S.at[5][la];
-        S.nla[slot] = (unsigned short)la;
-        S.npar[slot] = (unsigned short)head;
-        S.ncs[slot] = 0;
-        S.ncc[slot] = 0;
+      if (tid == 0) {
+        S.ctl[1] = 0;  // nodes in this batch
+        S.ctl[2] = 0;  // tasks in this batch
       }
-      if (lane == 0) {
-        S.ncs[head] = (unsigned short)tail;
-        S.ncc[head] = (unsigned short)cnt;
+      int dummy;
+      const int incl = block_inclusive_scan<BS>(cnt, tid, &S.ctl[4], &dummy);
+      __syncthreads();  // ctl[1..2] cleared before anybody raises them
+      const bool inb = (k < le) && (incl <= TCAP);
+      if (inb) {
+        atomicMax(&S.ctl[1], tid + 1);
+        atomicMax(&S.ctl[2], incl);
+        const int excl = incl - cnt;
+        S.tstart[tid] = (unsigned short)excl;
+        for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
       }
-      tail += cnt;
       __syncthreads();
-    } else {
-      // generic path (only reachable when ACAP > 64): chunked scan into the candidate list
-      int nc = 0;
-      for (int base = head + 1; base < sib_end; base += 64) {
-        const int sj = base + lane;
-        bool keep = false;
-        double sv = 0.0;
-        if (sj < sib_end) {
-          const int la = S.nla[sj];
-          Merged m;
-          dev_merge(x1, y1, z1, a1, v1, S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la], m);
-          sv = m.vol;
-          keep = sv > kMinGvol;
+      const int nin = S.ctl[1];
+      const int T = S.ctl[2];
+      if (tid == 0) S.tstart[nin] = (unsigned short)T;
+      AGBNP_BUILD_STAMP(10);
+
+      // phase 1: one task per lane -> switched volume of (node, sibling's atom)
+      for (int t = tid; t < T; t += BS) {
+        const int j = tmap[t];
+        const int kk = nb + j;
+        const int s = kk + 1 + (t - (int)S.tstart[j]);
+        const int la = S.nla[s];
+        const double v = dev_merge_volume(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
+                                          S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la]);
+        tvol[t] = v > kMinGvol ? v : 0.0;
+      }
+      __syncthreads();
+      AGBNP_BUILD_STAMP(11);
+
+      // phase 2: children per node, their base slots
+      int c = 0;
+      if (inb) {
+        const int ts = incl - cnt;
+        for (int t = ts; t < incl; t++) c += tvol[t] > 0.0 ? 1 : 0;
+      }
+      int created;
+      const int cincl = block_inclusive_scan<BS>(c, tid, &S.ctl[4], &created);
+      if (tail + created > NCAP) return kBuildNodeOverflow;
+      if (inb) {
+        const int cb = tail + cincl - c;
+        S.cbase[tid] = (unsigned short)cb;
+        if (c > 0) {
+          S.ncs[k] = (unsigned short)cb;
+          S.ncc[k] = (unsigned short)c;
         }
-        const unsigned long long mask = __ballot(keep);
-        if (mask) {
-          if (keep) {
-            const int p = nc + lane_prefix(mask);
-            S.cand_vol[p] = sv;
-            S.cand_idx[p] = sj;
+      }
+      __syncthreads();
+      AGBNP_BUILD_STAMP(12);
+
+      // phase 3: every kept task finds its rank inside its node's kept set and writes the child there
+      for (int t = tid; t < T; t += BS) {
+        const double v = tvol[t];
+        if (v > 0.0) {
+          const int j = tmap[t];
+          const int kk = nb + j;
+          const int ts = S.tstart[j], te = S.tstart[j + 1];
+          int rank = 0;
+          for (int u = ts; u < te; u++) {
+            const double vu = tvol[u];
+            rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
           }
-          nc += __popcll(mask);
+          const int slot = (int)S.cbase[j] + rank;
+          const int la = S.nla[kk + 1 + (t - ts)];
+          Merged m;
+          dev_merge(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la], S.at[1][la], S.at[2][la],
+                    S.at[3][la], S.at[4][la], m);
+          S.nd[0][slot] = m.x;
+          S.nd[1][slot] = m.y;
+          S.nd[2][slot] = m.z;
+          S.nd[3][slot] = m.a;
+          S.nd[4][slot] = m.v;
+          S.nd[5][slot] = S.nd[5][kk] + S.at[5][la];
+          S.nla[slot] = (unsigned short)la;
+          S.npar[slot] = (unsigned short)kk;
+          S.ncs[slot] = 0;
+          S.ncc[slot] = 0;
         }
       }
-      if (nc == 0) continue;
-      if (tail + nc > NCAP) return kBuildNodeOverflow;
       __syncthreads();
-      append_ranked<NCAP, ACAP, false>(S, A, lane, head, nc, tail, x1, y1, z1, a1, v1, g1);
-      if (lane == 0) {
-        S.ncs[head] = (unsigned short)tail;
-        S.ncc[head] = (unsigned short)nc;
-      }
-      tail += nc;
-      __syncthreads();
+      AGBNP_BUILD_STAMP(13);
+      tail += created;
+      nb += nin;
     }
+    if (tid == 0) S.lvl[L + 2] = tail;
   }
-  if (lane == 0) {
-    // lvl[cur+1] was set on entry to level `cur` and equals tail here; deeper levels are empty
-    for (int L = cur + 2; L <= 9; L++) S.lvl[L] = tail;
+  if (tid == 0) {
+    // lvl[L+1] already equals tail (set when level L-1 was expanded); deeper levels are empty
+    for (int M = L + 2; M <= 9; M++) S.lvl[M] = tail;
   }
   __syncthreads();
   *nnodes_out = tail;
@@ -390,16 +480,16 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
 }
 
 // ---- top-down recompute of every node's Gaussian and gamma from the local atom table ------------------
-template <int NCAP, int ACAP>
-__device__ void rescan_topdown(const TreeStore<NCAP, ACAP>& S, int lane) {
-  if (lane == 0) {
+template <int NCAP, int ACAP, int BS>
+__device__ void rescan_topdown(const TreeStore<NCAP, ACAP>& S, int tid) {
+  if (tid == 0) {
     for (int k = 0; k < 6; k++) S.nd[k][0] = S.at[k][0];
   }
   __syncthreads();
   for (int L = 2; L <= kMaxOrder; L++) {
     const int b = S.lvl[L], e = S.lvl[L + 1];
     if (b >= e) break;
-    for (int n = b + lane; n < e; n += 64) {
+    for (int n = b + tid; n < e; n += BS) {
       const int p = S.npar[n];
       const int la = S.nla[n];
       Merged m;
@@ -419,9 +509,9 @@ __device__ void rescan_topdown(const TreeStore<NCAP, ACAP>& S, int lane) {
 // ---- bottom-up sweep (gaussvol.cpp:400-487) -------------------------------------------------------------
 // Accumulates into the local atom table: gradient (at[6..8]) and, if WITH_VOL, self volume (at[9]).
 // Returns the subtree energy (valid on every lane) if WITH_VOL.
-template <int NCAP, int ACAP, bool WITH_VOL>
-__device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int lane) {
-  if (lane == 0) S.misc[0] = 0.0;
+template <int NCAP, int ACAP, int BS, bool WITH_VOL>
+__device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int tid) {
+  if (tid == 0) S.misc[0] = 0.0;
   int deepest = 1;
   for (int L = 2; L <= kMaxOrder; L++)
     if (S.lvl[L + 1] > S.lvl[L]) deepest = L;
@@ -430,7 +520,7 @@ __device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int lane) {
     const int b = S.lvl[L], e = S.lvl[L + 1];
     const double cf = (L & 1) ? 1.0 : -1.0;
     const double cp = cf / (double)L;
-    for (int n = b + lane; n < e; n += 64) {
+    for (int n = b + tid; n < e; n += BS) {
       const int p = S.npar[n];
       const int la = S.nla[n];
       const double a1 = S.nd[3][p], ai = S.at[3][la];
@@ -452,7 +542,7 @@ __device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int lane) {
         pey += S.nd[4][c];
         pez += S.nd[5][c];
       }
-      const double inv_a1i = 1.0 / (a1 + ai);
+      const double inv_a1i = fast_rcp(a1 + ai);
       const double c2 = ai * inv_a1i;
       lds_add(&S.at[6][la], -m.dvx * fe + pex * c2);
       lds_add(&S.at[7][la], -m.dvy * fe + pey * c2);
@@ -489,8 +579,9 @@ __device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int lane) {
   if (WITH_VOL) {
     // level-1 node: volume = V_i, coefficient +1 (gaussvol.cpp:138-141)
     const double vroot = S.at[4][0];
-    if (lane == 0) lds_add(&S.at[9][0], vroot);
     energy = S.misc[0] + S.at[5][0] * vroot;
+    __syncthreads();
+    if (tid == 0) lds_add(&S.at[9][0], vroot);
     __syncthreads();
   }
   return energy;

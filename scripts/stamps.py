@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-phase shader-clock shares of k_tree_cavity from the -DAGBNP_STAMPS build.
+Usage: AGBNP_HIP_LIBRARY=scripts/_diag/libagbnp_hip_stamps.so python scripts/stamps.py [system]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import openmm_agbnp_plugin_amd as P
+from openmm_agbnp_plugin_amd import _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else "1dwc"
+s = P.load_system(name)
+ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+lib = _lib.load()
+buf = (C.c_ulonglong * 16)()
+ctx.setPositions(s.pos); ctx.getState()
+lib.agbnp_debug_stamps(buf, 1)
+reps = 20
+for k in range(reps):
+    ctx.setPositions(s.jittered(k)); ctx.getState()
+lib.agbnp_debug_stamps(buf, 1)
+v = np.array(list(buf), dtype=np.float64) / reps
+names = {0: "build (total)", 1: "topology out", 2: "sweep 1", 3: "switch radii", 4: "rescan", 5: "sweep 2", 6: "flush",
+         8: " build: level-2 scan", 9: " build: level-2 rank+create", 10: " build: phase0 (tasks/scan/map)", 11: " build: phase1 (volumes)",
+         12: " build: phase2 (count/scan)", 13: " build: phase3 (rank+create)"}
+tot = v[:7].sum()
+print(f"{name}: cycles per evaluation summed over {s.nheavy} workgroups (lane 0), total {tot:.3e}")
+for k, n in names.items():
+    print(f"  {n:34s} {v[k]:12.3e}  {100*v[k]/tot:5.1f}%   per subtree {v[k]/s.nheavy:9.0f} cyc")

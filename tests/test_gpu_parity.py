@@ -182,6 +182,23 @@ def test_update_parameters_in_context(gpu_required, systems):
         small.updateParametersInContext(ctx)
 
 
+def test_diagnostic_vectors(gpu_required, systems):
+    s = systems("fixture264")
+    o = Oracle(*s.params(), version=1)
+    o.execute(s.pos)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    with pytest.raises(P.OpenMMException, match="no completed evaluation"):
+        k.vector("born")
+    k.set_diagnostics(True)
+    k.execute(s.pos, np.zeros((s.n, 3)))
+    for name in ("selfvol_vdw", "selfvol_large", "born", "scale"):
+        np.testing.assert_allclose(k.vector(name), o.vector(name), rtol=0, atol=1e-12)
+    assert abs(k.scalar("e_vol1") - o.scalar("e_vol1")) < TIGHT and abs(k.scalar("e_vol2") - o.scalar("e_vol2")) < TIGHT
+    assert abs(k.scalar("e_atom") + k.scalar("e_gb_pair") - o.scalar("e_gb") - o.scalar("e_vdw")) < TIGHT
+    np.testing.assert_array_equal(k.tables()["type_screener"], o.tables()["type_screener"])
+
+
 def test_force_group_mask(gpu_required, systems):
     s = systems("fixture264")
     force = P.AGBNPForce.from_arrays(*s.params(), version=0)
