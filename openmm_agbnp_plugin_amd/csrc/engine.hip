@@ -80,7 +80,7 @@ struct agbnp_hip_context {
   hipStream_t stream = nullptr;
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
   DevBuf<int2> d_ameta, d_hmeta;
   DevBuf<double2> d_lut;
@@ -262,6 +262,8 @@ void wire_args(agbnp_hip_context* c) {
   T.node_pool = c->d_node_pool.p;
   T.atom_pool = c->d_atom_pool.p;
   P.hdr = c->d_hdr.p;
+  P.order = c->d_order.p;
+  T.order = c->d_order.p;
   T.status = c->d_status.p;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
@@ -304,6 +306,11 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)c->P.asplits * n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
+  {
+    std::vector<int> ident(nhp);
+    for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
+    HIP_TRY(c, c->d_order.upload(ident));
+  }
   HIP_TRY(c, c->d_hdr.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nhp));
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));

@@ -34,6 +34,7 @@ struct PairArgs {
   double* gam;             // [nh] nu of the current tree pass
   double* epart;           // [2nh]
   const SubtreeHeader* hdr;  // [nh] written by the tree kernel (node counts for the statistics words)
+  int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
   int* status;
   // ---- pair-stage intermediates
   double* born_part;       // [hsplits][n]

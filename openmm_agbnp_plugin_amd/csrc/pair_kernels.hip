@@ -329,6 +329,35 @@ __global__ __launch_bounds__(1024) void k_energy_out(PairArgs P, int version, do
     ivals[c] = ired[0];
     __syncthreads();
   }
+  // processing order of the next evaluation: counting sort of the subtrees by node count, descending
+  // (geometry changes little between MD steps, so this step's sizes predict the next step's work)
+  {
+    constexpr int kBins = 512;
+    __shared__ int hist[kBins], start[kBins];
+    if (t < kBins) hist[t] = 0;
+    __syncthreads();
+    for (int h = t; h < P.nh; h += 1024) {
+      int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
+      atomicAdd(&hist[key < 0 ? 0 : key], 1);
+    }
+    __syncthreads();
+    if (t < kBins) start[t] = hist[t];
+    __syncthreads();
+    for (int off = 1; off < kBins; off <<= 1) {  // inclusive Hillis-Steele scan
+      int v = 0;
+      if (t < kBins && t >= off) v = start[t - off];
+      __syncthreads();
+      if (t < kBins) start[t] += v;
+      __syncthreads();
+    }
+    if (t < kBins) start[t] -= hist[t];  // exclusive
+    __syncthreads();
+    for (int h = t; h < P.nh; h += 1024) {
+      int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
+      const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
+      P.order[pos] = h;
+    }
+  }
   if (t == 0) {
     P.status[kStatTotalNodes] = ivals[0];
     P.status[kStatMaxNodes] = ivals[1];

@@ -30,6 +30,7 @@ namespace agbnp {
 
 struct TreeArgs {
   int nh;  // heavy atoms
+  const int* order;            // [nh] subtree processing order (largest subtree of the previous evaluation first)
   const double *hx, *hy, *hz;  // heavy-atom positions (SoA, heavy index)
   const double *a_large, *v_large, *a_vdw, *v_vdw;  // Gaussian exponent / volume per heavy atom
   const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam); pass 3: (W+U)/V_vdw

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
 
-  for (int hi = blockIdx.x; hi < A.nh; hi += gridDim.x) {
+  for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
+    const int hi = A.order[slot];  // longest-processing-time-first: big subtrees start early, small ones fill the tail
     for (int la = tid; la < ACAP; la += BS) {
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(BS) void k_tree_pseudo(TreeArgs A) {
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
-  for (int hi = blockIdx.x; hi < A.nh; hi += gridDim.x) {
+  for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
+    const int hi = A.order[slot];
     const SubtreeHeader* H = &A.hdr[hi];
     const int nnodes = H->nnodes, natoms = H->natoms;
     if (nnodes <= 1) continue;  // a lone atom has no position-dependent volume
