@@ -88,7 +88,7 @@ struct agbnp_hip_context {
   DevBuf<double> d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
   DevBuf<double4> d_aposq, d_hposs;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
-  DevBuf<double2> d_bws;
+  DevBuf<double2> d_bws, d_bornb;
   DevBuf<SubtreeHeader> d_hdr;
   DevBuf<ushort4> d_node_pool;
   DevBuf<int> d_atom_pool;
@@ -231,6 +231,7 @@ void wire_args(agbnp_hip_context* c) {
   P.brw = c->d_brw.p;
   P.e_atom = c->d_e_atom.p;
   P.bws = c->d_bws.p;
+  P.bornb = c->d_bornb.p;
   const size_t row = (size_t)P.asplits * c->n;
   P.gb_fx = c->d_gbf.p;
   P.gb_fy = c->d_gbf.p + row;
@@ -302,6 +303,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_brw.alloc(n));
   HIP_TRY(c, c->d_e_atom.alloc(n));
   HIP_TRY(c, c->d_bws.alloc(n));
+  HIP_TRY(c, c->d_bornb.alloc(n));
   HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)c->P.asplits * n));
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)c->P.asplits * n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));

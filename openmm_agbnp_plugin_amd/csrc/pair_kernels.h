@@ -40,6 +40,7 @@ struct PairArgs {
   double* born_part;       // [hsplits][n]
   double *born, *born_fp, *brw, *e_atom;  // [n]
   double2* bws;            // [n] {brw+bru, scale}
+  double2* bornb;          // [n] {B, 1/B}
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [asplits][n]
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [asplits][n]
   double* egb_part;        // [egb_parts]

@@ -93,15 +93,33 @@ __global__ __launch_bounds__(64) void k_born_pairs(int n, int nh, int hchunk, in
   const int j0 = blockIdx.y * hchunk;
   const int j1 = min(nh, j0 + hchunk);
   double sum = 0.0;
-  for (int j = j0; j < j1; j++) {
-    const double4 pj = hposs[j];  // wave-uniform -> scalar loads
-    const int2 mj = hmeta[j];
+  auto pair = [&](const double4& pj, const int2& mj) {
     const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
     if (d2 < kI4MaxA * kI4MaxA && mj.x != i) {
       const double d = sqrt(d2);
       sum += pj.w * spline_value(s_lut, (tbase + mj.y) * kI4Nodes, d);
     }
+  };
+  if (j0 < j1) {
+    // scalar-load pipeline: retire j's record, issue j+1's, then compute j (see k_gb_pairs)
+    double4 pA = hposs[j0];
+    int2 mA = hmeta[j0];
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+      asm volatile("; j landed" ::"s"(pA.x), "s"(mA.x));
+      const double4 pB = hposs[j + 1];
+      const int2 mB = hmeta[j + 1];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pA, mA);
+      asm volatile("; j+1 landed" ::"s"(pB.x), "s"(mB.x));
+      const int jn = j + 2 < j1 ? j + 2 : j + 1;
+      pA = hposs[jn];
+      mA = hmeta[jn];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pB, mB);
+    }
+    if (j < j1) pair(pA, mA);
   }
   if (valid) born_part[(size_t)blockIdx.y * n + i] = sum;
 }
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
   }
   const double br = 1. / t;
   P.born[i] = br;
+  P.bornb[i] = make_double2(br, t);  // {B, 1/B} for the GB pair loop
   P.born_fp[i] = fp;
   const double q = P.charge[i], alpha = P.alpha[i];
   const double bh = br + kHBRadius;
@@ -137,37 +156,58 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
 
 // ---- GB pairs: every i against a j range (all atoms, no cutoff) ----------------------------------------
 __global__ __launch_bounds__(64) void k_gb_pairs(int n, int achunk, const double4* __restrict__ aposq,
-                                                 const double* __restrict__ born, double* __restrict__ gb_fx,
+                                                 const double2* __restrict__ bornb, double* __restrict__ gb_fx,
                                                  double* __restrict__ gb_fy, double* __restrict__ gb_fz,
                                                  double* __restrict__ gb_y, double* __restrict__ egb_part) {
+  // bornb[j] = {B_j, 1/B_j}
   const int lane = threadIdx.x;
   const int i = blockIdx.x * 64 + lane;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
   const double4 pi = aposq[ii];
-  const double bi = born[ii];
+  const double2 bi = bornb[ii];
+  const double qi_k = kDielFactor * pi.w;
   const int j0 = blockIdx.y * achunk;
   const int j1 = min(n, j0 + achunk);
   double fx = 0, fy = 0, fz = 0, yacc = 0, eacc = 0;
-  for (int j = j0; j < j1; j++) {
-    const double4 pj = aposq[j];  // wave-uniform -> scalar loads
-    const double bj = born[j];
+  // One branch-free body per j (the self pair is computed and multiplied by 0) so that the loop is a single
+  // basic block: the scalar loads of j+1 issue at the top and complete under the ~70 FP64 instructions of j.
+  auto pair = [&](const double4& pj, const double2& bj, int j) {
     const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
-    const double qqf = pi.w * pj.w;
-    const double bb = bi * bj;
-    const double et = exp(-0.25 * d2 / bb);
+    const double bb = bi.x * bj.x;
+    const double et = exp(-0.25 * d2 * (bi.y * bj.y));  // exp(-d^2 / (4 B_i B_j))
     const double fgb = rsqrt(d2 + bb * et);
     const double fgb3 = fgb * fgb * fgb;
-    if (j != i) {
-      const double qq = kDielFactor * qqf;
-      eacc += qq * fgb;  // each unordered pair is met twice: 2*qq*fgb in total
-      const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
-      fx += dx * mw;
-      fy += dy * mw;
-      fz += dz * mw;
-      yacc += qqf * (bb + 0.25 * d2) * et * fgb3;
+    const double qj = (j != i) ? pj.w : 0.0;
+    const double qq = qi_k * qj;
+    eacc += qq * fgb;  // each unordered pair is met twice: 2*qq*fgb in total
+    const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
+    fx += dx * mw;
+    fy += dy * mw;
+    fz += dz * mw;
+    yacc += (pi.w * qj) * (bb + 0.25 * d2) * et * fgb3;
+  };
+  if (j0 < j1) {
+    double4 pA = aposq[j0];  // wave-uniform -> scalar loads
+    double2 bA = bornb[j0];
+    int j = j0;
+    for (; j + 1 < j1; j += 2) {
+      // SMEM returns out of order, so only lgkmcnt(0) is a safe wait: retire the loads of j (in flight since
+      // the previous half-iteration) BEFORE issuing those of j+1, then compute j while j+1 is in flight.
+      asm volatile("; j landed" ::"s"(pA.x), "s"(bA.x));
+      const double4 pB = aposq[j + 1];
+      const double2 bB = bornb[j + 1];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pA, bA, j);
+      asm volatile("; j+1 landed" ::"s"(pB.x), "s"(bB.x));
+      const int jn = j + 2 < j1 ? j + 2 : j + 1;
+      pA = aposq[jn];
+      bA = bornb[jn];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pB, bB, j + 1);
     }
+    if (j < j1) pair(pA, bA, j);
   }
   if (valid) {
     const size_t o = (size_t)blockIdx.y * n + i;
@@ -214,14 +254,12 @@ __global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, 
   const int j0 = blockIdx.y * achunk;
   const int j1 = min(n, j0 + achunk);
   double fx = 0, fy = 0, fz = 0, wu = 0;
-  for (int b = j0; b < j1; b++) {
-    const double4 pb = aposq[b];  // wave-uniform -> scalar loads
-    const double2 wb = bws[b];
-    const int2 mb = ameta[b];
+  auto pair = [&](const double4& pb, const double2& wb, const int2& mb, int b) {
     const double dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
     if (d2 < kI4MaxA * kI4MaxA && b != a) {
-      const double d = sqrt(d2);
+      const double rinv = rsqrt(d2);
+      const double d = d2 * rinv;
       double t = 0.0;
       if (mb.y >= 0) {  // b descreens a
         double q1, dq1;
@@ -234,11 +272,34 @@ __global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, 
         wu += wb.x * q2;
         t += wb.x * wa.y * dq2;
       }
-      t /= d;
+      t *= rinv;
       fx += dx * t;
       fy += dy * t;
       fz += dz * t;
     }
+  };
+  if (j0 < j1) {
+    // scalar-load pipeline: retire b's records, issue b+1's, then compute b (see k_gb_pairs)
+    double4 pA = aposq[j0];
+    double2 wA = bws[j0];
+    int2 mA = ameta[j0];
+    int b = j0;
+    for (; b + 1 < j1; b += 2) {
+      asm volatile("; b landed" ::"s"(pA.x), "s"(wA.x), "s"(mA.x));
+      const double4 pB = aposq[b + 1];
+      const double2 wB = bws[b + 1];
+      const int2 mB = ameta[b + 1];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pA, wA, mA, b);
+      asm volatile("; b+1 landed" ::"s"(pB.x), "s"(wB.x), "s"(mB.x));
+      const int bn = b + 2 < j1 ? b + 2 : b + 1;
+      pA = aposq[bn];
+      wA = bws[bn];
+      mA = ameta[bn];
+      __builtin_amdgcn_sched_barrier(0);
+      pair(pB, wB, mB, b + 1);
+    }
+    if (b < j1) pair(pA, wA, mA, b);
   }
   if (valid) {
     const size_t o = (size_t)blockIdx.y * n + a;
@@ -413,7 +474,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbPairs);
   hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(64), 0, st, P.n, P.achunk, (const double4*)P.aposq,
-                     (const double*)P.born, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
+                     (const double2*)P.bornb, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbFinish);
   hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
