@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -275,7 +276,10 @@ int allocate_work(agbnp_hip_context* c) {
   const size_t nhp = std::max(nh, 1);
   // j-range splits: aim at ~2048 wavefronts per pair launch (256 CUs x 8)
   const int nblk = (n + 63) / 64;
-  const int want = std::min(64, std::max(1, (2048 + nblk - 1) / nblk));
+  // pair launches: workgroups of 4 waves (same 64 i-atoms, j range quartered), `want` workgroups per i-block
+  int target_waves = 4096;
+  if (const char* env = getenv("AGBNP_HIP_PAIR_WAVES")) target_waves = std::max(64, atoi(env));  // tuning knob
+  const int want = std::min(128, std::max(1, (target_waves / 4 + nblk - 1) / nblk));
   c->P.achunk = std::max(16, (n + want - 1) / want);
   c->P.asplits = (n + c->P.achunk - 1) / c->P.achunk;
   c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);

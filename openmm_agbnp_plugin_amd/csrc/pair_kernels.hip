@@ -21,6 +21,9 @@
 
 namespace agbnp {
 
+constexpr int kPairWaves = 4;               // waves per pair-kernel workgroup; all work on the same 64 i-atoms
+constexpr int kPairBlock = 64 * kPairWaves;
+
 // ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, y2_k*dr^2/6}) ------------------
 __device__ __forceinline__ double spline_value(const double2* __restrict__ tab, int base, double d) {
   const double t = d * ((kI4Nodes - 1) / kI4MaxA);
@@ -77,21 +80,25 @@ __global__ __launch_bounds__(256) void k_scale(PairArgs P) {
 }
 
 // ---- inverse Born radii: partial sums over a j range ---------------------------------------------------
-__global__ __launch_bounds__(64) void k_born_pairs(int n, int nh, int hchunk, int ntj, int lut_entries,
+__global__ __launch_bounds__(kPairBlock) void k_born_pairs(int n, int nh, int hchunk, int ntj, int lut_entries,
                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
                                                    const double4* __restrict__ hposs, const int2* __restrict__ hmeta,
                                                    const double2* __restrict__ lut, double* __restrict__ born_part) {
   extern __shared__ double2 s_lut[];
-  const int lane = threadIdx.x;
-  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
+  __shared__ double s_red[kPairWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < lut_entries; t += kPairBlock) s_lut[t] = lut[t];
   __syncthreads();
   const int i = blockIdx.x * 64 + lane;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
   const double4 pi = aposq[ii];
   const int tbase = ameta[ii].x * ntj;
-  const int j0 = blockIdx.y * hchunk;
-  const int j1 = min(nh, j0 + hchunk);
+  // the block's j range is split once more over its waves (same 64 i-atoms in every wave)
+  const int sub = (hchunk + kPairWaves - 1) / kPairWaves;
+  const int jb = blockIdx.y * hchunk;
+  const int j0 = min(nh, jb + wave * sub);
+  const int j1 = min(min(nh, jb + hchunk), j0 + sub);
   double sum = 0.0;
   auto pair = [&](const double4& pj, const int2& mj) {
     const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
@@ -121,7 +128,13 @@ __global__ __launch_bounds__(64) void k_born_pairs(int n, int nh, int hchunk, in
     }
     if (j < j1) pair(pA, mA);
   }
-  if (valid) born_part[(size_t)blockIdx.y * n + i] = sum;
+  s_red[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && valid) {
+    double t = s_red[0][lane];
+    for (int w = 1; w < kPairWaves; w++) t += s_red[w][lane];  // fixed order -> reproducible
+    born_part[(size_t)blockIdx.y * n + i] = t;
+  }
 }
 
 // ---- per atom: beta -> B, f', vdW energy, GB self energy, brw, scale factor -----------------------------
@@ -155,20 +168,23 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
 }
 
 // ---- GB pairs: every i against a j range (all atoms, no cutoff) ----------------------------------------
-__global__ __launch_bounds__(64) void k_gb_pairs(int n, int achunk, const double4* __restrict__ aposq,
+__global__ __launch_bounds__(kPairBlock) void k_gb_pairs(int n, int achunk, const double4* __restrict__ aposq,
                                                  const double2* __restrict__ bornb, double* __restrict__ gb_fx,
                                                  double* __restrict__ gb_fy, double* __restrict__ gb_fz,
                                                  double* __restrict__ gb_y, double* __restrict__ egb_part) {
   // bornb[j] = {B_j, 1/B_j}
-  const int lane = threadIdx.x;
+  __shared__ double s_red[kPairWaves][5][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
   const double4 pi = aposq[ii];
   const double2 bi = bornb[ii];
   const double qi_k = kDielFactor * pi.w;
-  const int j0 = blockIdx.y * achunk;
-  const int j1 = min(n, j0 + achunk);
+  const int sub = (achunk + kPairWaves - 1) / kPairWaves;
+  const int jb = blockIdx.y * achunk;
+  const int j0 = min(n, jb + wave * sub);
+  const int j1 = min(min(n, jb + achunk), j0 + sub);
   double fx = 0, fy = 0, fz = 0, yacc = 0, eacc = 0;
   // One branch-free body per j (the self pair is computed and multiplied by 0) so that the loop is a single
   // basic block: the scalar loads of j+1 issue at the top and complete under the ~70 FP64 instructions of j.
@@ -209,17 +225,28 @@ __global__ __launch_bounds__(64) void k_gb_pairs(int n, int achunk, const double
     }
     if (j < j1) pair(pA, bA, j);
   }
-  if (valid) {
-    const size_t o = (size_t)blockIdx.y * n + i;
-    gb_fx[o] = fx;
-    gb_fy[o] = fy;
-    gb_fz[o] = fz;
-    gb_y[o] = yacc;
-  } else {
-    eacc = 0.0;
+  s_red[wave][0][lane] = fx;
+  s_red[wave][1][lane] = fy;
+  s_red[wave][2][lane] = fz;
+  s_red[wave][3][lane] = yacc;
+  s_red[wave][4][lane] = valid ? eacc : 0.0;
+  __syncthreads();
+  if (wave == 0) {
+    double r[5];
+    for (int k = 0; k < 5; k++) {
+      r[k] = s_red[0][k][lane];
+      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];  // fixed order -> reproducible
+    }
+    if (valid) {
+      const size_t o = (size_t)blockIdx.y * n + i;
+      gb_fx[o] = r[0];
+      gb_fy[o] = r[1];
+      gb_fz[o] = r[2];
+      gb_y[o] = r[3];
+    }
+    const double e = wave_sum(r[4]);
+    if (lane == 0) egb_part[blockIdx.y * gridDim.x + blockIdx.x] = e;
   }
-  const double e = wave_sum(eacc);
-  if (lane == 0) egb_part[blockIdx.y * gridDim.x + blockIdx.x] = e;
 }
 
 // ---- per atom: Y -> bru, bw = brw + bru ---------------------------------------------------------------
@@ -236,14 +263,15 @@ __global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
 }
 
 // ---- Born-radius chain rule: forces + (W+U) sums ---------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, int lut_entries,
+__global__ __launch_bounds__(kPairBlock) void k_dborn_pairs(int n, int achunk, int ntj, int lut_entries,
                                                     const double4* __restrict__ aposq, const int2* __restrict__ ameta,
                                                     const double2* __restrict__ bws, const double2* __restrict__ lut,
                                                     double* __restrict__ db_fx, double* __restrict__ db_fy,
                                                     double* __restrict__ db_fz, double* __restrict__ db_wu) {
   extern __shared__ double2 s_lut[];
-  const int lane = threadIdx.x;
-  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
+  __shared__ double s_red[kPairWaves][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < lut_entries; t += kPairBlock) s_lut[t] = lut[t];
   __syncthreads();
   const int a = blockIdx.x * 64 + lane;
   const bool valid = a < n;
@@ -251,8 +279,10 @@ __global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, 
   const double4 pa = aposq[aa];
   const double2 wa = bws[aa];  // {bw_a, s_a}
   const int2 ma = ameta[aa];   // {screened type, screener type}
-  const int j0 = blockIdx.y * achunk;
-  const int j1 = min(n, j0 + achunk);
+  const int sub = (achunk + kPairWaves - 1) / kPairWaves;
+  const int jb = blockIdx.y * achunk;
+  const int j0 = min(n, jb + wave * sub);
+  const int j1 = min(min(n, jb + achunk), j0 + sub);
   double fx = 0, fy = 0, fz = 0, wu = 0;
   auto pair = [&](const double4& pb, const double2& wb, const int2& mb, int b) {
     const double dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
@@ -301,12 +331,22 @@ __global__ __launch_bounds__(64) void k_dborn_pairs(int n, int achunk, int ntj, 
     }
     if (b < j1) pair(pA, wA, mA, b);
   }
-  if (valid) {
+  s_red[wave][0][lane] = fx;
+  s_red[wave][1][lane] = fy;
+  s_red[wave][2][lane] = fz;
+  s_red[wave][3][lane] = wu;
+  __syncthreads();
+  if (wave == 0 && valid) {
+    double r[4];
+    for (int k = 0; k < 4; k++) {
+      r[k] = s_red[0][k][lane];
+      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];  // fixed order -> reproducible
+    }
     const size_t o = (size_t)blockIdx.y * n + a;
-    db_fx[o] = fx;
-    db_fy[o] = fy;
-    db_fz[o] = fz;
-    db_wu[o] = wu;
+    db_fx[o] = r[0];
+    db_fy[o] = r[1];
+    db_fz[o] = r[2];
+    db_wu[o] = r[3];
   }
 }
 
@@ -466,21 +506,21 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   hipLaunchKernelGGL(k_scale, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKBornPairs);
-  hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(64), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
+  hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(kPairBlock), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
                      (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKBornFinish);
   hipLaunchKernelGGL(k_born_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbPairs);
-  hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(64), 0, st, P.n, P.achunk, (const double4*)P.aposq,
+  hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(kPairBlock), 0, st, P.n, P.achunk, (const double4*)P.aposq,
                      (const double2*)P.bornb, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbFinish);
   hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornPairs);
-  hipLaunchKernelGGL(k_dborn_pairs, dim3(nblk, P.asplits), dim3(64), lds, st, P.n, P.achunk, P.ntj, P.lut_entries,
+  hipLaunchKernelGGL(k_dborn_pairs, dim3(nblk, P.asplits), dim3(kPairBlock), lds, st, P.n, P.achunk, P.ntj, P.lut_entries,
                      (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornFinish);
