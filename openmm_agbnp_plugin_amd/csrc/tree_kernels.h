@@ -200,6 +200,17 @@ __device__ __forceinline__ void glb_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// wave64 inclusive scan (DPP: 4 shifts inside each row of 16 lanes, then two row broadcasts)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
 // inclusive scan of one int per thread over the workgroup; *total = sum over all threads.
 // `part` = BS/64 ints of LDS.  Contains two barriers.
 template <int BS>
@@ -352,7 +363,7 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     S.nd[5][slot] = rg + g2;
     S.nla[slot] = (unsigned short)slot;
     S.npar[slot] = 0;
-    S.ncs[slot] = 0;
+    S.ncs[slot] = (unsigned short)(1 + ncand);  // until the node is expanded: end of its sibling list
     S.ncc[slot] = 0;
   }
   if (tid == 0) {
@@ -373,32 +384,30 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
     if (lb >= le) break;
     for (int nb = lb; nb < le;) {
-      // phase 0: one node per lane -> number of younger siblings = tasks
-      const int k = nb + tid;
-      int cnt = 0;
-      if (k < le) {
-        const int par = S.npar[k];
-        cnt = (int)S.ncs[par] + (int)S.ncc[par] - k - 1;
-      }
-      if (tid == 0) {
-        S.ctl[1] = 0;  // nodes in this batch
-        S.ctl[2] = 0;  // tasks in this batch
-      }
-      int dummy;
-      const int incl = block_inclusive_scan<BS>(cnt, tid, &S.ctl[4], &dummy);
-      __syncthreads();  // ctl[1..2] cleared before anybody raises them
-      const bool inb = (k < le) && (incl <= TCAP);
-      if (inb) {
-        atomicMax(&S.ctl[1], tid + 1);
-        atomicMax(&S.ctl[2], incl);
-        const int excl = incl - cnt;
-        S.tstart[tid] = (unsigned short)excl;
-        for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
+      // phase 0 (wave 0): up to 64 nodes, one per lane -> number of younger siblings = tasks, their prefix sum,
+      // the task -> node byte map.  A node's ncs still holds the end of its sibling list at this point.
+      if (tid < 64) {
+        const int k = nb + tid;
+        const bool has = k < le;
+        const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
+        const int incl = wave_inclusive_scan(cnt);
+        const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
+        const int nin = __popcll(__ballot(inb));
+        const int T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
+        if (inb) {
+          const int excl = incl - cnt;
+          S.tstart[tid] = (unsigned short)excl;
+          for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
+        }
+        if (tid == 0) {
+          S.tstart[nin] = (unsigned short)T;
+          S.ctl[1] = nin;
+          S.ctl[2] = T;
+        }
       }
       __syncthreads();
       const int nin = S.ctl[1];
       const int T = S.ctl[2];
-      if (tid == 0) S.tstart[nin] = (unsigned short)T;
       AGBNP_BUILD_STAMP(10);
 
       // phase 1: one task per lane -> switched volume of (node, sibling's atom)
@@ -414,24 +423,27 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
       __syncthreads();
       AGBNP_BUILD_STAMP(11);
 
-      // phase 2: children per node, their base slots
-      int c = 0;
-      if (inb) {
-        const int ts = incl - cnt;
-        for (int t = ts; t < incl; t++) c += tvol[t] > 0.0 ? 1 : 0;
-      }
-      int created;
-      const int cincl = block_inclusive_scan<BS>(c, tid, &S.ctl[4], &created);
-      if (tail + created > NCAP) return kBuildNodeOverflow;
-      if (inb) {
-        const int cb = tail + cincl - c;
-        S.cbase[tid] = (unsigned short)cb;
-        if (c > 0) {
-          S.ncs[k] = (unsigned short)cb;
-          S.ncc[k] = (unsigned short)c;
+      // phase 2 (wave 0): children per node, their base slots
+      if (tid < 64) {
+        int c = 0;
+        if (tid < nin) {
+          const int ts = S.tstart[tid], te = S.tstart[tid + 1];
+          for (int t = ts; t < te; t++) c += tvol[t] > 0.0 ? 1 : 0;
         }
+        const int cincl = wave_inclusive_scan(c);
+        const int cb = tail + cincl - c;
+        if (tid < nin) {
+          S.cbase[tid] = (unsigned short)cb;
+          if (c > 0) {
+            S.ncs[nb + tid] = (unsigned short)cb;  // from here on: first child
+            S.ncc[nb + tid] = (unsigned short)c;
+          }
+        }
+        if (tid == 63) S.ctl[3] = cincl;
       }
       __syncthreads();
+      const int created = S.ctl[3];
+      if (tail + created > NCAP) return kBuildNodeOverflow;
       AGBNP_BUILD_STAMP(12);
 
       // phase 3: every kept task finds its rank inside its node's kept set and writes the child there
@@ -446,7 +458,8 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
             const double vu = tvol[u];
             rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
           }
-          const int slot = (int)S.cbase[j] + rank;
+          const int cb = S.cbase[j];
+          const int slot = cb + rank;
           const int la = S.nla[kk + 1 + (t - ts)];
           Merged m;
           dev_merge(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la], S.at[1][la], S.at[2][la],
@@ -459,7 +472,7 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
           S.nd[5][slot] = S.nd[5][kk] + S.at[5][la];
           S.nla[slot] = (unsigned short)la;
           S.npar[slot] = (unsigned short)kk;
-          S.ncs[slot] = 0;
+          S.ncs[slot] = (unsigned short)(cb + (int)S.ncc[kk]);  // end of this child's sibling list
           S.ncc[slot] = 0;
         }
       }
