@@ -21,7 +21,8 @@ lib.agbnp_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64) / reps
 names = {0: "build (total)", 1: "topology out", 2: "sweep 1", 3: "switch radii", 4: "rescan", 5: "sweep 2", 6: "flush",
          8: " build: level-2 scan", 9: " build: level-2 rank+create", 10: " build: phase0 (tasks/scan/map)", 11: " build: phase1 (volumes)",
-         12: " build: phase2 (count/scan)", 13: " build: phase3 (rank+create)"}
+         12: " build: phase2 (count/scan)", 13: " build: phase3 (rank+create)",
+         7: " sweeps: reads+merge (first round/level)", 14: " sweeps: children loop", 15: " sweeps: rcp+atomics+writes+barrier"}
 tot = v[:7].sum()
 print(f"{name}: cycles per evaluation summed over {s.nheavy} workgroups (lane 0), total {tot:.3e}")
 for k, n in names.items():
