@@ -362,7 +362,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   const int* s = c->last_status;
   if (s[kStatNodeOverflow] || s[kStatAtomOverflow]) {
     if (c->variant >= kGlobalVariant)
-      return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 1024 partners per heavy atom)");
+      return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 255 partners per heavy atom)");
     c->variant++;
     *repeat = 1;
     return AGBNP_HIP_OK;

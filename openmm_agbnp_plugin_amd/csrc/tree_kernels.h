@@ -19,8 +19,17 @@
 //   * level-synchronous expansion: every (node, younger sibling) pair of a level is one task = one lane;
 //     tasks -> switched volumes in LDS -> per-node child counts (prefix sum) -> per-task rank inside its
 //     node's kept set -> children written directly at their sorted position.
-//   * per-node derived quantities (switched volume, sfp, dv1, dvv1) are recomputed from
-//     (parent Gaussian, atom Gaussian) in the sweep instead of being stored: 7 doubles/node in LDS.
+//   * no bottom-up recursion: the reference's (psi, F, P) recursion (gaussvol.cpp:400-487) is the chain rule for
+//     E = sum_n c_n gamma_n s(G_n) G_n, where G_n is the UNswitched overlap of the atoms of node n.  G_n is a
+//     product of Gaussians, so dG_n/dr_m = -2 a_m (r_m - c_n) G_n for every atom m of the node, and
+//       dE/dr_m   = sum_{n contains m} c_n gamma_n sfp_n * (-2 a_m)(r_m - c_n) G_n
+//       selfvol_m = sum_{n contains m} c_n s(G_n) G_n                 (c_n = +-1/level)
+//     A pass is therefore: (1) top-down rescan (Gaussians, gammas, one 8-byte "atom path" per node),
+//     (2) one node-parallel step turning (G_n, gamma_n, level) into the two scalars coef_n, w_n,
+//     (3) an atom-owned gather: every local atom is owned by one lane group, walks the node list and adds the
+//     terms of the nodes whose path contains it -- no atomics (64-bit LDS atomics cost ~160 cycles per
+//     wave instruction on gfx950), no level ordering, bit-reproducible inside a subtree.
+//     The subtree root's gradient follows from translation invariance (the gradients of a subtree sum to 0).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,7 +70,7 @@ struct TreeStore {
                    // after the bottom-up sweep of a node: 0 psi', 1 E, 2 F_E, 3-5 P_E
   double* at[10];  // local atoms: 0-2 centre, 3 exponent, 4 volume, 5 gamma, 6-8 gradient acc, 9 self-volume acc
   double* cand_vol;  // [ACAP] level-2 candidate volumes; reused as the task->node byte map of a batch
-  double* misc;      // [4]: 0 energy accumulator
+  double* misc;      // [8]: per-wave partial sums of a volume pass
   int* cand_idx;     // [ACAP]
   int* at_gidx;      // [ACAP]
   int* lvl;          // [12]
@@ -75,7 +84,7 @@ struct TreeStore {
   static constexpr size_t kStampBytes = 0;
 #endif
 
-  static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 4) +
+  static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 8) +
                                    sizeof(int) * (2 * (size_t)ACAP + 24) +
                                    sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + kStampBytes;
 
@@ -88,7 +97,7 @@ struct TreeStore {
     cand_vol = d;
     d += ACAP;
     misc = d;
-    d += 4;
+    d += 8;
     int* ip = reinterpret_cast<int*>(d);
     cand_idx = ip;
     ip += ACAP;
@@ -283,7 +292,6 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     S.npar[0] = 0xFFFF;
     S.ncs[0] = 1;
     S.ncc[0] = 0;
-    S.misc[0] = 0.0;
     S.ctl[0] = 0;  // level-2 candidate counter
   }
   __syncthreads();
@@ -493,11 +501,20 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   return kBuildOk;
 }
 
-// ---- top-down recompute of every node's Gaussian and gamma from the local atom table ------------------
-template <int NCAP, int ACAP, int BS>
-__device__ void rescan_topdown(const TreeStore<NCAP, ACAP>& S, int tid) {
+// ---- one volume pass over a built subtree for the radii / gammas currently in the local atom table ------------
+// Adds the gradient (at[6..8]) and, if asked, the self volumes (at[9]) of every non-root local atom;
+// returns sum_n c_n gamma_n V_n in *e_sum and sum_n c_n V_n in *w_sum over the nodes below the root (valid on
+// every lane when WITH_ENERGY).  nd[6] (task volumes during the build) carries the atom paths.
+template <int NCAP, int ACAP, int BS, bool WITH_ENERGY>
+__device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
+                            double* w_sum) {
+  static_assert(ACAP <= 256, "atom path stores one byte per level");
+  static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
+  unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
+  // (1) top-down: Gaussians, gammas and atom paths (byte k = local atom added at level k+2)
   if (tid == 0) {
     for (int k = 0; k < 6; k++) S.nd[k][0] = S.at[k][0];
+    path[0] = 0ull;
   }
   __syncthreads();
   for (int L = 2; L <= kMaxOrder; L++) {
@@ -515,90 +532,109 @@ __device__ void rescan_topdown(const TreeStore<NCAP, ACAP>& S, int tid) {
       S.nd[3][n] = m.a;
       S.nd[4][n] = m.v;
       S.nd[5][n] = S.nd[5][p] + S.at[5][la];
+      path[n] = path[p] | ((unsigned long long)la << (8 * (L - 2)));
     }
     __syncthreads();
   }
+  // (2) node-parallel: exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n, gamma slot <- w_n = c_n s(G_n) G_n
+  double e_part = 0.0, w_part = 0.0;
+  for (int n = 1 + tid; n < nnodes; n += BS) {
+    const int level = 2 + ((63 - __clzll(path[n])) >> 3);
+    const double cp = ((level & 1) ? 1.0 : -1.0) / (double)level;
+    const double g = S.nd[4][n], gam = S.nd[5][n];
+    double sp;
+    const double sw = dev_switch(g, sp);
+    const double w = cp * sw * g;
+    S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
+    S.nd[5][n] = w;
+    e_part += gam * w;
+    w_part += w;
+  }
+  if (WITH_ENERGY) {
+    for (int off = 32; off > 0; off >>= 1) {
+      e_part += __shfl_xor(e_part, off, 64);
+      w_part += __shfl_xor(w_part, off, 64);
+    }
+    if ((tid & 63) == 0) {
+      S.misc[2 * (tid >> 6)] = e_part;
+      S.misc[2 * (tid >> 6) + 1] = w_part;
+    }
+  }
+  __syncthreads();
+  if (WITH_ENERGY) {
+    double es = 0.0, ws = 0.0;
+    for (int w = 0; w < BS / 64; w++) {  // fixed order
+      es += S.misc[2 * w];
+      ws += S.misc[2 * w + 1];
+    }
+    *e_sum = es;
+    *w_sum = ws;
+  }
+  // (3) atom-owned gather.  A wave owns 16 consecutive local atoms; its four 16-lane groups split the node
+  // list four ways and are folded with two lane exchanges at the end, so every atom is written by one lane.
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int slice = lane >> 4;
+    constexpr int kAtomsPerRound = 16 * (BS / 64);
+    for (int abase = 0; abase < natoms; abase += kAtomsPerRound) {
+      const int a = abase + wave * 16 + (lane & 15);
+      const bool live = a >= 1 && a < natoms;  // the root atom is done by translation invariance
+      const int aa_idx = live ? a : 0;
+      const double xa = S.at[0][aa_idx], ya = S.at[1][aa_idx], za = S.at[2][aa_idx], ea = S.at[3][aa_idx];
+      const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)aa_idx;
+      double gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
+      for (int n = 1 + slice; n < nnodes; n += 4) {
+        const unsigned long long x = path[n] ^ pat;
+        const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
+        if (member) {
+          const double am = S.nd[3][n] * ea;
+          gx += am * (xa - S.nd[0][n]);
+          gy += am * (ya - S.nd[1][n]);
+          gz += am * (za - S.nd[2][n]);
+          sv += S.nd[5][n];
+        }
+      }
+      gx += __shfl_xor(gx, 16, 64);
+      gy += __shfl_xor(gy, 16, 64);
+      gz += __shfl_xor(gz, 16, 64);
+      sv += __shfl_xor(sv, 16, 64);
+      gx += __shfl_xor(gx, 32, 64);
+      gy += __shfl_xor(gy, 32, 64);
+      gz += __shfl_xor(gz, 32, 64);
+      sv += __shfl_xor(sv, 32, 64);
+      if (live && slice == 0) {
+        S.at[6][a] += gx;
+        S.at[7][a] += gy;
+        S.at[8][a] += gz;
+        if (with_selfvol) S.at[9][a] += sv;
+      }
+    }
+  }
+  __syncthreads();
 }
 
-// ---- bottom-up sweep (gaussvol.cpp:400-487) -------------------------------------------------------------
-// Accumulates into the local atom table: gradient (at[6..8]) and, if WITH_VOL, self volume (at[9]).
-// Returns the subtree energy (valid on every lane) if WITH_VOL.
-template <int NCAP, int ACAP, int BS, bool WITH_VOL>
-__device__ double sweep_bottomup(const TreeStore<NCAP, ACAP>& S, int tid) {
-  if (tid == 0) S.misc[0] = 0.0;
-  int deepest = 1;
-  for (int L = 2; L <= kMaxOrder; L++)
-    if (S.lvl[L + 1] > S.lvl[L]) deepest = L;
-  __syncthreads();
-  for (int L = deepest; L >= 2; --L) {
-    const int b = S.lvl[L], e = S.lvl[L + 1];
-    const double cf = (L & 1) ? 1.0 : -1.0;
-    const double cp = cf / (double)L;
-    for (int n = b + tid; n < e; n += BS) {
-      const int p = S.npar[n];
-      const int la = S.nla[n];
-      const double a1 = S.nd[3][p], ai = S.at[3][la];
-      Merged m;
-      dev_merge(S.nd[0][p], S.nd[1][p], S.nd[2][p], a1, S.nd[4][p], S.at[0][la], S.at[1][la], S.at[2][la], ai, S.at[4][la], m);
-      const double gam = S.nd[5][n];
-      double psip = cp * m.vol;
-      double en = cp * gam * m.vol;
-      double fe = cp * m.sfp * gam;
-      double pex = 0.0, pey = 0.0, pez = 0.0;
-      const int cs = S.ncs[n], cc = S.ncc[n];
-      for (int c = cs; c < cs + cc; c++) {
-        if (WITH_VOL) {
-          psip += S.nd[0][c];
-          en += S.nd[1][c];
-        }
-        fe += S.nd[2][c];
-        pex += S.nd[3][c];
-        pey += S.nd[4][c];
-        pez += S.nd[5][c];
-      }
-      const double inv_a1i = fast_rcp(a1 + ai);
-      const double c2 = ai * inv_a1i;
-      lds_add(&S.at[6][la], -m.dvx * fe + pex * c2);
-      lds_add(&S.at[7][la], -m.dvy * fe + pey * c2);
-      lds_add(&S.at[8][la], -m.dvz * fe + pez * c2);
-      if (WITH_VOL) lds_add(&S.at[9][la], psip);
-      const double c2p = a1 * inv_a1i;
-      const double ox = m.dvx * fe + pex * c2p;
-      const double oy = m.dvy * fe + pey * c2p;
-      const double oz = m.dvz * fe + pez * c2p;
-      const double of = m.dvv1 * fe;
-      if (L == 2) {
-        // parent is the level-1 root: a_i/a_1i = 1, dv1 = 0 there, so the root's gradient is the sum of P_E
-        lds_add(&S.at[6][0], ox);
-        lds_add(&S.at[7][0], oy);
-        lds_add(&S.at[8][0], oz);
-        if (WITH_VOL) {
-          lds_add(&S.at[9][0], psip);
-          lds_add(&S.misc[0], en);
-        }
-      } else {
-        if (WITH_VOL) {
-          S.nd[0][n] = psip;
-          S.nd[1][n] = en;
-        }
-        S.nd[2][n] = of;
-        S.nd[3][n] = ox;
-        S.nd[4][n] = oy;
-        S.nd[5][n] = oz;
-      }
+// ---- after the passes: the root atom's gradient = -(sum of the other local atoms' gradients) ----------------
+template <int NCAP, int ACAP, int BS>
+__device__ void root_gradient_from_invariance(const TreeStore<NCAP, ACAP>& S, int tid, int natoms) {
+  if (tid < 64) {
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int la = 1 + tid; la < natoms; la += 64) {
+      sx += S.at[6][la];
+      sy += S.at[7][la];
+      sz += S.at[8][la];
     }
-    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+      sx += __shfl_xor(sx, off, 64);
+      sy += __shfl_xor(sy, off, 64);
+      sz += __shfl_xor(sz, off, 64);
+    }
+    if (tid == 0) {
+      S.at[6][0] = -sx;
+      S.at[7][0] = -sy;
+      S.at[8][0] = -sz;
+    }
   }
-  double energy = 0.0;
-  if (WITH_VOL) {
-    // level-1 node: volume = V_i, coefficient +1 (gaussvol.cpp:138-141)
-    const double vroot = S.at[4][0];
-    energy = S.misc[0] + S.at[5][0] * vroot;
-    __syncthreads();
-    if (tid == 0) lds_add(&S.at[9][0], vroot);
-    __syncthreads();
-  }
-  return energy;
+  __syncthreads();
 }
 
 }  // namespace agbnp

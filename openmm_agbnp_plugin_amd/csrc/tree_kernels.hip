@@ -36,7 +36,7 @@ __device__ unsigned long long g_stamps[16];
 // Build + cavity passes of one heavy atom's subtree (reference steps A-D of
 // platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
+__global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
     __syncthreads();
     STAMP_BEGIN();
     int nnodes = 0, natoms = 0;
+    const bool want_sv1 = A.sv_large != nullptr;  // pass-1 self volumes are a diagnostic only
     const int rc = build_subtree<NCAP, ACAP, BS>(S, A, tid, hi, &nnodes, &natoms);
     STAMP(0);
     if (rc != kBuildOk) {
@@ -83,14 +84,20 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
       }
     }
     STAMP(1);
-    // ---- pass 1: enlarged radii, nu = +gamma/roffset
-    const double e1 = sweep_bottomup<NCAP, ACAP, BS, true>(S, tid);
+    // ---- pass 1 (enlarged radii, nu = +gamma/roffset) over the freshly built tree
+    double e_sum, w_sum;
+    volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum);
     STAMP(2);
-    // pass-1 self volumes are a diagnostic only; hand them out and reset the accumulator
+    // level-1 node: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
+    const double e1 = e_sum + S.at[5][0] * S.at[4][0];
+    const double sv1_root = w_sum + S.at[4][0];
+    __syncthreads();
     for (int la = tid; la < natoms; la += BS) {
-      const double sv = S.at[9][la];
       const int hj = S.at_gidx[la];
-      if (A.sv_large != nullptr && sv != 0.0) glb_add(&A.sv_large[hj], sv);
+      if (want_sv1) {
+        const double sv = la == 0 ? sv1_root : S.at[9][la];
+        if (sv != 0.0) glb_add(&A.sv_large[hj], sv);
+      }
       S.at[9][la] = 0.0;
       // switch the local atoms to vdW radii, nu = -gamma/roffset
       S.at[3][la] = A.a_vdw[hj];
@@ -98,12 +105,14 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
       S.at[5][la] = -S.at[5][la];
     }
     __syncthreads();
-
     STAMP(3);
-    // ---- rescan + pass 2
-    rescan_topdown<NCAP, ACAP, BS>(S, tid);
+
+    // ---- pass 2: vdW radii, nu = -gamma/roffset
+    volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum);
     STAMP(4);
-    const double e2 = sweep_bottomup<NCAP, ACAP, BS, true>(S, tid);
+    const double e2 = e_sum + S.at[5][0] * S.at[4][0];
+    const double sv2_root = w_sum + S.at[4][0];
+    root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     STAMP(5);
 
     // ---- flush per-atom sums
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
       glb_add(&A.gx[hj], S.at[6][la]);
       glb_add(&A.gy[hj], S.at[7][la]);
       glb_add(&A.gz[hj], S.at[8][la]);
-      glb_add(&A.sv_vdw[hj], S.at[9][la]);
+      glb_add(&A.sv_vdw[hj], la == 0 ? sv2_root : S.at[9][la]);
     }
     if (tid == 0) {
       A.epart[2 * hi] = e1;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(BS) void k_tree_cavity(TreeArgs A) {
 // gradient-only bottom-up sweep runs.  The reference does two sweeps (W then U); the sweep is linear
 // in nu, so one sweep with the sum gives the same gradient.
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS) void k_tree_pseudo(TreeArgs A) {
+__global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
@@ -162,8 +171,9 @@ __global__ __launch_bounds__(BS) void k_tree_pseudo(TreeArgs A) {
       S.at[8][la] = 0.0;
     }
     __syncthreads();
-    rescan_topdown<NCAP, ACAP, BS>(S, tid);
-    sweep_bottomup<NCAP, ACAP, BS, false>(S, tid);
+    double unused_e, unused_w;
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &unused_e, &unused_w);
+    root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
       glb_add(&A.gx[hj], S.at[6][la]);
@@ -187,7 +197,7 @@ extern "C" void agbnp_debug_stamps(unsigned long long* out, int reset) {
 // ---- host-side launchers -------------------------------------------------------------------------
 // variant: 0 = (512 nodes, 64 atoms) LDS, 1 = (1024,128) LDS, 2 = (2048,256) LDS, 3 = (32768,1024) global scratch
 constexpr int kGlobalNodeCap = 32768;
-constexpr int kGlobalAtomCap = 1024;
+constexpr int kGlobalAtomCap = 256;  // one byte per atom in the path words
 constexpr int kBS = AGBNP_TREE_BLOCK;  // lanes per subtree (compile-time knob, default kTreeBlock)
 static_assert(kBS <= kTreeBlock && kBS % 64 == 0, "tree block size");
 
