@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 def algorithmic_bytes(n_atoms, slots):
     """SURVEY.md s.8d:  B_alg = S*128*8 + T*4096*4 + N*104  per AGBNP1 evaluation, and its split over the
     kernels: tree sweeps 6 (cavity kernel) + 2 (pseudo-volume kernel); one 64x64 pair-tile
-    pass each for the 2-body search (cavity kernel), Born, GB and dBorn; per-atom I/O in prep/forces_out."""
+    pass each for the 2-body search (cavity kernel), Born, GB and dBorn; per-atom I/O in prep/outputs."""
     nb = (n_atoms + 63) // 64
     tiles = nb * (nb + 1) // 2
     node, tile, atom = slots * 128, tiles * 4096, n_atoms * 104
@@ -45,7 +45,7 @@ def algorithmic_bytes(n_atoms, slots):
         "k_gb_pairs": tile,
         "k_dborn_pairs": tile,
         "k_prep": atom // 2,
-        "k_forces_out": atom - atom // 2,
+        "k_outputs": atom - atom // 2,
     }
     return 8 * node + 4 * tile + atom, per_kernel
 

@@ -52,7 +52,7 @@ enum StatusWord {
 // kernel ids of one evaluation, in launch order (bench/profiling support)
 enum KernelId {
   kKPrep = 0, kKTreeCavity, kKScale, kKBornPairs, kKBornFinish, kKGbPairs, kKGbFinish, kKDbornPairs, kKDbornFinish,
-  kKTreePseudo, kKForcesOut, kKEnergyOut, kKernelCount
+  kKTreePseudo, kKOutputs, kKernelCount
 };
 
 }  // namespace agbnp

@@ -6,7 +6,7 @@
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
 //   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_pairs -> k_gb_finish
-//          -> k_dborn_pairs -> k_dborn_finish -> k_tree_pseudo] -> k_forces_out -> k_energy_out
+//          -> k_dborn_pairs -> k_dborn_finish -> k_tree_pseudo] -> k_outputs
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
 // point that computes fails with AGBNP_HIP_ERR_DEVICE.
@@ -623,7 +623,7 @@ int agbnp_hip_num_kernels(void) { return kKernelCount; }
 const char* agbnp_hip_kernel_name(int index) {
   static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_scale",       "k_born_pairs",
                                             "k_born_finish", "k_gb_pairs",    "k_gb_finish",   "k_dborn_pairs",
-                                            "k_dborn_finish", "k_tree_pseudo", "k_forces_out",  "k_energy_out"};
+                                            "k_dborn_finish", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 

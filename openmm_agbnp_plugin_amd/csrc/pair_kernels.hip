@@ -360,114 +360,121 @@ __global__ __launch_bounds__(256) void k_dborn_finish(PairArgs P) {
   P.gam[h] = wu * P.inv_vol_h[h];
 }
 
-// ---- forces out (accumulated into the caller's buffer) -------------------------------------------------
-__global__ __launch_bounds__(256) void k_forces_out(PairArgs P, int version, double* __restrict__ force_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  double fx = 0, fy = 0, fz = 0;
-  const int h = P.a2h[i];
-  if (h >= 0) {  // cavity + pseudo-volume gradients -> force
-    fx = -P.gx[h];
-    fy = -P.gy[h];
-    fz = -P.gz[h];
-  }
-  if (version == 1) {
-    for (int js = 0; js < P.asplits; js++) {
-      const size_t o = (size_t)js * P.n + i;
-      fx += P.gb_fx[o] + P.db_fx[o];
-      fy += P.gb_fy[o] + P.db_fy[o];
-      fz += P.gb_fz[o] + P.db_fz[o];
-    }
-  }
-  force_out[3 * i] += fx;
-  force_out[3 * i + 1] += fy;
-  force_out[3 * i + 2] += fz;
+// ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
+//   blocks [0, nfb)  forces: F = -grad(tree) + sum of the pair partial rows, ADDED to the caller's buffer
+//   block  nfb       energy: fixed-order sum of every energy partial, ADDED to the caller's scalar
+//   block  nfb+1     bookkeeping for the NEXT evaluation: tree statistics and the largest-first subtree order
+__device__ __forceinline__ double block_sum_256(double v, double* red4) {
+  v = wave_sum(v);
+  const int t = threadIdx.x;
+  if ((t & 63) == 0) red4[t >> 6] = v;
+  __syncthreads();
+  const double r = (red4[0] + red4[1]) + (red4[2] + red4[3]);  // fixed order -> reproducible
+  __syncthreads();
+  return r;
 }
 
-// ---- energy: fixed-order sum of all partials -----------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_energy_out(PairArgs P, int version, double* __restrict__ energy_out,
-                                                     double* __restrict__ components) {
-  __shared__ double red[1024];
+__global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double* __restrict__ force_out,
+                                                 double* __restrict__ energy_out, double* __restrict__ components) {
+  const int nfb = (P.n + 255) / 256;
   const int t = threadIdx.x;
-  double ecav1 = 0, ecav2 = 0, eatom = 0, egb = 0;
-  for (int h = t; h < P.nh; h += 1024) {
-    ecav1 += P.epart[2 * h];
-    ecav2 += P.epart[2 * h + 1];
-  }
-  if (version == 1) {
-    for (int i = t; i < P.n; i += 1024) eatom += P.e_atom[i];
-    for (int k = t; k < P.egb_parts; k += 1024) egb += P.egb_part[k];
-  }
-  double vals[4] = {ecav1, ecav2, eatom, egb};
-  double out[4];
-  for (int c = 0; c < 4; c++) {
-    red[t] = vals[c];
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if (t < s) red[t] += red[t + s];
-      __syncthreads();
+  if ((int)blockIdx.x < nfb) {
+    const int i = blockIdx.x * 256 + t;
+    if (i >= P.n) return;
+    double fx = 0, fy = 0, fz = 0;
+    const int h = P.a2h[i];
+    if (h >= 0) {  // cavity + pseudo-volume gradients -> force
+      fx = -P.gx[h];
+      fy = -P.gy[h];
+      fz = -P.gz[h];
     }
-    out[c] = red[0];
-    __syncthreads();
+    if (version == 1) {
+      for (int js = 0; js < P.asplits; js++) {
+        const size_t o = (size_t)js * P.n + i;
+        fx += P.gb_fx[o] + P.db_fx[o];
+        fy += P.gb_fy[o] + P.db_fy[o];
+        fz += P.gb_fz[o] + P.db_fz[o];
+      }
+    }
+    force_out[3 * i] += fx;
+    force_out[3 * i + 1] += fy;
+    force_out[3 * i + 2] += fz;
+    return;
   }
-  // tree statistics of this evaluation (diagnostics): total / max nodes, max local atoms
-  __shared__ int ired[1024];
+  if ((int)blockIdx.x == nfb) {
+    __shared__ double red4[4];
+    double ecav1 = 0, ecav2 = 0, eatom = 0, egb = 0;
+    for (int h = t; h < P.nh; h += 256) {
+      ecav1 += P.epart[2 * h];
+      ecav2 += P.epart[2 * h + 1];
+    }
+    if (version == 1) {
+      for (int i = t; i < P.n; i += 256) eatom += P.e_atom[i];
+      for (int k = t; k < P.egb_parts; k += 256) egb += P.egb_part[k];
+    }
+    const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
+    const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
+    if (t == 0) {
+      components[0] = o0;
+      components[1] = o1;
+      components[2] = o2;
+      components[3] = o3;
+      energy_out[0] += o0 + o1 + o2 + o3;
+    }
+    return;
+  }
+  // ---- bookkeeping block
+  constexpr int kBins = 512;
+  __shared__ int hist[kBins], start[kBins], part[4], imax[8];
+  for (int k = t; k < kBins; k += 256) hist[k] = 0;
+  __syncthreads();
   int tot = 0, mx = 0, ma = 0;
-  for (int h = t; h < P.nh; h += 1024) {
+  for (int h = t; h < P.nh; h += 256) {
     const int nn = P.hdr[h].nnodes, na = P.hdr[h].natoms;
     tot += nn;
     mx = nn > mx ? nn : mx;
     ma = na > ma ? na : ma;
+    const int key = kBins - 1 - (nn >> 2);
+    atomicAdd(&hist[key < 0 ? 0 : key], 1);
   }
-  int ivals[3] = {tot, mx, ma};
-  for (int c = 0; c < 3; c++) {
-    ired[t] = ivals[c];
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if (t < s) ired[t] = c == 0 ? ired[t] + ired[t + s] : (ired[t] > ired[t + s] ? ired[t] : ired[t + s]);
-      __syncthreads();
-    }
-    ivals[c] = ired[0];
-    __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) {
+    tot += __shfl_xor(tot, off, 64);
+    mx = max(mx, __shfl_xor(mx, off, 64));
+    ma = max(ma, __shfl_xor(ma, off, 64));
   }
-  // processing order of the next evaluation: counting sort of the subtrees by node count, descending
-  // (geometry changes little between MD steps, so this step's sizes predict the next step's work)
-  {
-    constexpr int kBins = 512;
-    __shared__ int hist[kBins], start[kBins];
-    if (t < kBins) hist[t] = 0;
-    __syncthreads();
-    for (int h = t; h < P.nh; h += 1024) {
-      int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
-      atomicAdd(&hist[key < 0 ? 0 : key], 1);
-    }
-    __syncthreads();
-    if (t < kBins) start[t] = hist[t];
-    __syncthreads();
-    for (int off = 1; off < kBins; off <<= 1) {  // inclusive Hillis-Steele scan
-      int v = 0;
-      if (t < kBins && t >= off) v = start[t - off];
-      __syncthreads();
-      if (t < kBins) start[t] += v;
-      __syncthreads();
-    }
-    if (t < kBins) start[t] -= hist[t];  // exclusive
-    __syncthreads();
-    for (int h = t; h < P.nh; h += 1024) {
-      int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
-      const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
-      P.order[pos] = h;
-    }
+  if ((t & 63) == 0) {
+    part[t >> 6] = tot;
+    imax[t >> 6] = mx;
+    imax[4 + (t >> 6)] = ma;
   }
+  __syncthreads();
   if (t == 0) {
-    P.status[kStatTotalNodes] = ivals[0];
-    P.status[kStatMaxNodes] = ivals[1];
-    P.status[kStatMaxAtoms] = ivals[2];
-    components[0] = out[0];
-    components[1] = out[1];
-    components[2] = out[2];
-    components[3] = out[3];
-    energy_out[0] += out[0] + out[1] + out[2] + out[3];
+    P.status[kStatTotalNodes] = part[0] + part[1] + part[2] + part[3];
+    P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
+    P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
+  }
+  // exclusive scan of the histogram (bins are in descending size order): thread t owns bins 2t, 2t+1
+  const int h0 = hist[2 * t], h1 = hist[2 * t + 1];
+  int incl = h0 + h1;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
+  }
+  __syncthreads();
+  if ((t & 63) == 63) part[t >> 6] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < (t >> 6); w++) before += part[w];
+  const int excl = before + incl - (h0 + h1);
+  start[2 * t] = excl;
+  start[2 * t + 1] = excl + h0;
+  __syncthreads();
+  // largest-first processing order of the next evaluation (geometry changes little between MD steps, so this
+  // step's sizes predict the next step's work)
+  for (int h = t; h < P.nh; h += 256) {
+    const int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
+    const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
+    P.order[pos] = h;
   }
 }
 
@@ -531,11 +538,8 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
 
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl) {
-  AGBNP_MARK(kKForcesOut);
-  hipLaunchKernelGGL(k_forces_out, dim3((P.n + 255) / 256), dim3(256), 0, st, P, version, force_out);
-  AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKEnergyOut);
-  hipLaunchKernelGGL(k_energy_out, dim3(1), dim3(1024), 0, st, P, version, energy_out, components);
+  AGBNP_MARK(kKOutputs);
+  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + 2), dim3(256), 0, st, P, version, force_out, energy_out, components);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);
   return hipSuccess;
