@@ -5,7 +5,7 @@
 // execute() :139-149 -> agbnp_hip_execute_{host,device}, copyParametersToContext() :1796-1815 ->
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
-//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_pairs -> k_gb_finish
+//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_tiles -> k_gb_finish
 //          -> k_dborn_pairs -> k_dborn_finish -> k_tree_pseudo] -> k_outputs
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
@@ -81,7 +81,7 @@ struct agbnp_hip_context {
   hipStream_t stream = nullptr;
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
   DevBuf<int2> d_ameta, d_hmeta;
   DevBuf<double2> d_lut;
@@ -235,9 +235,11 @@ void wire_args(agbnp_hip_context* c) {
   P.bornb = c->d_bornb.p;
   const size_t row = (size_t)P.asplits * c->n;
   P.gb_fx = c->d_gbf.p;
-  P.gb_fy = c->d_gbf.p + row;
-  P.gb_fz = c->d_gbf.p + 2 * row;
-  P.gb_y = c->d_gbf.p + 3 * row;
+  P.gb_fy = c->d_gbf.p + c->n;
+  P.gb_fz = c->d_gbf.p + 2 * (size_t)c->n;
+  P.gb_y = c->d_gbf.p + 3 * (size_t)c->n;
+  P.gb_items = c->d_gb_items.p;
+  P.gb_items_count = (int)c->d_gb_items.count;
   P.db_fx = c->d_dbf.p;
   P.db_fy = c->d_dbf.p + row;
   P.db_fz = c->d_dbf.p + 2 * row;
@@ -284,7 +286,18 @@ int allocate_work(agbnp_hip_context* c) {
   c->P.asplits = (n + c->P.achunk - 1) / c->P.achunk;
   c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);
   c->P.hsplits = std::max(1, (nh + c->P.hchunk - 1) / c->P.hchunk);
-  c->P.egb_parts = nblk * c->P.asplits;
+  {
+    // work items of the symmetric GB tile kernel: two halves per off-diagonal tile, then the diagonal tiles
+    if (nblk > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 particles are not supported by the tile index encoding");
+    std::vector<int> items;
+    items.reserve((size_t)nblk * nblk);
+    for (int I = 0; I < nblk; I++)
+      for (int J = I + 1; J < nblk; J++)
+        for (int half = 0; half < 2; half++) items.push_back(I | (J << 12) | (half << 24));
+    for (int I = 0; I < nblk; I++) items.push_back(I | (I << 12));
+    HIP_TRY(c, c->d_gb_items.upload(items));
+    c->P.egb_parts = (int)items.size();
+  }
 
   HIP_TRY(c, c->d_status.alloc(kStatWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatWords));
@@ -308,7 +321,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_e_atom.alloc(n));
   HIP_TRY(c, c->d_bws.alloc(n));
   HIP_TRY(c, c->d_bornb.alloc(n));
-  HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)c->P.asplits * n));
+  HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)c->P.asplits * n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
@@ -622,7 +635,7 @@ int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
   static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_scale",       "k_born_pairs",
-                                            "k_born_finish", "k_gb_pairs",    "k_gb_finish",   "k_dborn_pairs",
+                                            "k_born_finish", "k_gb_tiles",    "k_gb_finish",   "k_dborn_pairs",
                                             "k_dborn_finish", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }

@@ -41,7 +41,9 @@ struct PairArgs {
   double *born, *born_fp, *brw, *e_atom;  // [n]
   double2* bws;            // [n] {brw+bru, scale}
   double2* bornb;          // [n] {B, 1/B}
-  double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [asplits][n]
+  double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
+  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles: I | J<<12 | half<<24
+  int gb_items_count;
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [asplits][n]
   double* egb_part;        // [egb_parts]
   int hsplits, hchunk;     // split of the heavy-atom j range (Born)

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
+  P.gb_fx[i] = 0.0;  // GB sums arrive through atomics
+  P.gb_fy[i] = 0.0;
+  P.gb_fz[i] = 0.0;
+  P.gb_y[i] = 0.0;
   const int h = P.a2h[i];
   if (h >= 0) {
     P.hx[h] = x;
@@ -109,7 +113,9 @@ __global__ __launch_bounds__(kPairBlock) void k_born_pairs(int n, int nh, int hc
     }
   };
   if (j0 < j1) {
-    // scalar-load pipeline: retire j's record, issue j+1's, then compute j (see k_gb_pairs)
+    // Scalar-load pipeline.  SMEM returns out of order, so only lgkmcnt(0) is a safe wait: retire the record of
+    // j (in flight since the previous half-iteration) BEFORE issuing the loads of j+1, then compute j while j+1
+    // is in flight.  The empty asm consumes the registers (forces the wait there), sched_barrier pins the order.
     double4 pA = hposs[j0];
     int2 mA = hmeta[j0];
     int j = j0;
@@ -167,86 +173,92 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
   P.brw[i] = -pifac * 3. * alpha * br * br * fp / (bh3 * bh);
 }
 
-// ---- GB pairs: every i against a j range (all atoms, no cutoff) ----------------------------------------
-__global__ __launch_bounds__(kPairBlock) void k_gb_pairs(int n, int achunk, const double4* __restrict__ aposq,
+// ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
+// A wave owns one half of a tile (I <= J): lane l keeps atom i = 64 I + l and its sums in registers, a second
+// register set (record + sums of one j atom of block J) travels round the wave by DPP wave rotation, so every
+// (i, j) pair of the tile meets exactly once and both ends are updated from one evaluation of the pair terms
+// (half the FP64 work of the row form; no LDS, no vector memory in the loop).  Off-diagonal tiles are cut in
+// two work items of 32 rotations; a diagonal tile is one item that visits cyclic distances 1..32 (distance 32
+// only from the lower half of the lanes).  Per-atom sums leave through FP64 HBM atomics into single rows.
+__device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 64)
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x134, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x134, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ void hbm_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                  const double2* __restrict__ bornb, double* __restrict__ gb_fx,
                                                  double* __restrict__ gb_fy, double* __restrict__ gb_fz,
                                                  double* __restrict__ gb_y, double* __restrict__ egb_part) {
-  // bornb[j] = {B_j, 1/B_j}
-  __shared__ double s_red[kPairWaves][5][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
-  const bool valid = i < n;
-  const int ii = valid ? i : n - 1;
-  const double4 pi = aposq[ii];
-  const double2 bi = bornb[ii];
-  const double qi_k = kDielFactor * pi.w;
-  const int sub = (achunk + kPairWaves - 1) / kPairWaves;
-  const int jb = blockIdx.y * achunk;
-  const int j0 = min(n, jb + wave * sub);
-  const int j1 = min(min(n, jb + achunk), j0 + sub);
-  double fx = 0, fy = 0, fz = 0, yacc = 0, eacc = 0;
-  // One branch-free body per j (the self pair is computed and multiplied by 0) so that the loop is a single
-  // basic block: the scalar loads of j+1 issue at the top and complete under the ~70 FP64 instructions of j.
-  auto pair = [&](const double4& pj, const double2& bj, int j) {
-    const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+  const int lane = threadIdx.x;
+  const int item = items[blockIdx.x];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff, half = (item >> 24) & 1;
+  const bool diag = I == J;
+  const int start = diag ? 1 : 32 * half;  // cyclic offset of the first j met by lane l
+  const int i = 64 * I + lane;
+  const bool vi = i < n;
+  const double4 pi = aposq[vi ? i : n - 1];
+  const double2 bi = bornb[vi ? i : n - 1];
+  const double qi = vi ? pi.w : 0.0;
+  const int j = 64 * J + ((lane + start) & 63);
+  const bool vj = j < n;
+  const double4 pj0 = aposq[vj ? j : n - 1];
+  const double2 bj0 = bornb[vj ? j : n - 1];
+  double xj = pj0.x, yj = pj0.y, zj = pj0.z, qj = vj ? pj0.w : 0.0, bj = bj0.x, ibj = bj0.y;
+  double fxi = 0, fyi = 0, fzi = 0, yi = 0, fxj = 0, fyj = 0, fzj = 0, yj_acc = 0, e = 0;
+  for (int k = 0; k < 32; k++) {
+    const double dx = xj - pi.x, dy = yj - pi.y, dz = zj - pi.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
-    const double bb = bi.x * bj.x;
-    const double et = exp(-0.25 * d2 * (bi.y * bj.y));  // exp(-d^2 / (4 B_i B_j))
+    const double bb = bi.x * bj;
+    const double et = exp(-0.25 * d2 * (bi.y * ibj));  // exp(-d^2 / (4 B_i B_j))
     const double fgb = rsqrt(d2 + bb * et);
     const double fgb3 = fgb * fgb * fgb;
-    const double qj = (j != i) ? pj.w : 0.0;
-    const double qq = qi_k * qj;
-    eacc += qq * fgb;  // each unordered pair is met twice: 2*qq*fgb in total
+    // diagonal tile, cyclic distance 32: the pair (l, l+32) would otherwise be met from both ends
+    const double qqf = (diag && k == 31 && lane >= 32) ? 0.0 : qi * qj;
+    const double qq = kDielFactor * qqf;
+    e += 2.0 * qq * fgb;
     const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
-    fx += dx * mw;
-    fy += dy * mw;
-    fz += dz * mw;
-    yacc += (pi.w * qj) * (bb + 0.25 * d2) * et * fgb3;
-  };
-  if (j0 < j1) {
-    double4 pA = aposq[j0];  // wave-uniform -> scalar loads
-    double2 bA = bornb[j0];
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-      // SMEM returns out of order, so only lgkmcnt(0) is a safe wait: retire the loads of j (in flight since
-      // the previous half-iteration) BEFORE issuing those of j+1, then compute j while j+1 is in flight.
-      asm volatile("; j landed" ::"s"(pA.x), "s"(bA.x));
-      const double4 pB = aposq[j + 1];
-      const double2 bB = bornb[j + 1];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pA, bA, j);
-      asm volatile("; j+1 landed" ::"s"(pB.x), "s"(bB.x));
-      const int jn = j + 2 < j1 ? j + 2 : j + 1;
-      pA = aposq[jn];
-      bA = bornb[jn];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pB, bB, j + 1);
-    }
-    if (j < j1) pair(pA, bA, j);
+    const double gx = dx * mw, gy = dy * mw, gz = dz * mw;
+    fxi += gx;
+    fyi += gy;
+    fzi += gz;
+    fxj -= gx;
+    fyj -= gy;
+    fzj -= gz;
+    const double yt = qqf * (bb + 0.25 * d2) * et * fgb3;
+    yi += yt;
+    yj_acc += yt;
+    xj = rot1(xj);
+    yj = rot1(yj);
+    zj = rot1(zj);
+    qj = rot1(qj);
+    bj = rot1(bj);
+    ibj = rot1(ibj);
+    fxj = rot1(fxj);
+    fyj = rot1(fyj);
+    fzj = rot1(fzj);
+    yj_acc = rot1(yj_acc);
   }
-  s_red[wave][0][lane] = fx;
-  s_red[wave][1][lane] = fy;
-  s_red[wave][2][lane] = fz;
-  s_red[wave][3][lane] = yacc;
-  s_red[wave][4][lane] = valid ? eacc : 0.0;
-  __syncthreads();
-  if (wave == 0) {
-    double r[5];
-    for (int k = 0; k < 5; k++) {
-      r[k] = s_red[0][k][lane];
-      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];  // fixed order -> reproducible
-    }
-    if (valid) {
-      const size_t o = (size_t)blockIdx.y * n + i;
-      gb_fx[o] = r[0];
-      gb_fy[o] = r[1];
-      gb_fz[o] = r[2];
-      gb_y[o] = r[3];
-    }
-    const double e = wave_sum(r[4]);
-    if (lane == 0) egb_part[blockIdx.y * gridDim.x + blockIdx.x] = e;
+  if (vi) {
+    hbm_add(&gb_fx[i], fxi);
+    hbm_add(&gb_fy[i], fyi);
+    hbm_add(&gb_fz[i], fzi);
+    hbm_add(&gb_y[i], yi);
   }
+  const int jend = 64 * J + ((lane + start + 32) & 63);  // whose sums this lane holds after 32 rotations
+  if (jend < n) {
+    hbm_add(&gb_fx[jend], fxj);
+    hbm_add(&gb_fy[jend], fyj);
+    hbm_add(&gb_fz[jend], fzj);
+    hbm_add(&gb_y[jend], yj_acc);
+  }
+  e = wave_sum(e);
+  if (lane == 0) egb_part[blockIdx.x] = e;
 }
 
 // ---- per atom: Y -> bru, bw = brw + bru ---------------------------------------------------------------
@@ -254,8 +266,7 @@ __global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const double pifac = 1. / (4. * kPi);
-  double y = 0.0;
-  for (int js = 0; js < P.asplits; js++) y += P.gb_y[(size_t)js * P.n + i];
+  const double y = P.gb_y[i];
   const double q = P.charge[i], br = P.born[i];
   const double bru = -pifac * kDielFactor * (q * q + y * br) * P.born_fp[i];
   const int h = P.a2h[i];
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(kPairBlock) void k_dborn_pairs(int n, int achunk, i
     }
   };
   if (j0 < j1) {
-    // scalar-load pipeline: retire b's records, issue b+1's, then compute b (see k_gb_pairs)
+    // scalar-load pipeline: retire b's records, issue b+1's, then compute b (see k_born_pairs)
     double4 pA = aposq[j0];
     double2 wA = bws[j0];
     int2 mA = ameta[j0];
@@ -389,11 +400,14 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
       fz = -P.gz[h];
     }
     if (version == 1) {
+      fx += P.gb_fx[i];
+      fy += P.gb_fy[i];
+      fz += P.gb_fz[i];
       for (int js = 0; js < P.asplits; js++) {
         const size_t o = (size_t)js * P.n + i;
-        fx += P.gb_fx[o] + P.db_fx[o];
-        fy += P.gb_fy[o] + P.db_fy[o];
-        fz += P.gb_fz[o] + P.db_fz[o];
+        fx += P.db_fx[o];
+        fy += P.db_fy[o];
+        fz += P.db_fz[o];
       }
     }
     force_out[3 * i] += fx;
@@ -520,7 +534,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   hipLaunchKernelGGL(k_born_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbPairs);
-  hipLaunchKernelGGL(k_gb_pairs, dim3(nblk, P.asplits), dim3(kPairBlock), 0, st, P.n, P.achunk, (const double4*)P.aposq,
+  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(64), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
                      (const double2*)P.bornb, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbFinish);
