@@ -583,16 +583,17 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
       const double xa = S.at[0][aa_idx], ya = S.at[1][aa_idx], za = S.at[2][aa_idx], ea = S.at[3][aa_idx];
       const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)aa_idx;
       double gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
+      // branch-free body: the six LDS reads of a node are independent of the membership test, so a trip costs
+      // one LDS round trip instead of two (path -> test -> record)
       for (int n = 1 + slice; n < nnodes; n += 4) {
         const unsigned long long x = path[n] ^ pat;
+        const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
         const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
-        if (member) {
-          const double am = S.nd[3][n] * ea;
-          gx += am * (xa - S.nd[0][n]);
-          gy += am * (ya - S.nd[1][n]);
-          gz += am * (za - S.nd[2][n]);
-          sv += S.nd[5][n];
-        }
+        const double am = member ? cf * ea : 0.0;
+        gx += am * (xa - cx);
+        gy += am * (ya - cy);
+        gz += am * (za - cz);
+        sv += member ? wn : 0.0;
       }
       gx += __shfl_xor(gx, 16, 64);
       gy += __shfl_xor(gy, 16, 64);

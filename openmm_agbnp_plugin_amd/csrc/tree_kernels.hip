@@ -7,6 +7,7 @@ namespace agbnp {
 // workgroups (lane 0).  Never compiled into the product library.
 #ifdef AGBNP_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase; [15] = slowest workgroup in total
 // per-workgroup sums live in the store (S.stamps); flushed once at the end (no contention inside phases)
 #define STAMP_BEGIN()                                   \
   if (tid < 16) S.stamps[tid] = 0;                      \
@@ -25,6 +26,8 @@ __device__ unsigned long long g_stamps[16];
   do {                                                             \
     __syncthreads();                                               \
     if (tid < 16) atomicAdd(&g_stamps[tid], S.stamps[tid]);        \
+    if (tid < 16) atomicMax(&g_stamps_max[tid], S.stamps[tid]);    \
+    if (tid == 0) atomicMax(&g_stamps_max[15], S.stamps[0] + S.stamps[1] + S.stamps[2] + S.stamps[3] + S.stamps[4] + S.stamps[5] + S.stamps[6]); \
     __syncthreads();                                               \
   } while (0)
 #else
@@ -190,6 +193,13 @@ extern "C" void agbnp_debug_stamps(unsigned long long* out, int reset) {
   if (reset) {
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+  }
+}
+extern "C" void agbnp_debug_stamps_max(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_max), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_max), z, sizeof(z));
   }
 }
 #endif

@@ -14,6 +14,7 @@ lib = _lib.load()
 buf = (C.c_ulonglong * 16)()
 ctx.setPositions(s.pos); ctx.getState()
 lib.agbnp_debug_stamps(buf, 1)
+lib.agbnp_debug_stamps_max((C.c_ulonglong * 16)(), 1)
 reps = 20
 for k in range(reps):
     ctx.setPositions(s.jittered(k)); ctx.getState()
@@ -23,7 +24,11 @@ names = {0: "build (total)", 1: "topology out", 2: "sweep 1", 3: "switch radii",
          8: " build: level-2 scan", 9: " build: level-2 rank+create", 10: " build: phase0 (tasks/scan/map)", 11: " build: phase1 (volumes)",
          12: " build: phase2 (count/scan)", 13: " build: phase3 (rank+create)",
          7: " sweeps: reads+merge (first round/level)", 14: " sweeps: children loop", 15: " sweeps: rcp+atomics+writes+barrier"}
+mx = (C.c_ulonglong * 16)()
+lib.agbnp_debug_stamps_max(mx, 1)
+mx = np.array(list(mx), dtype=np.float64)
 tot = v[:7].sum()
 print(f"{name}: cycles per evaluation summed over {s.nheavy} workgroups (lane 0), total {tot:.3e}")
 for k, n in names.items():
     print(f"  {n:34s} {v[k]:12.3e}  {100*v[k]/tot:5.1f}%   per subtree {v[k]/s.nheavy:9.0f} cyc")
+print(f"slowest workgroup: total {mx[15]:.0f} cyc (mean {tot/s.nheavy:.0f}); build {mx[0]:.0f}, pass1 {mx[2]:.0f}, pass2 {mx[4]:.0f}")
