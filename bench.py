@@ -109,7 +109,10 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     K, W = args.steps, args.warmup
-    system = P.load_system(args.system)
+    if args.system.endswith("_x4"):  # HIV-RT stand-in (BASELINE.json config 4): 2x2x1 lattice of copies, 7 nm pitch
+        system = P.lattice(P.load_system(args.system[:-3]), 2, 2, 1, 7.0)
+    else:
+        system = P.load_system(args.system)
     n = system.n
     force = P.AGBNPForce.from_arrays(*system.params(), version=1)
     force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)  # as example/1dwc_benchmark.py:10 (inert: Reference semantics)

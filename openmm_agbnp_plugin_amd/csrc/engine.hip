@@ -88,6 +88,7 @@ struct agbnp_hip_context {
   // per-evaluation device data
   DevBuf<double> d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
   DevBuf<double4> d_aposq, d_hposs;
+  DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
   DevBuf<double2> d_bws, d_bornb;
   DevBuf<SubtreeHeader> d_hdr;
@@ -265,7 +266,8 @@ void wire_args(agbnp_hip_context* c) {
   T.hdr = c->d_hdr.p;
   T.node_pool = c->d_node_pool.p;
   T.atom_pool = c->d_atom_pool.p;
-  P.hdr = c->d_hdr.p;
+  P.sizes = c->d_sizes.p;
+  T.sizes = c->d_sizes.p;
   P.order = c->d_order.p;
   T.order = c->d_order.p;
   T.status = c->d_status.p;
@@ -314,6 +316,8 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
   HIP_TRY(c, c->d_aposq.alloc(n));
   HIP_TRY(c, c->d_hposs.alloc(nhp));
+  HIP_TRY(c, c->d_sizes.alloc(nhp));
+  HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
   HIP_TRY(c, c->d_born_part.alloc((size_t)c->P.hsplits * n));
   HIP_TRY(c, c->d_born.alloc(n));
   HIP_TRY(c, c->d_born_fp.alloc(n));

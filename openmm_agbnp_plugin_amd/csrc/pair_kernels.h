@@ -33,7 +33,7 @@ struct PairArgs {
   double *sv_vdw, *sv_large;  // [nh]
   double* gam;             // [nh] nu of the current tree pass
   double* epart;           // [2nh]
-  const SubtreeHeader* hdr;  // [nh] written by the tree kernel (node counts for the statistics words)
+  const int2* sizes;       // [nh] {nodes, local atoms} per subtree, written by the tree kernel
   int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
   int* status;
   // ---- pair-stage intermediates

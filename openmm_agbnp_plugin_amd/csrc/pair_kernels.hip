@@ -417,14 +417,27 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   }
   if ((int)blockIdx.x == nfb) {
     __shared__ double red4[4];
-    double ecav1 = 0, ecav2 = 0, eatom = 0, egb = 0;
-    for (int h = t; h < P.nh; h += 256) {
-      ecav1 += P.epart[2 * h];
-      ecav2 += P.epart[2 * h + 1];
-    }
+    // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
+    // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
+    auto strided_sum = [&](const double* __restrict__ a, int count, int stride, int offset) {
+      double acc = 0.0;
+      for (int base = 0; base < count; base += 256 * 8) {
+        double v[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const int k = base + b * 256 + t;
+          v[b] = k < count ? a[(size_t)k * stride + offset] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc += v[b];
+      }
+      return acc;
+    };
+    const double ecav1 = strided_sum(P.epart, P.nh, 2, 0), ecav2 = strided_sum(P.epart, P.nh, 2, 1);
+    double eatom = 0, egb = 0;
     if (version == 1) {
-      for (int i = t; i < P.n; i += 256) eatom += P.e_atom[i];
-      for (int k = t; k < P.egb_parts; k += 256) egb += P.egb_part[k];
+      eatom = strided_sum(P.e_atom, P.n, 1, 0);
+      egb = strided_sum(P.egb_part, P.egb_parts, 1, 0);
     }
     const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
     const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
@@ -438,18 +451,28 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     return;
   }
   // ---- bookkeeping block
-  constexpr int kBins = 512;
+  constexpr int kBins = 512, kBatch = 8;
   __shared__ int hist[kBins], start[kBins], part[4], imax[8];
   for (int k = t; k < kBins; k += 256) hist[k] = 0;
   __syncthreads();
   int tot = 0, mx = 0, ma = 0;
-  for (int h = t; h < P.nh; h += 256) {
-    const int nn = P.hdr[h].nnodes, na = P.hdr[h].natoms;
-    tot += nn;
-    mx = nn > mx ? nn : mx;
-    ma = na > ma ? na : ma;
-    const int key = kBins - 1 - (nn >> 2);
-    atomicAdd(&hist[key < 0 ? 0 : key], 1);
+  for (int base = 0; base < P.nh; base += 256 * kBatch) {
+    int2 sz[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {  // independent loads first, then the (slow) LDS atomics
+      const int h = base + b * 256 + t;
+      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      if (sz[b].x >= 0) {
+        tot += sz[b].x;
+        mx = sz[b].x > mx ? sz[b].x : mx;
+        ma = sz[b].y > ma ? sz[b].y : ma;
+        const int key = kBins - 1 - (sz[b].x >> 2);
+        atomicAdd(&hist[key < 0 ? 0 : key], 1);
+      }
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     tot += __shfl_xor(tot, off, 64);
@@ -485,10 +508,21 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   __syncthreads();
   // largest-first processing order of the next evaluation (geometry changes little between MD steps, so this
   // step's sizes predict the next step's work)
-  for (int h = t; h < P.nh; h += 256) {
-    const int key = kBins - 1 - (P.hdr[h].nnodes >> 2);
-    const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
-    P.order[pos] = h;
+  for (int base = 0; base < P.nh; base += 256 * kBatch) {
+    int nn[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      const int h = base + b * 256 + t;
+      nn[b] = h < P.nh ? P.sizes[h].x : -1;
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      if (nn[b] >= 0) {
+        const int key = kBins - 1 - (nn[b] >> 2);
+        const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
+        P.order[pos] = base + b * 256 + t;
+      }
+    }
   }
 }
 

@@ -51,6 +51,7 @@ struct TreeArgs {
   double* sv_vdw;     // [nh] self volumes with vdW radii
   double* epart;      // [2*nh] cavity energies E1,E2 per subtree
   SubtreeHeader* hdr;  // [nh]
+  int2* sizes;         // [nh] {nodes, local atoms} of every subtree, compact copy for the bookkeeping block
   ushort4* node_pool;  // [nh][NCAP] topology records, fixed stride per subtree (variant-dependent)
   int* atom_pool;      // [nh][ACAP] local atom -> heavy index
   int* status;  // [kStatWords]

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         atomicAdd(&A.status[rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow], 1);
         A.hdr[hi].nnodes = 0;
         A.hdr[hi].natoms = 0;
+        A.sizes[hi] = make_int2(0, 0);
       }
       __syncthreads();
       continue;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         h.lvl[0] = 0;
         for (int L = 1; L <= 9; L++) h.lvl[L] = S.lvl[L];
         A.hdr[hi] = h;
+        A.sizes[hi] = make_int2(nnodes, natoms);
       }
     }
     STAMP(1);
