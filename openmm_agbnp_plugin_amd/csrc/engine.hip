@@ -289,14 +289,15 @@ int allocate_work(agbnp_hip_context* c) {
   c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);
   c->P.hsplits = std::max(1, (nh + c->P.hchunk - 1) / c->P.hchunk);
   {
-    // work items of the symmetric GB tile kernel: two halves per off-diagonal tile, then the diagonal tiles
+    // work items of the symmetric GB tile kernel: four quarters per off-diagonal tile, then two per diagonal tile
     if (nblk > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 particles are not supported by the tile index encoding");
     std::vector<int> items;
     items.reserve((size_t)nblk * nblk);
     for (int I = 0; I < nblk; I++)
       for (int J = I + 1; J < nblk; J++)
-        for (int half = 0; half < 2; half++) items.push_back(I | (J << 12) | (half << 24));
-    for (int I = 0; I < nblk; I++) items.push_back(I | (I << 12));
+        for (int part = 0; part < 64 / AGBNP_GB_STEPS; part++) items.push_back(I | (J << 12) | (part << 24));
+    for (int I = 0; I < nblk; I++)
+      for (int part = 0; part < 32 / (AGBNP_GB_STEPS < 32 ? AGBNP_GB_STEPS : 32); part++) items.push_back(I | (I << 12) | (part << 24));
     HIP_TRY(c, c->d_gb_items.upload(items));
     c->P.egb_parts = (int)items.size();
   }

@@ -6,6 +6,10 @@
 
 #include "agbnp_common.h"
 
+#ifndef AGBNP_GB_STEPS
+#define AGBNP_GB_STEPS 32
+#endif
+
 namespace agbnp {
 
 struct PairArgs {
@@ -42,7 +46,7 @@ struct PairArgs {
   double2* bws;            // [n] {brw+bru, scale}
   double2* bornb;          // [n] {B, 1/B}
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
-  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles: I | J<<12 | half<<24
+  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles: I | J<<12 | part<<24
   int gb_items_count;
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [asplits][n]
   double* egb_part;        // [egb_parts]

@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
 // register set (record + sums of one j atom of block J) travels round the wave by DPP wave rotation, so every
 // (i, j) pair of the tile meets exactly once and both ends are updated from one evaluation of the pair terms
 // (half the FP64 work of the row form; no LDS, no vector memory in the loop).  Off-diagonal tiles are cut in
-// two work items of 32 rotations; a diagonal tile is one item that visits cyclic distances 1..32 (distance 32
+// four work items of 16 rotations; a diagonal tile is two items that visit cyclic distances 1..32 (distance 32
 // only from the lower half of the lanes).  Per-atom sums leave through FP64 HBM atomics into single rows.
+constexpr int kGbSteps = AGBNP_GB_STEPS;  // rotations per work item: 64 = a whole off-diagonal tile, 32 = half, 16 = quarter
+
 __device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 64)
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x134, 0xf, 0xf, false);
@@ -197,9 +199,10 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
                                                  double* __restrict__ gb_y, double* __restrict__ egb_part) {
   const int lane = threadIdx.x;
   const int item = items[blockIdx.x];
-  const int I = item & 0xfff, J = (item >> 12) & 0xfff, half = (item >> 24) & 1;
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff, part = (item >> 24) & 3;
   const bool diag = I == J;
-  const int start = diag ? 1 : 32 * half;  // cyclic offset of the first j met by lane l
+  const int nsteps = diag ? (kGbSteps < 32 ? kGbSteps : 32) : kGbSteps;
+  const int start = (diag ? 1 : 0) + nsteps * part;  // cyclic offset of the first j met by lane l
   const int i = 64 * I + lane;
   const bool vi = i < n;
   const double4 pi = aposq[vi ? i : n - 1];
@@ -211,7 +214,8 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
   const double2 bj0 = bornb[vj ? j : n - 1];
   double xj = pj0.x, yj = pj0.y, zj = pj0.z, qj = vj ? pj0.w : 0.0, bj = bj0.x, ibj = bj0.y;
   double fxi = 0, fyi = 0, fzi = 0, yi = 0, fxj = 0, fyj = 0, fzj = 0, yj_acc = 0, e = 0;
-  for (int k = 0; k < 32; k++) {
+#pragma unroll 2
+  for (int k = 0; k < nsteps; k++) {
     const double dx = xj - pi.x, dy = yj - pi.y, dz = zj - pi.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
     const double bb = bi.x * bj;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
     const double fgb = rsqrt(d2 + bb * et);
     const double fgb3 = fgb * fgb * fgb;
     // diagonal tile, cyclic distance 32: the pair (l, l+32) would otherwise be met from both ends
-    const double qqf = (diag && k == 31 && lane >= 32) ? 0.0 : qi * qj;
+    const double qqf = (diag && start + k == 32 && lane >= 32) ? 0.0 : qi * qj;
     const double qq = kDielFactor * qqf;
     e += 2.0 * qq * fgb;
     const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
     hbm_add(&gb_fz[i], fzi);
     hbm_add(&gb_y[i], yi);
   }
-  const int jend = 64 * J + ((lane + start + 32) & 63);  // whose sums this lane holds after 32 rotations
+  const int jend = 64 * J + ((lane + start + nsteps) & 63);  // whose sums this lane holds after the rotations
   if (jend < n) {
     hbm_add(&gb_fx[jend], fxj);
     hbm_add(&gb_fy[jend], fyj);
