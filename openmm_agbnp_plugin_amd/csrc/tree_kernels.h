@@ -221,6 +221,28 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
+// sum of one double per lane over the wave, returned on every lane (DPP adds inside rows, two row broadcasts,
+// then a broadcast of lane 63): ~3x cheaper than six ds_bpermute exchanges
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1   (lanes without a source add 0.0)
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3; lane 63 holds the wave sum
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // inclusive scan of one int per thread over the workgroup; *total = sum over all threads.
 // `part` = BS/64 ints of LDS.  Contains two barriers.
 template <int BS>
@@ -552,10 +574,8 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     w_part += w;
   }
   if (WITH_ENERGY) {
-    for (int off = 32; off > 0; off >>= 1) {
-      e_part += __shfl_xor(e_part, off, 64);
-      w_part += __shfl_xor(w_part, off, 64);
-    }
+    e_part = wave_sum_f64(e_part);
+    w_part = wave_sum_f64(w_part);
     if ((tid & 63) == 0) {
       S.misc[2 * (tid >> 6)] = e_part;
       S.misc[2 * (tid >> 6) + 1] = w_part;
@@ -571,14 +591,16 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     *e_sum = es;
     *w_sum = ws;
   }
-  // (3) atom-owned gather.  A wave owns 16 consecutive local atoms; its four 16-lane groups split the node
-  // list four ways and are folded with two lane exchanges at the end, so every atom is written by one lane.
+  // (3) atom-owned gather.  The 256 lanes form (atom, slice) pairs: A = 16/32/64 atoms per round (the smallest
+  // power of two that covers the subtree's local atoms) times BS/A slices of the node list, so small subtrees
+  // (most of them) walk the nodes 16 ways instead of 4.  Slices are folded inside a wave by lane exchanges and
+  // across waves through four LDS rows; every atom is finally updated by exactly one lane: no atomics.
   {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int slice = lane >> 4;
-    constexpr int kAtomsPerRound = 16 * (BS / 64);
-    for (int abase = 0; abase < natoms; abase += kAtomsPerRound) {
-      const int a = abase + wave * 16 + (lane & 15);
+    const int A = natoms <= 16 ? 16 : (natoms <= 32 ? 32 : 64);
+    const int nslices = BS / A;
+    const int slice = tid / A, al = tid - slice * A;
+    for (int abase = 0; abase < natoms; abase += A) {
+      const int a = abase + al;
       const bool live = a >= 1 && a < natoms;  // the root atom is done by translation invariance
       const int aa_idx = live ? a : 0;
       const double xa = S.at[0][aa_idx], ya = S.at[1][aa_idx], za = S.at[2][aa_idx], ea = S.at[3][aa_idx];
@@ -586,7 +608,7 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
       double gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
       // branch-free body: the six LDS reads of a node are independent of the membership test, so a trip costs
       // one LDS round trip instead of two (path -> test -> record)
-      for (int n = 1 + slice; n < nnodes; n += 4) {
+      for (int n = 1 + slice; n < nnodes; n += nslices) {
         const unsigned long long x = path[n] ^ pat;
         const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
         const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
@@ -596,19 +618,43 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
         gz += am * (za - cz);
         sv += member ? wn : 0.0;
       }
-      gx += __shfl_xor(gx, 16, 64);
-      gy += __shfl_xor(gy, 16, 64);
-      gz += __shfl_xor(gz, 16, 64);
-      sv += __shfl_xor(sv, 16, 64);
-      gx += __shfl_xor(gx, 32, 64);
-      gy += __shfl_xor(gy, 32, 64);
-      gz += __shfl_xor(gz, 32, 64);
-      sv += __shfl_xor(sv, 32, 64);
-      if (live && slice == 0) {
-        S.at[6][a] += gx;
-        S.at[7][a] += gy;
-        S.at[8][a] += gz;
-        if (with_selfvol) S.at[9][a] += sv;
+      // fold the slices that live in this wave (lanes A, 2A, ... apart)
+      for (int off = A; off < 64; off <<= 1) {
+        gx += __shfl_xor(gx, off, 64);
+        gy += __shfl_xor(gy, off, 64);
+        gz += __shfl_xor(gz, off, 64);
+        sv += __shfl_xor(sv, off, 64);
+      }
+      // Exchange area for the cross-wave fold.  With ACAP <= 64 there is a single round, so the node records
+      // are dead after the barrier and their first rows are reused; larger variants (several rounds possible)
+      // have NCAP >= 4*BS and use the unswitched-volume row, which nothing reads after step (2).
+      constexpr bool kSingleRound = ACAP <= 64;
+      static_assert(kSingleRound || NCAP >= 4 * BS, "exchange area");
+      double* ex0 = kSingleRound ? S.nd[0] : S.nd[4];
+      double* ex1 = kSingleRound ? S.nd[1] : S.nd[4] + BS;
+      double* ex2 = kSingleRound ? S.nd[2] : S.nd[4] + 2 * BS;
+      double* ex3 = kSingleRound ? S.nd[3] : S.nd[4] + 3 * BS;
+      __syncthreads();  // every wave is done reading the node records
+      const int wave = tid >> 6, lane = tid & 63;
+      if (lane < A) {
+        ex0[wave * 64 + lane] = gx;
+        ex1[wave * 64 + lane] = gy;
+        ex2[wave * 64 + lane] = gz;
+        ex3[wave * 64 + lane] = sv;
+      }
+      __syncthreads();
+      if (tid < A && live) {  // wave 0 lanes own the atoms; fixed summation order
+        double tx = 0.0, ty = 0.0, tz = 0.0, tv = 0.0;
+        for (int w = 0; w < BS / 64; w++) {
+          tx += ex0[w * 64 + tid];
+          ty += ex1[w * 64 + tid];
+          tz += ex2[w * 64 + tid];
+          tv += ex3[w * 64 + tid];
+        }
+        S.at[6][a] += tx;
+        S.at[7][a] += ty;
+        S.at[8][a] += tz;
+        if (with_selfvol) S.at[9][a] += tv;
       }
     }
   }
@@ -625,11 +671,9 @@ __device__ void root_gradient_from_invariance(const TreeStore<NCAP, ACAP>& S, in
       sy += S.at[7][la];
       sz += S.at[8][la];
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      sx += __shfl_xor(sx, off, 64);
-      sy += __shfl_xor(sy, off, 64);
-      sz += __shfl_xor(sz, off, 64);
-    }
+    sx = wave_sum_f64(sx);
+    sy = wave_sum_f64(sy);
+    sz = wave_sum_f64(sz);
     if (tid == 0) {
       S.at[6][0] = -sx;
       S.at[7][0] = -sy;
