@@ -103,10 +103,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU.  AGBNP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks:
+    # ranks then share devices (local_rank modulo the device count) and the two tiny collectives run on CPU tensors.
+    backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     K, W = args.steps, args.warmup
     if args.system.endswith("_x4"):  # HIV-RT stand-in (BASELINE.json config 4): 2x2x1 lattice of copies, 7 nm pitch
@@ -117,7 +125,7 @@ def main():
     force = P.AGBNPForce.from_arrays(*system.params(), version=1)
     force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)  # as example/1dwc_benchmark.py:10 (inert: Reference semantics)
     force.setCutoffDistance(1.0)
-    kernel = P.HipCalcAGBNPForceKernel(device=local_rank)
+    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
     kernel.initialize(force)
 
     # synthetic geometries, different per replica; resident in HBM before the timed region
@@ -161,10 +169,10 @@ def main():
             break
     if elapsed is None:
         raise SystemExit("bench: tree capacity did not settle")
-    elapsed = max_over_ranks(dist if world > 1 else None, elapsed, device)
+    elapsed = max_over_ranks(dist if world > 1 else None, elapsed, coll_device)
     ms_per_step = 1e3 * elapsed / K
     local_ns_day = 86.4 / ms_per_step
-    per_rank = gather_throughput(dist if world > 1 else None, local_ns_day, ms_per_step, device)
+    per_rank = gather_throughput(dist if world > 1 else None, local_ns_day, ms_per_step, coll_device)
     value = world * 86.4 / ms_per_step  # whole job: all replicas' steps / max-over-ranks time
 
     result = None
