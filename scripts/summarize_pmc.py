@@ -27,7 +27,7 @@ rows = []
 for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
     rows.append(dict(kernel=k, launches=nf[k], FETCH_SIZE_KiB=round(f[k], 1), WRITE_SIZE_KiB=round(w.get(k, 0), 1),
                      hbm_bytes_per_launch=int((2 * f[k] + w.get(k, 0)) * 1024)))
-out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv")
+out = os.path.join(ROOT, "profiles", tag, "pmc_summary.csv")
 with open(out, "w") as fh:
     cw = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
     cw.writeheader()
@@ -37,5 +37,5 @@ dom = max(rows, key=lambda r: r["hbm_bytes_per_launch"]) if len(sys.argv) < 6 el
 json.dump(dict(kernel=dom["kernel"], system=system, hbm_bytes_per_launch=dom["hbm_bytes_per_launch"],
                FETCH_SIZE_KiB=dom["FETCH_SIZE_KiB"], WRITE_SIZE_KiB=dom["WRITE_SIZE_KiB"],
                all_kernels_bytes_per_eval=sum(r["hbm_bytes_per_launch"] for r in rows),
-               source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; profiles/{tag}_pmc_summary.csv"),
+               source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; profiles/{tag}/pmc_summary.csv"),
           open(os.path.join(ROOT, "profiles", "traffic_pmc.json"), "w"), indent=1)
