@@ -100,6 +100,26 @@ def load_system(name):
         return parse_structure(f.read(), name=os.path.splitext(os.path.basename(path))[0])
 
 
+def load_dms(path, name=None):
+    """Read a Desmond .dms structure (SQLite) the way the reference's examples do: positions and charges from
+    the `particle` table, radius and gamma from the `agbnp2` table (schema seen in example/1dwc_agbnp1.dms;
+    trpcage's `agbnp1` table lists every id twice, so `agbnp2` is the one to join), hydrogens by atomic number.
+    The .dms -> addParticle mapping of OpenMM's DesmondDMSFile is outside the reference tree and unpinned
+    (SURVEY.md s.8c); this loader applies the reference TEST's parameterisation instead, exactly like the
+    bundled .dat fixtures (tests/golden/make_fixtures.py uses the same query)."""
+    import sqlite3
+    con = sqlite3.connect(f"file:{path}?mode=ro", uri=True)
+    try:
+        rows = con.execute(
+            "SELECT p.id,p.x,p.y,p.z,a.radius,p.charge,a.igamma,p.anum "
+            "FROM particle p JOIN agbnp2 a ON p.id=a.id ORDER BY p.id").fetchall()
+    finally:
+        con.close()
+    text = f"{len(rows)}\n" + "\n".join(
+        f"{i} {x!r} {y!r} {z!r} {r!r} {q!r} {g!r} {1 if anum == 1 else 0}" for (i, x, y, z, r, q, g, anum) in rows)
+    return parse_structure(text, name=name or os.path.splitext(os.path.basename(path))[0])
+
+
 def lattice(system, nx, ny, nz, pitch_nm):
     """Synthetic larger system: nx*ny*nz translated copies (stand-in for the missing hivrt file,
     SURVEY.md section 8d C4).  Copies do not overlap when pitch exceeds the molecule's extent + 2 nm... they still

@@ -112,3 +112,16 @@ def test_structure_parser_units(systems):
     j = s.jittered(3)
     assert j.shape == s.pos.shape and 0 < np.abs(j - s.pos).max() < 0.02
     np.testing.assert_array_equal(j, s.jittered(3))
+
+
+@pytest.mark.parametrize("name,dms", [("trpcage", "trpcage_agbnp1.dms"), ("1dwc", "1dwc_agbnp1.dms")])
+def test_dms_loader_matches_exported_fixture(systems, name, dms):
+    """Build-container only: the reference's example/*.dms files exist only there (never on the GPU box)."""
+    path = os.path.join("/root/reference/example", dms)
+    if not os.path.exists(path):
+        pytest.skip("reference examples are not present on this machine")
+    a, b = P.load_dms(path), systems(name)
+    assert a.n == b.n
+    for x, y in ((a.pos, b.pos), (a.radius, b.radius), (a.gamma, b.gamma), (a.alpha, b.alpha), (a.charge, b.charge)):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a.ishydrogen, b.ishydrogen)
