@@ -234,7 +234,7 @@ void wire_args(agbnp_hip_context* c) {
   P.e_atom = c->d_e_atom.p;
   P.bws = c->d_bws.p;
   P.bornb = c->d_bornb.p;
-  const size_t row = (size_t)P.asplits * c->n;
+  const size_t row = (size_t)c->n;
   P.gb_fx = c->d_gbf.p;
   P.gb_fy = c->d_gbf.p + c->n;
   P.gb_fz = c->d_gbf.p + 2 * (size_t)c->n;
@@ -319,7 +319,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_hposs.alloc(nhp));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
-  HIP_TRY(c, c->d_born_part.alloc((size_t)c->P.hsplits * n));
+  HIP_TRY(c, c->d_born_part.alloc((size_t)n));
   HIP_TRY(c, c->d_born.alloc(n));
   HIP_TRY(c, c->d_born_fp.alloc(n));
   HIP_TRY(c, c->d_brw.alloc(n));
@@ -327,7 +327,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_bws.alloc(n));
   HIP_TRY(c, c->d_bornb.alloc(n));
   HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)n));
-  HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)c->P.asplits * n));
+  HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
   {

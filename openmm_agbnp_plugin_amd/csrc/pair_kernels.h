@@ -41,14 +41,14 @@ struct PairArgs {
   int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
   int* status;
   // ---- pair-stage intermediates
-  double* born_part;       // [hsplits][n]
+  double* born_part;       // [n] sum_j s_j Q (atomic sums of the j-range workgroups)
   double *born, *born_fp, *brw, *e_atom;  // [n]
   double2* bws;            // [n] {brw+bru, scale}
   double2* bornb;          // [n] {B, 1/B}
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
   const int* gb_items;     // [gb_items_count] work items of k_gb_tiles: I | J<<12 | part<<24
   int gb_items_count;
-  double *db_fx, *db_fy, *db_fz, *db_wu;  // [asplits][n]
+  double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force and W+U (atomic sums)
   double* egb_part;        // [egb_parts]
   int hsplits, hchunk;     // split of the heavy-atom j range (Born)
   int asplits, achunk;     // split of the all-atom j range (GB, dBorn)

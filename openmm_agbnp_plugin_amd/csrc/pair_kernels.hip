@@ -46,6 +46,10 @@ __device__ __forceinline__ void spline_value_deriv(const double2* __restrict__ t
   der = ((hi.x - lo.x) + (1.0 - 3.0 * a * a) * lo.y + (3.0 * b * b - 1.0) * hi.y) * invdr;
 }
 
+__device__ __forceinline__ void hbm_add(double* p, double v) {  // global_atomic_add_f64
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -62,6 +66,11 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
   P.gb_fy[i] = 0.0;
   P.gb_fz[i] = 0.0;
   P.gb_y[i] = 0.0;
+  P.born_part[i] = 0.0;  // Born sums and chain-rule sums arrive through atomics too
+  P.db_fx[i] = 0.0;
+  P.db_fy[i] = 0.0;
+  P.db_fz[i] = 0.0;
+  P.db_wu[i] = 0.0;
   const int h = P.a2h[i];
   if (h >= 0) {
     P.hx[h] = x;
@@ -138,8 +147,8 @@ __global__ __launch_bounds__(kPairBlock) void k_born_pairs(int n, int nh, int hc
   __syncthreads();
   if (wave == 0 && valid) {
     double t = s_red[0][lane];
-    for (int w = 1; w < kPairWaves; w++) t += s_red[w][lane];  // fixed order -> reproducible
-    born_part[(size_t)blockIdx.y * n + i] = t;
+    for (int w = 1; w < kPairWaves; w++) t += s_red[w][lane];
+    hbm_add(&born_part[i], t);  // single row: the per-atom kernel that follows reads one value
   }
 }
 
@@ -148,8 +157,7 @@ __global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const double pifac = 1. / (4. * kPi);
-  double s = 0.0;
-  for (int js = 0; js < P.hsplits; js++) s += P.born_part[(size_t)js * P.n + i];
+  const double s = P.born_part[i];
   const double beta = P.inv_rvdw[i] - pifac * s;
   // ReferenceAGBNPKernels.cpp:41-55
   const double amin = 1. / kI4MaxA;
@@ -187,10 +195,6 @@ __device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 6
   const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x134, 0xf, 0xf, false);
   const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x134, 0xf, 0xf, false);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-__device__ __forceinline__ void hbm_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
@@ -355,13 +359,12 @@ __global__ __launch_bounds__(kPairBlock) void k_dborn_pairs(int n, int achunk, i
     double r[4];
     for (int k = 0; k < 4; k++) {
       r[k] = s_red[0][k][lane];
-      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];  // fixed order -> reproducible
+      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];
     }
-    const size_t o = (size_t)blockIdx.y * n + a;
-    db_fx[o] = r[0];
-    db_fy[o] = r[1];
-    db_fz[o] = r[2];
-    db_wu[o] = r[3];
+    hbm_add(&db_fx[a], r[0]);  // single rows, summed by HBM atomics
+    hbm_add(&db_fy[a], r[1]);
+    hbm_add(&db_fz[a], r[2]);
+    hbm_add(&db_wu[a], r[3]);
   }
 }
 
@@ -370,9 +373,7 @@ __global__ __launch_bounds__(256) void k_dborn_finish(PairArgs P) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= P.nh) return;
   const int a = P.h2a[h];
-  double wu = 0.0;
-  for (int js = 0; js < P.asplits; js++) wu += P.db_wu[(size_t)js * P.n + a];
-  P.gam[h] = wu * P.inv_vol_h[h];
+  P.gam[h] = P.db_wu[a] * P.inv_vol_h[h];
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -404,15 +405,9 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
       fz = -P.gz[h];
     }
     if (version == 1) {
-      fx += P.gb_fx[i];
-      fy += P.gb_fy[i];
-      fz += P.gb_fz[i];
-      for (int js = 0; js < P.asplits; js++) {
-        const size_t o = (size_t)js * P.n + i;
-        fx += P.db_fx[o];
-        fy += P.db_fy[o];
-        fz += P.db_fz[o];
-      }
+      fx += P.gb_fx[i] + P.db_fx[i];
+      fy += P.gb_fy[i] + P.db_fy[i];
+      fz += P.gb_fz[i] + P.db_fz[i];
     }
     force_out[3 * i] += fx;
     force_out[3 * i + 1] += fy;
