@@ -43,7 +43,7 @@ def algorithmic_bytes(n_atoms, slots):
         "k_tree_pseudo": 2 * node,
         "k_born_pairs": tile,
         "k_gb_tiles": tile,
-        "k_dborn_pairs": tile,
+        "k_dborn_tiles": tile,
         "k_prep": atom // 2,
         "k_outputs": atom - atom // 2,
     }

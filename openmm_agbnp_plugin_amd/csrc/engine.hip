@@ -6,7 +6,7 @@
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
 //   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_tiles -> k_gb_finish
-//          -> k_dborn_pairs -> k_dborn_finish -> k_tree_pseudo] -> k_outputs
+//          -> k_dborn_tiles -> k_dborn_finish -> k_tree_pseudo] -> k_outputs
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
 // point that computes fails with AGBNP_HIP_ERR_DEVICE.
@@ -86,7 +86,7 @@ struct agbnp_hip_context {
   DevBuf<int2> d_ameta, d_hmeta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
-  DevBuf<double> d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
+  DevBuf<double> d_abox, d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
   DevBuf<double4> d_aposq, d_hposs;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -218,6 +218,7 @@ void wire_args(agbnp_hip_context* c) {
   P.hy = c->d_hy.p;
   P.hz = c->d_hz.p;
   P.aposq = c->d_aposq.p;
+  P.abox = c->d_abox.p;
   P.hposs = c->d_hposs.p;
   P.gx = c->d_gx.p;
   P.gy = c->d_gy.p;
@@ -316,6 +317,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_epart.alloc(2 * nhp));
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
   HIP_TRY(c, c->d_aposq.alloc(n));
+  HIP_TRY(c, c->d_abox.alloc(6 * (size_t)nblk));
   HIP_TRY(c, c->d_hposs.alloc(nhp));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
@@ -640,7 +642,7 @@ int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
   static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_scale",       "k_born_pairs",
-                                            "k_born_finish", "k_gb_tiles",    "k_gb_finish",   "k_dborn_pairs",
+                                            "k_born_finish", "k_gb_tiles",    "k_gb_finish",   "k_dborn_tiles",
                                             "k_dborn_finish", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }

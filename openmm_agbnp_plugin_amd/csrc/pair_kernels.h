@@ -31,6 +31,7 @@ struct PairArgs {
   // ---- geometry (SoA for the tree, packed records for the pair loops)
   double *hx, *hy, *hz;    // [nh]
   double4* aposq;          // [n] {x,y,z,q}
+  double* abox;            // [ceil(n/64)][6] bounding box {min xyz, max xyz} of every 64-atom block
   double4* hposs;          // [nh] {x,y,z,s_j}
   // ---- tree accumulators / outputs
   double *gx, *gy, *gz;    // [nh]
@@ -46,7 +47,7 @@ struct PairArgs {
   double2* bws;            // [n] {brw+bru, scale}
   double2* bornb;          // [n] {B, 1/B}
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
-  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles: I | J<<12 | part<<24
+  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles / k_dborn_tiles: I | J<<12 | part<<24
   int gb_items_count;
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force and W+U (atomic sums)
   double* egb_part;        // [egb_parts]

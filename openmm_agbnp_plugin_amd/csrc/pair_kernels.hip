@@ -59,6 +59,25 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kStatWords && blockIdx.x == 0) P.status[i] = 0;
+  {
+    // bounding box of every block of 64 consecutive atoms (one wave each) for the tile culling of the
+    // range-limited pair stages
+    const int ic = i < P.n ? i : P.n - 1;
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; d++) lo[d] = hi[d] = P.pos[3 * ic + d];
+    for (int off = 32; off > 0; off >>= 1)
+      for (int d = 0; d < 3; d++) {
+        lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
+        hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
+      }
+    const int blk = i >> 6;
+    if ((i & 63) == 0 && blk * 64 < P.n) {
+      for (int d = 0; d < 3; d++) {
+        P.abox[6 * blk + d] = lo[d];
+        P.abox[6 * blk + 3 + d] = hi[d];
+      }
+    }
+  }
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
@@ -281,90 +300,106 @@ __global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
   P.bws[i] = make_double2(P.brw[i] + bru, h >= 0 ? P.hposs[h].w : 0.0);
 }
 
-// ---- Born-radius chain rule: forces + (W+U) sums ---------------------------------------------------------
-__global__ __launch_bounds__(kPairBlock) void k_dborn_pairs(int n, int achunk, int ntj, int lut_entries,
-                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
-                                                    const double2* __restrict__ bws, const double2* __restrict__ lut,
-                                                    double* __restrict__ db_fx, double* __restrict__ db_fy,
-                                                    double* __restrict__ db_fz, double* __restrict__ db_wu) {
+// ---- Born-radius chain rule, symmetric 64x64 tiles with range culling -------------------------------------
+// Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
+//   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
+// Same machinery as k_gb_tiles: block I in registers, the record and sums of block J travel by DPP rotation,
+// every unordered pair is met once and serves both directions (two table look-ups, one distance).
+// A work item whose two 64-atom bounding boxes are more than the table's 2 nm reach apart exits at once.
+__device__ __forceinline__ int rot1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(64) void k_dborn_tiles(int n, int ntj, int lut_entries, const int* __restrict__ items,
+                                                    const double* __restrict__ abox, const double4* __restrict__ aposq,
+                                                    const int2* __restrict__ ameta, const double2* __restrict__ bws,
+                                                    const double2* __restrict__ lut, double* __restrict__ db_fx,
+                                                    double* __restrict__ db_fy, double* __restrict__ db_fz,
+                                                    double* __restrict__ db_wu) {
   extern __shared__ double2 s_lut[];
-  __shared__ double s_red[kPairWaves][4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < lut_entries; t += kPairBlock) s_lut[t] = lut[t];
+  const int lane = threadIdx.x;
+  const int item = items[blockIdx.x];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff, part = (item >> 24) & 3;
+  const bool diag = I == J;
+  if (!diag) {  // wave-uniform range test on the two bounding boxes
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(abox[6 * J + d] - abox[6 * I + 3 + d], abox[6 * I + d] - abox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    if (gap2 >= kI4MaxA * kI4MaxA) return;
+  }
+  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
   __syncthreads();
-  const int a = blockIdx.x * 64 + lane;
-  const bool valid = a < n;
-  const int aa = valid ? a : n - 1;
-  const double4 pa = aposq[aa];
-  const double2 wa = bws[aa];  // {bw_a, s_a}
-  const int2 ma = ameta[aa];   // {screened type, screener type}
-  const int sub = (achunk + kPairWaves - 1) / kPairWaves;
-  const int jb = blockIdx.y * achunk;
-  const int j0 = min(n, jb + wave * sub);
-  const int j1 = min(min(n, jb + achunk), j0 + sub);
-  double fx = 0, fy = 0, fz = 0, wu = 0;
-  auto pair = [&](const double4& pb, const double2& wb, const int2& mb, int b) {
-    const double dx = pb.x - pa.x, dy = pb.y - pa.y, dz = pb.z - pa.z;
+  const int nsteps = diag ? (kGbSteps < 32 ? kGbSteps : 32) : kGbSteps;
+  const int start = (diag ? 1 : 0) + nsteps * part;
+  const int i = 64 * I + lane;
+  const bool vi = i < n;
+  const double4 pi = aposq[vi ? i : n - 1];
+  const double2 wi = vi ? bws[i] : make_double2(0.0, 0.0);  // {bw_i, s_i}; zero weights switch a padded lane off
+  const int2 mi = ameta[vi ? i : n - 1];                    // {screened type, screener type or -1}
+  const int tsr_i = vi ? mi.y : -1;
+  const int j = 64 * J + ((lane + start) & 63);
+  const bool vj = j < n;
+  const double4 pj0 = aposq[vj ? j : n - 1];
+  const double2 wj0 = vj ? bws[j] : make_double2(0.0, 0.0);
+  const int2 mj0 = ameta[vj ? j : n - 1];
+  double xj = pj0.x, yj = pj0.y, zj = pj0.z, bwj = wj0.x, sj = wj0.y;
+  int tj = mj0.x | (((vj ? mj0.y : -1) + 1) << 16);  // screened type | (screener type + 1) << 16
+  int jid = vj ? j : -1;
+  double fxi = 0, fyi = 0, fzi = 0, wui = 0, fxj = 0, fyj = 0, fzj = 0, wuj = 0;
+#pragma unroll 2
+  for (int k = 0; k < nsteps; k++) {
+    const double dx = xj - pi.x, dy = yj - pi.y, dz = zj - pi.z;
     const double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 < kI4MaxA * kI4MaxA && b != a) {
+    const bool once = !(diag && start + k == 32 && lane >= 32);  // diagonal tile, distance 32: one end only
+    if (d2 < kI4MaxA * kI4MaxA && vi && jid >= 0 && once) {
       const double rinv = rsqrt(d2);
       const double d = d2 * rinv;
+      const int tsd_j = tj & 0xffff, tsr_j = (tj >> 16) - 1;
       double t = 0.0;
-      if (mb.y >= 0) {  // b descreens a
+      if (tsr_j >= 0) {  // j descreens i
         double q1, dq1;
-        spline_value_deriv(s_lut, (ma.x * ntj + mb.y) * kI4Nodes, d, q1, dq1);
-        t += wa.x * wb.y * dq1;
+        spline_value_deriv(s_lut, (mi.x * ntj + tsr_j) * kI4Nodes, d, q1, dq1);
+        wuj += wi.x * q1;
+        t += wi.x * sj * dq1;
       }
-      if (ma.y >= 0) {  // a descreens b
+      if (tsr_i >= 0) {  // i descreens j
         double q2, dq2;
-        spline_value_deriv(s_lut, (mb.x * ntj + ma.y) * kI4Nodes, d, q2, dq2);
-        wu += wb.x * q2;
-        t += wb.x * wa.y * dq2;
+        spline_value_deriv(s_lut, (tsd_j * ntj + tsr_i) * kI4Nodes, d, q2, dq2);
+        wui += bwj * q2;
+        t += bwj * wi.y * dq2;
       }
       t *= rinv;
-      fx += dx * t;
-      fy += dy * t;
-      fz += dz * t;
+      const double gx = dx * t, gy = dy * t, gz = dz * t;
+      fxi += gx;
+      fyi += gy;
+      fzi += gz;
+      fxj -= gx;
+      fyj -= gy;
+      fzj -= gz;
     }
-  };
-  if (j0 < j1) {
-    // scalar-load pipeline: retire b's records, issue b+1's, then compute b (see k_born_pairs)
-    double4 pA = aposq[j0];
-    double2 wA = bws[j0];
-    int2 mA = ameta[j0];
-    int b = j0;
-    for (; b + 1 < j1; b += 2) {
-      asm volatile("; b landed" ::"s"(pA.x), "s"(wA.x), "s"(mA.x));
-      const double4 pB = aposq[b + 1];
-      const double2 wB = bws[b + 1];
-      const int2 mB = ameta[b + 1];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pA, wA, mA, b);
-      asm volatile("; b+1 landed" ::"s"(pB.x), "s"(wB.x), "s"(mB.x));
-      const int bn = b + 2 < j1 ? b + 2 : b + 1;
-      pA = aposq[bn];
-      wA = bws[bn];
-      mA = ameta[bn];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pB, wB, mB, b + 1);
-    }
-    if (b < j1) pair(pA, wA, mA, b);
+    xj = rot1(xj);
+    yj = rot1(yj);
+    zj = rot1(zj);
+    bwj = rot1(bwj);
+    sj = rot1(sj);
+    tj = rot1i(tj);
+    jid = rot1i(jid);
+    fxj = rot1(fxj);
+    fyj = rot1(fyj);
+    fzj = rot1(fzj);
+    wuj = rot1(wuj);
   }
-  s_red[wave][0][lane] = fx;
-  s_red[wave][1][lane] = fy;
-  s_red[wave][2][lane] = fz;
-  s_red[wave][3][lane] = wu;
-  __syncthreads();
-  if (wave == 0 && valid) {
-    double r[4];
-    for (int k = 0; k < 4; k++) {
-      r[k] = s_red[0][k][lane];
-      for (int w = 1; w < kPairWaves; w++) r[k] += s_red[w][k][lane];
-    }
-    hbm_add(&db_fx[a], r[0]);  // single rows, summed by HBM atomics
-    hbm_add(&db_fy[a], r[1]);
-    hbm_add(&db_fz[a], r[2]);
-    hbm_add(&db_wu[a], r[3]);
+  if (vi) {
+    hbm_add(&db_fx[i], fxi);
+    hbm_add(&db_fy[i], fyi);
+    hbm_add(&db_fz[i], fzi);
+    hbm_add(&db_wu[i], wui);
+  }
+  if (jid >= 0) {  // after the rotations the lane holds the sums of atom jid
+    hbm_add(&db_fx[jid], fxj);
+    hbm_add(&db_fy[jid], fyj);
+    hbm_add(&db_fz[jid], fzj);
+    hbm_add(&db_wu[jid], wuj);
   }
 }
 
@@ -553,7 +588,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   AGBNP_MARK(kKScale);
@@ -574,8 +609,9 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornPairs);
-  hipLaunchKernelGGL(k_dborn_pairs, dim3(nblk, P.asplits), dim3(kPairBlock), lds, st, P.n, P.achunk, P.ntj, P.lut_entries,
-                     (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
+  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.gb_items_count), dim3(64), lds, st, P.n, P.ntj, P.lut_entries, P.gb_items,
+                     (const double*)P.abox, (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy,
+                     P.db_fz, P.db_wu);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornFinish);
   hipLaunchKernelGGL(k_dborn_finish, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
