@@ -308,27 +308,32 @@ __global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
 // A work item whose two 64-atom bounding boxes are more than the table's 2 nm reach apart exits at once.
 __device__ __forceinline__ int rot1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(64) void k_dborn_tiles(int n, int ntj, int lut_entries, const int* __restrict__ items,
+__global__ __launch_bounds__(256) void k_dborn_tiles(int n, int ntj, int lut_entries, int nitems, const int* __restrict__ items,
                                                     const double* __restrict__ abox, const double4* __restrict__ aposq,
                                                     const int2* __restrict__ ameta, const double2* __restrict__ bws,
                                                     const double2* __restrict__ lut, double* __restrict__ db_fx,
                                                     double* __restrict__ db_fy, double* __restrict__ db_fz,
                                                     double* __restrict__ db_wu) {
   extern __shared__ double2 s_lut[];
-  const int lane = threadIdx.x;
-  const int item = items[blockIdx.x];
+  // four waves = four work items share one copy of the spline tables
+  const int lane = threadIdx.x & 63;
+  const int item_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int item = items[item_id < nitems ? item_id : nitems - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff, part = (item >> 24) & 3;
   const bool diag = I == J;
+  bool in_range = item_id < nitems;
   if (!diag) {  // wave-uniform range test on the two bounding boxes
     double gap2 = 0.0;
     for (int d = 0; d < 3; d++) {
       const double g = fmax(0.0, fmax(abox[6 * J + d] - abox[6 * I + 3 + d], abox[6 * I + d] - abox[6 * J + 3 + d]));
       gap2 += g * g;
     }
-    if (gap2 >= kI4MaxA * kI4MaxA) return;
+    in_range = in_range && gap2 < kI4MaxA * kI4MaxA;
   }
-  for (int t = lane; t < lut_entries; t += 64) s_lut[t] = lut[t];
+  if (__syncthreads_or(in_range ? 1 : 0) == 0) return;  // the whole workgroup is out of range
+  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
   __syncthreads();
+  if (!in_range) return;
   const int nsteps = diag ? (kGbSteps < 32 ? kGbSteps : 32) : kGbSteps;
   const int start = (diag ? 1 : 0) + nsteps * part;
   const int i = 64 * I + lane;
@@ -609,7 +614,8 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornPairs);
-  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.gb_items_count), dim3(64), lds, st, P.n, P.ntj, P.lut_entries, P.gb_items,
+  hipLaunchKernelGGL(k_dborn_tiles, dim3((P.gb_items_count + 3) / 4), dim3(256), lds, st, P.n, P.ntj, P.lut_entries,
+                     P.gb_items_count, P.gb_items,
                      (const double*)P.abox, (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy,
                      P.db_fz, P.db_wu);
   AGBNP_CHECK_LAUNCH();
