@@ -322,19 +322,15 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   // ---- level 2: all heavy atoms with a larger index whose overlap with the root survives the switch.
   // Each wave compacts its hits (ballot + mbcnt) and reserves room with one LDS add; a hit parks its atom
   // record in the (still unused) upper node slots so that ranking never goes back to HBM.
-  for (int base = hi + 1; base < A.nh; base += BS) {
-    const int hj = base + tid;
+  // Two candidates per lane and trip, every field requested up front: one HBM/L2 round trip per 2*BS atoms
+  // instead of three dependent ones (position -> exponent/volume -> gamma) per BS atoms.
+  auto consider = [&](int hj, bool valid, double xj, double yj, double zj, double aj, double vj, double gj) {
     bool keep = false;
-    double sv = 0.0, xj = 0, yj = 0, zj = 0, aj = 0, vj = 0;
-    if (hj < A.nh) {
-      xj = A.hx[hj];
-      yj = A.hy[hj];
-      zj = A.hz[hj];
+    double sv = 0.0;
+    if (valid) {
       const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
       const double d2 = dx * dx + dy * dy + dz * dz;
       if (d2 < A.rcut2) {
-        aj = A.a_large[hj];
-        vj = A.v_large[hj];
         sv = dev_merge_volume(rx, ry, rz, ra, rv, xj, yj, zj, aj, vj);
         keep = sv > kMinGvol;
       }
@@ -355,10 +351,19 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
           S.nd[2][st] = zj;
           S.nd[3][st] = aj;
           S.nd[4][st] = vj;
-          S.nd[5][st] = A.gam[hj];
+          S.nd[5][st] = gj;
         }
       }
     }
+  };
+  for (int base = hi + 1; base < A.nh; base += 2 * BS) {
+    const int h0 = base + tid, h1 = base + BS + tid;
+    const bool v0 = h0 < A.nh, v1 = h1 < A.nh;
+    const int c0 = v0 ? h0 : hi, c1 = v1 ? h1 : hi;
+    const double x0 = A.hx[c0], y0 = A.hy[c0], z0 = A.hz[c0], a0 = A.a_large[c0], w0 = A.v_large[c0], g0 = A.gam[c0];
+    const double x1 = A.hx[c1], y1 = A.hy[c1], z1 = A.hz[c1], a1 = A.a_large[c1], w1 = A.v_large[c1], g1 = A.gam[c1];
+    consider(h0, v0, x0, y0, z0, a0, w0, g0);
+    if (base + BS < A.nh) consider(h1, v1, x1, y1, z1, a1, w1, g1);
   }
   __syncthreads();
   AGBNP_BUILD_STAMP(8);
