@@ -298,3 +298,26 @@ def test_finite_difference_gradient_on_gpu(gpu_required, systems):
         ctx.setPositions(pm)
         em, _ = ctx.getState()
         assert abs(-(ep - em) / (2 * h) - f[atom, d]) < 2e-4 * max(1.0, abs(f[atom, d]))
+
+
+def test_cxx_mirror_reads_like_the_reference_test(gpu_required, tmp_path):
+    """The C++ host mirror (cpp/AGBNPForce.h) + C ABI from a C++ program shaped like the reference's own
+    TestReferenceAGBNPForce.cpp, on the reference's own fixture, against v0.reference / v1.reference."""
+    import subprocess
+    from tests.pins import REFERENCE_PRINTED
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "TestHipAGBNPForce")
+    libdir = os.path.join(root, "openmm_agbnp_plugin_amd")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "cxx", "TestHipAGBNPForce.cpp"), "-o", exe,
+                    os.path.join(libdir, "libagbnp_hip.so"), f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    data = open(os.path.join(root, "tests", "golden", "fixture264.dat")).read()
+    for version in (0, 1):
+        want = REFERENCE_PRINTED[version]
+        out = subprocess.run([exe, str(version), repr(want["energy"]), repr(want["energy_moved"])], input=data, text=True,
+                             capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.split("\n")
+        assert lines[0] == f"Energy: {want['energy']:g}"
+        assert f"Energy Change: {want['change']:g}" in out.stdout
+        assert f"Energy Change from Gradient: {want['change_from_gradient']:g}" in out.stdout
+        assert "PASS" in out.stdout

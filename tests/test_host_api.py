@@ -125,3 +125,18 @@ def test_dms_loader_matches_exported_fixture(systems, name, dms):
     for x, y in ((a.pos, b.pos), (a.radius, b.radius), (a.gamma, b.gamma), (a.alpha, b.alpha), (a.charge, b.charge)):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a.ishydrogen, b.ishydrogen)
+
+
+def test_cxx_host_mirror_compiles_and_links():
+    """cpp/AGBNPForce.h + the C++ test program build against the shared library (no GPU needed to link)."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "openmm_agbnp_plugin_amd")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "TestHipAGBNPForce")
+        subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cxx", "TestHipAGBNPForce.cpp"), "-o", exe,
+                        os.path.join(libdir, "libagbnp_hip.so"), f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        if _lib.load().agbnp_hip_device_count() == 0:
+            # without a device the program must fail loudly with the engine's message, not fall back to anything
+            out = subprocess.run([exe, "1"], input="1\n0 0 0 0 1.7 0.1 0.117 0\n", text=True, capture_output=True, timeout=60)
+            assert out.returncode != 0 and "no HIP device" in out.stdout
