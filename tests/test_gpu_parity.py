@@ -321,3 +321,38 @@ def test_cxx_mirror_reads_like_the_reference_test(gpu_required, tmp_path):
         assert f"Energy Change: {want['change']:g}" in out.stdout
         assert f"Energy Change from Gradient: {want['change_from_gradient']:g}" in out.stdout
         assert "PASS" in out.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_clusters(gpu_required, seed):
+    """Synthetic compact clusters with many radius types, mixed hydrogens and random charges: exercises type
+    tables, dense overlaps (deep trees) and ragged sizes that the protein fixtures do not."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(40, 330))
+    # dense packing: points on a jittered cubic lattice with 0.21 nm spacing (denser than a protein interior)
+    side = int(np.ceil(n ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    pos = grid * 0.21 + rng.normal(0, 0.02, (n, 3))
+    ish = (rng.random(n) < 0.45).astype(np.int32)
+    radii_pool = np.array([0.12, 0.145, 0.155, 0.17, 0.175, 0.18, 0.19, 0.2])
+    radius = np.where(ish == 1, 0.121, rng.choice(radii_pool, n))
+    gamma = np.where(ish == 1, 0.0, 0.117 * 418.4)
+    charge = rng.normal(0, 0.4, n)
+    from openmm_agbnp_plugin_amd.systems import vdw_alpha_from_radius
+    sysm = P.AGBNPSystem(f"cluster{seed}", pos, radius, gamma, vdw_alpha_from_radius(radius), charge, ish)
+    for version in (0, 1):
+        e, f, ctx = gpu_eval(sysm, version)
+        eo, fo = Oracle(*sysm.params(), version=version).execute(sysm.pos)
+        assert_close(e, f, eo, fo, tol=1e-6)
+
+
+def test_absurd_density_is_a_clean_capacity_error(gpu_required):
+    """Atoms packed far beyond any physical density make the overlap tree explode (> 32768 nodes under one
+    atom): the engine must climb through its variants and then fail with a message, not crash or hang."""
+    rng = np.random.default_rng(3)
+    n = 216
+    grid = np.stack(np.meshgrid(*[np.arange(6)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    pos = grid * 0.10 + rng.normal(0, 0.01, (n, 3))
+    sysm = P.AGBNPSystem("blob", pos, np.full(n, 0.2), np.full(n, 48.9), np.full(n, -1.0), np.zeros(n), np.zeros(n, dtype=np.int32))
+    with pytest.raises(P.OpenMMException, match="exceeds the largest supported capacity"):
+        gpu_eval(sysm, 0)
