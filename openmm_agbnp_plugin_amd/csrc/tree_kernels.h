@@ -78,6 +78,7 @@ struct TreeStore {
   int* ctl;          // [12] workgroup control words (counters, scan partials)
   unsigned short *nla, *npar, *ncs, *ncc;  // [NCAP]
   unsigned short *tstart, *cbase;          // [kTreeBlock + 2] per-batch task start / child base
+  unsigned long long* kmask;               // [TCAP/64] per 64 tasks of a batch: which ones survive the switch
 #ifdef AGBNP_STAMPS
   unsigned long long* stamps;  // [16] diagnostic build only
   static constexpr size_t kStampBytes = 16 * sizeof(unsigned long long) + 8;
@@ -87,7 +88,8 @@ struct TreeStore {
 
   static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 8) +
                                    sizeof(int) * (2 * (size_t)ACAP + 24) +
-                                   sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + kStampBytes;
+                                   sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + 8 +
+                                   sizeof(unsigned long long) * (TCAP / 64) + kStampBytes;
 
   __device__ __forceinline__ void carve(char* base) {
     double* d = reinterpret_cast<double*>(base);
@@ -115,8 +117,9 @@ struct TreeStore {
     ncc = sp + 3 * (size_t)NCAP;
     tstart = sp + 4 * (size_t)NCAP;
     cbase = tstart + (kTreeBlock + 2);
+    kmask = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(cbase + (kTreeBlock + 2)) + 7) & ~(uintptr_t)7);
 #ifdef AGBNP_STAMPS
-    stamps = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(cbase + (kTreeBlock + 2)) + 7) & ~(uintptr_t)7);
+    stamps = kmask + TCAP / 64;
 #endif
   }
 };
@@ -286,6 +289,16 @@ __device__ __forceinline__ int block_inclusive_scan(int v, int tid, int* part, i
 #define AGBNP_BUILD_STAMP_BEGIN()
 #endif
 
+// bits of the tasks [ts, te) (te - ts <= 63) that survived, bit b <-> task ts + b
+__device__ __forceinline__ unsigned long long kept_bits(const unsigned long long* kmask, int ts, int te) {
+  const int len = te - ts;
+  if (len <= 0) return 0ull;
+  const int c0 = ts >> 6, sh = ts & 63;
+  unsigned long long m = kmask[c0] >> sh;
+  if (sh + len > 64) m |= kmask[c0 + 1] << (64 - sh);  // sh > 0 here
+  return m & ((1ull << len) - 1ull);
+}
+
 enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
 
 // ---- build the subtree of heavy atom `hi` (large radii) ---------------------------------------------
@@ -454,7 +467,10 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
         const int la = S.nla[s];
         const double v = dev_merge_volume(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
                                           S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la]);
-        tvol[t] = v > kMinGvol ? v : 0.0;
+        const bool kept = v > kMinGvol;
+        tvol[t] = kept ? v : 0.0;
+        const unsigned long long km = __ballot(kept);  // tasks t0..t0+63 of this wave trip: t0 = t - lane
+        if ((tid & 63) == 0) S.kmask[t >> 6] = km;
       }
       __syncthreads();
       AGBNP_BUILD_STAMP(11);
@@ -462,10 +478,7 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
       // phase 2 (wave 0): children per node, their base slots
       if (tid < 64) {
         int c = 0;
-        if (tid < nin) {
-          const int ts = S.tstart[tid], te = S.tstart[tid + 1];
-          for (int t = ts; t < te; t++) c += tvol[t] > 0.0 ? 1 : 0;
-        }
+        if (tid < nin) c = __popcll(kept_bits(S.kmask, S.tstart[tid], S.tstart[tid + 1]));
         const int cincl = wave_inclusive_scan(c);
         const int cb = tail + cincl - c;
         if (tid < nin) {
@@ -490,7 +503,8 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
           const int kk = nb + j;
           const int ts = S.tstart[j], te = S.tstart[j + 1];
           int rank = 0;
-          for (int u = ts; u < te; u++) {
+          for (unsigned long long m = kept_bits(S.kmask, ts, te); m; m &= m - 1) {  // kept siblings only
+            const int u = ts + __builtin_ctzll(m);
             const double vu = tvol[u];
             rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
           }
