@@ -390,7 +390,8 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     int rank = 0;
     for (int k = 0; k < ncand; k++) {
       const double vk = S.cand_vol[k];
-      rank += (vk > my || (vk == my && S.cand_idx[k] < hj)) ? 1 : 0;
+      rank += vk > my ? 1 : 0;
+      if (vk == my && S.cand_idx[k] < hj) rank++;  // exact tie (incl. k == c: never counted): order by atom index
     }
     const int slot = 1 + rank;  // level-2 node k <-> local atom k
     const int st = NCAP - 1 - c;
