@@ -5,8 +5,7 @@
 // execute() :139-149 -> agbnp_hip_execute_{host,device}, copyParametersToContext() :1796-1815 ->
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
-//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_born_finish -> k_gb_tiles -> k_gb_finish
-//          -> k_dborn_tiles -> k_dborn_finish -> k_tree_pseudo] -> k_outputs
+//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_gb_tiles -> k_dborn_tiles -> k_tree_pseudo] -> k_outputs
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
 // point that computes fails with AGBNP_HIP_ERR_DEVICE.
@@ -90,7 +89,7 @@ struct agbnp_hip_context {
   DevBuf<double4> d_aposq, d_hposs;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
-  DevBuf<double2> d_bws, d_bornb;
+  DevBuf<double> d_scale;
   DevBuf<SubtreeHeader> d_hdr;
   DevBuf<ushort4> d_node_pool;
   DevBuf<int> d_atom_pool;
@@ -233,8 +232,7 @@ void wire_args(agbnp_hip_context* c) {
   P.born_fp = c->d_born_fp.p;
   P.brw = c->d_brw.p;
   P.e_atom = c->d_e_atom.p;
-  P.bws = c->d_bws.p;
-  P.bornb = c->d_bornb.p;
+  P.scale = c->d_scale.p;
   const size_t row = (size_t)c->n;
   P.gb_fx = c->d_gbf.p;
   P.gb_fy = c->d_gbf.p + c->n;
@@ -258,6 +256,9 @@ void wire_args(agbnp_hip_context* c) {
   T.a_vdw = c->d_a_vdw.p;
   T.v_vdw = c->d_v_vdw.p;
   T.gam = c->d_gam.p;
+  T.db_wu = c->d_dbf.p + 3 * (size_t)c->n;
+  T.inv_vol_h = c->d_inv_vol_h.p;
+  T.h2a = c->d_h2a.p;
   T.gx = c->d_gx.p;
   T.gy = c->d_gy.p;
   T.gz = c->d_gz.p;
@@ -326,8 +327,8 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_born_fp.alloc(n));
   HIP_TRY(c, c->d_brw.alloc(n));
   HIP_TRY(c, c->d_e_atom.alloc(n));
-  HIP_TRY(c, c->d_bws.alloc(n));
-  HIP_TRY(c, c->d_bornb.alloc(n));
+  HIP_TRY(c, c->d_scale.alloc(n));
+  HIP_TRY(c, hipMemset(c->d_scale.p, 0, sizeof(double) * n));
   HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
@@ -641,9 +642,8 @@ int agbnp_hip_set_profiling(agbnp_hip_context* c, int enabled) {
 int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
-  static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_scale",       "k_born_pairs",
-                                            "k_born_finish", "k_gb_tiles",    "k_gb_finish",   "k_dborn_tiles",
-                                            "k_dborn_finish", "k_tree_pseudo", "k_outputs"};
+  static const char* names[kKernelCount] = {"k_prep",     "k_tree_cavity", "k_scale",       "k_born_pairs",
+                                            "k_gb_tiles", "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 

@@ -44,8 +44,7 @@ struct PairArgs {
   // ---- pair-stage intermediates
   double* born_part;       // [n] sum_j s_j Q (atomic sums of the j-range workgroups)
   double *born, *born_fp, *brw, *e_atom;  // [n]
-  double2* bws;            // [n] {brw+bru, scale}
-  double2* bornb;          // [n] {B, 1/B}
+  double* scale;           // [n] volume scaling factor s_i (0 for hydrogens)
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
   const int* gb_items;     // [gb_items_count] work items of k_gb_tiles / k_dborn_tiles: I | J<<12 | part<<24
   int gb_items_count;

@@ -1,6 +1,10 @@
 // Pair stages of AGBNP1 on gfx950: inverse Born radii, GB pair energy/forces, Born-radius chain-rule
 // forces, plus the per-atom glue between them.
 //
+// Per-atom glue (Born radius from the descreening sum, bru from Y, nu from W+U) has no kernels of its own: the
+// consumer recomputes it from the finished sums in its prologue, which costs a few dozen flops per atom and
+// saves three launches per evaluation.
+//
 // Reference semantics (platforms/reference/src/ReferenceAGBNPKernels.cpp, restated in oracle run_v1()):
 //   :420-433  volume scaling factors s_i = selfvol_i / (4 pi R_i^3 / 3)
 //   :435-454  beta_i = 1/R_i - (1/4pi) sum_{j heavy, j!=i, d<2nm} s_j Q(d; type_i, type_j);  B_i, f'_i (:41-55)
@@ -108,7 +112,9 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
 __global__ __launch_bounds__(256) void k_scale(PairArgs P) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= P.nh) return;
-  P.hposs[h] = make_double4(P.hx[h], P.hy[h], P.hz[h], P.sv_vdw[h] * P.inv_vol_h[h]);
+  const double sj = P.sv_vdw[h] * P.inv_vol_h[h];
+  P.hposs[h] = make_double4(P.hx[h], P.hy[h], P.hz[h], sj);
+  P.scale[P.h2a[h]] = sj;  // hydrogens keep the 0 they were created with
 }
 
 // ---- inverse Born radii: partial sums over a j range ---------------------------------------------------
@@ -171,33 +177,24 @@ __global__ __launch_bounds__(kPairBlock) void k_born_pairs(int n, int nh, int hc
   }
 }
 
-// ---- per atom: beta -> B, f', vdW energy, GB self energy, brw, scale factor -----------------------------
-__global__ __launch_bounds__(256) void k_born_finish(PairArgs P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  const double pifac = 1. / (4. * kPi);
-  const double s = P.born_part[i];
-  const double beta = P.inv_rvdw[i] - pifac * s;
-  // ReferenceAGBNPKernels.cpp:41-55
-  const double amin = 1. / kI4MaxA;
-  const double a2 = 1. / (kI4MaxA * kI4MaxA);
-  double t, fp;
+// ---- per-atom Born-radius algebra, recomputed by its consumers instead of a kernel of its own ---------------
+// beta_i = 1/R_i - (1/4pi) sum_j s_j Q  ->  B_i = 1/f(beta_i), f' (ReferenceAGBNPKernels.cpp:41-55,450-454)
+struct BornRadius {
+  double br, inv_br, fp;
+};
+__device__ __forceinline__ BornRadius born_radius(double inv_rvdw, double qsum) {
+  const double beta = inv_rvdw - (1. / (4. * kPi)) * qsum;
+  const double amin = 1. / kI4MaxA, a2 = 1. / (kI4MaxA * kI4MaxA);
+  BornRadius r;
   if (beta < 0.0) {
-    t = amin;
-    fp = 0.0;
+    r.inv_br = amin;
+    r.fp = 0.0;
   } else {
-    t = sqrt(a2 + beta * beta);
-    fp = beta / t;
+    r.inv_br = sqrt(a2 + beta * beta);
+    r.fp = beta / r.inv_br;
   }
-  const double br = 1. / t;
-  P.born[i] = br;
-  P.bornb[i] = make_double2(br, t);  // {B, 1/B} for the GB pair loop
-  P.born_fp[i] = fp;
-  const double q = P.charge[i], alpha = P.alpha[i];
-  const double bh = br + kHBRadius;
-  const double bh3 = bh * bh * bh;
-  P.e_atom[i] = alpha / bh3 + kDielFactor * q * q / br;
-  P.brw[i] = -pifac * 3. * alpha * br * br * fp / (bh3 * bh);
+  r.br = 1. / r.inv_br;
+  return r;
 }
 
 // ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
@@ -217,7 +214,10 @@ __device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 6
 }
 
 __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
-                                                 const double2* __restrict__ bornb, double* __restrict__ gb_fx,
+                                                 const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
+                                                 const double* __restrict__ alpha, double* __restrict__ born,
+                                                 double* __restrict__ born_fp, double* __restrict__ brw,
+                                                 double* __restrict__ e_atom, double* __restrict__ gb_fx,
                                                  double* __restrict__ gb_fy, double* __restrict__ gb_fz,
                                                  double* __restrict__ gb_y, double* __restrict__ egb_part) {
   const int lane = threadIdx.x;
@@ -228,14 +228,28 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
   const int start = (diag ? 1 : 0) + nsteps * part;  // cyclic offset of the first j met by lane l
   const int i = 64 * I + lane;
   const bool vi = i < n;
-  const double4 pi = aposq[vi ? i : n - 1];
-  const double2 bi = bornb[vi ? i : n - 1];
+  const int ic = vi ? i : n - 1;
+  const double4 pi = aposq[ic];
+  // Born radii from the finished descreening sums (every item recomputes them for its 128 atoms: a few dozen
+  // flops per atom against 32 x 64 pair evaluations, and one kernel launch less per evaluation)
+  const BornRadius bri = born_radius(inv_rvdw[ic], born_part[ic]);
+  const double2 bi = make_double2(bri.br, bri.inv_br);
   const double qi = vi ? pi.w : 0.0;
+  if (diag && part == 0 && vi) {
+    // the diagonal item of a block publishes the per-atom results exactly once:
+    // B_i, f'_i, vdW energy + GB self energy, brw_i (ReferenceAGBNPKernels.cpp:477,513-533)
+    const double bh = bri.br + kHBRadius, bh3 = bh * bh * bh, al = alpha[i];
+    born[i] = bri.br;
+    born_fp[i] = bri.fp;
+    e_atom[i] = al / bh3 + kDielFactor * pi.w * pi.w * bri.inv_br;
+    brw[i] = -(1. / (4. * kPi)) * 3. * al * bri.br * bri.br * bri.fp / (bh3 * bh);
+  }
   const int j = 64 * J + ((lane + start) & 63);
   const bool vj = j < n;
-  const double4 pj0 = aposq[vj ? j : n - 1];
-  const double2 bj0 = bornb[vj ? j : n - 1];
-  double xj = pj0.x, yj = pj0.y, zj = pj0.z, qj = vj ? pj0.w : 0.0, bj = bj0.x, ibj = bj0.y;
+  const int jc = vj ? j : n - 1;
+  const double4 pj0 = aposq[jc];
+  const BornRadius brj = born_radius(inv_rvdw[jc], born_part[jc]);
+  double xj = pj0.x, yj = pj0.y, zj = pj0.z, qj = vj ? pj0.w : 0.0, bj = brj.br, ibj = brj.inv_br;
   double fxi = 0, fyi = 0, fzi = 0, yi = 0, fxj = 0, fyj = 0, fzj = 0, yj_acc = 0, e = 0;
 #pragma unroll 2
   for (int k = 0; k < nsteps; k++) {
@@ -288,18 +302,6 @@ __global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ 
   if (lane == 0) egb_part[blockIdx.x] = e;
 }
 
-// ---- per atom: Y -> bru, bw = brw + bru ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gb_finish(PairArgs P) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  const double pifac = 1. / (4. * kPi);
-  const double y = P.gb_y[i];
-  const double q = P.charge[i], br = P.born[i];
-  const double bru = -pifac * kDielFactor * (q * q + y * br) * P.born_fp[i];
-  const int h = P.a2h[i];
-  P.bws[i] = make_double2(P.brw[i] + bru, h >= 0 ? P.hposs[h].w : 0.0);
-}
-
 // ---- Born-radius chain rule, symmetric 64x64 tiles with range culling -------------------------------------
 // Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
 //   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
@@ -310,7 +312,9 @@ __device__ __forceinline__ int rot1i(int v) { return __builtin_amdgcn_update_dpp
 
 __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int ntj, int lut_entries, int nitems, const int* __restrict__ items,
                                                     const double* __restrict__ abox, const double4* __restrict__ aposq,
-                                                    const int2* __restrict__ ameta, const double2* __restrict__ bws,
+                                                    const int2* __restrict__ ameta, const double* __restrict__ born,
+                                                    const double* __restrict__ born_fp, const double* __restrict__ brw,
+                                                    const double* __restrict__ gb_y, const double* __restrict__ scale,
                                                     const double2* __restrict__ lut, double* __restrict__ db_fx,
                                                     double* __restrict__ db_fy, double* __restrict__ db_fz,
                                                     double* __restrict__ db_wu) {
@@ -338,14 +342,20 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int ntj, int lut_ent
   const int start = (diag ? 1 : 0) + nsteps * part;
   const int i = 64 * I + lane;
   const bool vi = i < n;
+  // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
+  // formed here from the finished GB sums instead of a per-atom kernel in between
+  auto weights = [&](int a, double q) {
+    const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
+    return make_double2(brw[a] + bru, scale[a]);
+  };
   const double4 pi = aposq[vi ? i : n - 1];
-  const double2 wi = vi ? bws[i] : make_double2(0.0, 0.0);  // {bw_i, s_i}; zero weights switch a padded lane off
+  const double2 wi = vi ? weights(i, pi.w) : make_double2(0.0, 0.0);  // zero weights switch a padded lane off
   const int2 mi = ameta[vi ? i : n - 1];                    // {screened type, screener type or -1}
   const int tsr_i = vi ? mi.y : -1;
   const int j = 64 * J + ((lane + start) & 63);
   const bool vj = j < n;
   const double4 pj0 = aposq[vj ? j : n - 1];
-  const double2 wj0 = vj ? bws[j] : make_double2(0.0, 0.0);
+  const double2 wj0 = vj ? weights(j, pj0.w) : make_double2(0.0, 0.0);
   const int2 mj0 = ameta[vj ? j : n - 1];
   double xj = pj0.x, yj = pj0.y, zj = pj0.z, bwj = wj0.x, sj = wj0.y;
   int tj = mj0.x | (((vj ? mj0.y : -1) + 1) << 16);  // screened type | (screener type + 1) << 16
@@ -406,14 +416,6 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int ntj, int lut_ent
     hbm_add(&db_fz[jid], fzj);
     hbm_add(&db_wu[jid], wuj);
   }
-}
-
-// ---- per heavy atom: nu_i = (W_i + U_i) / V_i for the pseudo-volume pass --------------------------------
-__global__ __launch_bounds__(256) void k_dborn_finish(PairArgs P) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= P.nh) return;
-  const int a = P.h2a[h];
-  P.gam[h] = P.db_wu[a] * P.inv_vol_h[h];
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -603,24 +605,16 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(kPairBlock), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
                      (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKBornFinish);
-  hipLaunchKernelGGL(k_born_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
-  AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKGbPairs);
+  AGBNP_MARK(kKGbTiles);
   hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(64), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                     (const double2*)P.bornb, P.gb_fx, P.gb_fy, P.gb_fz, P.gb_y, P.egb_part);
+                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.gb_fy,
+                     P.gb_fz, P.gb_y, P.egb_part);
   AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKGbFinish);
-  hipLaunchKernelGGL(k_gb_finish, dim3((P.n + 255) / 256), dim3(256), 0, st, P);
-  AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKDbornPairs);
+  AGBNP_MARK(kKDbornTiles);
   hipLaunchKernelGGL(k_dborn_tiles, dim3((P.gb_items_count + 3) / 4), dim3(256), lds, st, P.n, P.ntj, P.lut_entries,
-                     P.gb_items_count, P.gb_items,
-                     (const double*)P.abox, (const double4*)P.aposq, P.ameta, (const double2*)P.bws, P.lut, P.db_fx, P.db_fy,
-                     P.db_fz, P.db_wu);
-  AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKDbornFinish);
-  hipLaunchKernelGGL(k_dborn_finish, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
+                     P.gb_items_count, P.gb_items, (const double*)P.abox, (const double4*)P.aposq, P.ameta,
+                     (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
+                     (const double*)P.scale, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }

@@ -42,7 +42,11 @@ struct TreeArgs {
   const int* order;            // [nh] subtree processing order (largest subtree of the previous evaluation first)
   const double *hx, *hy, *hz;  // heavy-atom positions (SoA, heavy index)
   const double *a_large, *v_large, *a_vdw, *v_vdw;  // Gaussian exponent / volume per heavy atom
-  const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam); pass 3: (W+U)/V_vdw
+  const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam)
+  // pass 3 (pseudo-volume): nu_i = (W_i + U_i) / V_i (ReferenceAGBNPKernels.cpp:718-722,738-742), formed on the fly
+  const double* db_wu;      // [n] W+U per atom
+  const double* inv_vol_h;  // [nh]
+  const int* h2a;           // [nh]
   double rcut2;       // conservative squared cutoff of the 2-body overlap search
   double* gx;         // [nh] gradient accumulators (dE/dr), heavy index
   double* gy;

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       S.at[2][la] = A.hz[hj];
       S.at[3][la] = A.a_vdw[hj];
       S.at[4][la] = A.v_vdw[hj];
-      S.at[5][la] = A.gam[hj];
+      S.at[5][la] = A.db_wu[A.h2a[hj]] * A.inv_vol_h[hj];
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
       S.at[8][la] = 0.0;
