@@ -85,12 +85,12 @@ struct agbnp_hip_context {
   hipEvent_t ev_tree_built = nullptr, ev_large_done = nullptr;
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items, d_db_items, d_pslot;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
   DevBuf<int2> d_ameta, d_hmeta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
-  DevBuf<double> d_abox, d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
+  DevBuf<double> d_pbox, d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
   DevBuf<double4> d_aposq, d_hposs;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -222,7 +222,12 @@ void wire_args(agbnp_hip_context* c) {
   P.hy = c->d_hy.p;
   P.hz = c->d_hz.p;
   P.aposq = c->d_aposq.p;
-  P.abox = c->d_abox.p;
+  P.pbox = c->d_pbox.p;
+  P.pslot = c->d_pslot.p;
+  P.nslots = (int)c->d_pslot.count;
+  P.nhb = (c->nh + 63) / 64;
+  P.db_items = c->d_db_items.p;
+  P.db_items_count = (int)c->d_db_items.count;
   P.hposs = c->d_hposs.p;
   P.gx = c->d_gx.p;
   P.gy = c->d_gy.p;
@@ -296,17 +301,36 @@ int allocate_work(agbnp_hip_context* c) {
   c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);
   c->P.hsplits = std::max(1, (nh + c->P.hchunk - 1) / c->P.hchunk);
   {
-    // work items of the symmetric GB tile kernel: four quarters per off-diagonal tile, then two per diagonal tile
+    // work items of the symmetric GB tile kernel: one workgroup per tile, off-diagonal tiles first
     if (nblk > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 particles are not supported by the tile index encoding");
     std::vector<int> items;
     items.reserve((size_t)nblk * nblk);
     for (int I = 0; I < nblk; I++)
-      for (int J = I + 1; J < nblk; J++)
-        for (int part = 0; part < 64 / AGBNP_GB_STEPS; part++) items.push_back(I | (J << 12) | (part << 24));
-    for (int I = 0; I < nblk; I++)
-      for (int part = 0; part < 32 / (AGBNP_GB_STEPS < 32 ? AGBNP_GB_STEPS : 32); part++) items.push_back(I | (I << 12) | (part << 24));
+      for (int J = I + 1; J < nblk; J++) items.push_back(I | (J << 12));
+    for (int I = 0; I < nblk; I++) items.push_back(I | (I << 12));
     HIP_TRY(c, c->d_gb_items.upload(items));
     c->P.egb_parts = (int)items.size();
+  }
+  {
+    // pair order of the chain-rule stage: heavy atoms, padding, hydrogens, padding (blocks of 64 slots), and its
+    // work items: symmetric heavy x heavy tiles first (two look-ups per pair), then the heavy x H tiles
+    const int nhb = (nh + 63) / 64, nlb = (n - nh + 63) / 64;
+    std::vector<int> pslot((size_t)(nhb + nlb) * 64, -1);
+    for (int h = 0; h < nh; h++) pslot[h] = c->h2a[h];
+    int k = nhb * 64;
+    for (int i = 0; i < n; i++)
+      if (c->a2h[i] < 0) pslot[k++] = i;
+    if (pslot.empty()) pslot.assign(64, -1);
+    HIP_TRY(c, c->d_pslot.upload(pslot));
+    std::vector<int> items;
+    for (int I = 0; I < nhb; I++)
+      for (int J = I + 1; J < nhb; J++) items.push_back(I | (J << 12));
+    for (int I = 0; I < nhb; I++)
+      for (int J = nhb; J < nhb + nlb; J++) items.push_back(I | (J << 12));
+    for (int I = 0; I < nhb; I++) items.push_back(I | (I << 12));
+    if (items.empty()) items.push_back(0);
+    HIP_TRY(c, c->d_db_items.upload(items));
+    if (nh == 0) c->d_db_items.count = 0;
   }
 
   HIP_TRY(c, c->d_status.alloc(kStatWords));
@@ -323,7 +347,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_epart.alloc(2 * nhp));
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
   HIP_TRY(c, c->d_aposq.alloc(n));
-  HIP_TRY(c, c->d_abox.alloc(6 * (size_t)nblk));
+  HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
   HIP_TRY(c, c->d_hposs.alloc(nhp));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
@@ -500,7 +524,7 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   std::vector<double2> lut(std::max<size_t>(1, c->lut.y.size()));
   for (size_t k = 0; k < c->lut.y.size(); k++) lut[k] = make_double2(c->lut.y[k], c->lut.y2[k] * dr * dr / 6.0);
   CREATE_TRY(c->d_lut.upload(lut));
-  if ((size_t)c->lut.y.size() * sizeof(double2) > 150 * 1024)
+  if ((size_t)c->lut.y.size() * sizeof(double2) > 128 * 1024)  // + 24 KB of tile records in k_dborn_tiles
     return bail(AGBNP_HIP_ERR_CAPACITY, "agbnp_hip_create: too many distinct radius pairs for the LDS-resident I4 tables", c);
 
   int rc = upload_parameters(c);

@@ -6,10 +6,6 @@
 
 #include "agbnp_common.h"
 
-#ifndef AGBNP_GB_STEPS
-#define AGBNP_GB_STEPS 32
-#endif
-
 namespace agbnp {
 
 struct PairArgs {
@@ -31,7 +27,9 @@ struct PairArgs {
   // ---- geometry (SoA for the tree, packed records for the pair loops)
   double *hx, *hy, *hz;    // [nh]
   double4* aposq;          // [n] {x,y,z,q}
-  double* abox;            // [ceil(n/64)][6] bounding box {min xyz, max xyz} of every 64-atom block
+  const int* pslot;        // [nslots] pair order: heavy atoms, padding (-1) to a block of 64, hydrogens, padding
+  int nslots, nhb;         // slots (multiple of 64), heavy blocks
+  double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
   double4* hposs;          // [nh] {x,y,z,s_j}
   // ---- tree accumulators / outputs
   double *gx, *gy, *gz;    // [nh]
@@ -46,8 +44,10 @@ struct PairArgs {
   double *born, *born_fp, *brw, *e_atom;  // [n]
   double* scale;           // [n] volume scaling factor s_i (0 for hydrogens)
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
-  const int* gb_items;     // [gb_items_count] work items of k_gb_tiles / k_dborn_tiles: I | J<<12 | part<<24
+  const int* gb_items;     // [gb_items_count] tiles of k_gb_tiles: I | J<<12 (64-atom blocks, atom order, I <= J)
   int gb_items_count;
+  const int* db_items;     // [db_items_count] tiles of k_dborn_tiles, same encoding over blocks of pair-order slots
+  int db_items_count;
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force and W+U (atomic sums)
   double* egb_part;        // [egb_parts]
   int hsplits, hchunk;     // split of the heavy-atom j range (Born)

@@ -20,6 +20,8 @@
 // from both ends instead of scattering the reaction force; the I4 spline tables sit in LDS.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "agbnp_common.h"
 #include "pair_kernels.h"
 
@@ -51,6 +53,10 @@ __device__ __forceinline__ void spline_value_deriv(const double2* __restrict__ t
 }
 
 __device__ __forceinline__ void hbm_add(double* p, double v) {  // global_atomic_add_f64
+#ifdef AGBNP_TIMING_NO_ATOMICS  // timing experiment only: results are wrong
+  if (v == 1.2345e300) *p = v;
+  return;
+#endif
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -63,22 +69,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kStatWords && blockIdx.x == 0) P.status[i] = 0;
-  {
-    // bounding box of every block of 64 consecutive atoms (one wave each) for the tile culling of the
-    // range-limited pair stages
-    const int ic = i < P.n ? i : P.n - 1;
+  if (i < P.nslots) {
+    // bounding box of every block of 64 slots in pair order (one wave each) for the tile culling of the
+    // chain-rule stage; padding slots are neutral
+    const int a = P.pslot[i];
     double lo[3], hi[3];
-    for (int d = 0; d < 3; d++) lo[d] = hi[d] = P.pos[3 * ic + d];
+    for (int d = 0; d < 3; d++) {
+      lo[d] = a >= 0 ? P.pos[3 * a + d] : 1e30;
+      hi[d] = a >= 0 ? lo[d] : -1e30;
+    }
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; d++) {
         lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
         hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
       }
-    const int blk = i >> 6;
-    if ((i & 63) == 0 && blk * 64 < P.n) {
+    if ((i & 63) == 0) {
       for (int d = 0; d < 3; d++) {
-        P.abox[6 * blk + d] = lo[d];
-        P.abox[6 * blk + 3 + d] = hi[d];
+        P.pbox[6 * (i >> 6) + d] = lo[d];
+        P.pbox[6 * (i >> 6) + 3 + d] = hi[d];
       }
     }
   }
@@ -198,224 +206,304 @@ __device__ __forceinline__ BornRadius born_radius(double inv_rvdw, double qsum) 
 }
 
 // ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
-// A wave owns one half of a tile (I <= J): lane l keeps atom i = 64 I + l and its sums in registers, a second
-// register set (record + sums of one j atom of block J) travels round the wave by DPP wave rotation, so every
-// (i, j) pair of the tile meets exactly once and both ends are updated from one evaluation of the pair terms
-// (half the FP64 work of the row form; no LDS, no vector memory in the loop).  Off-diagonal tiles are cut in
-// four work items of 16 rotations; a diagonal tile is two items that visit cyclic distances 1..32 (distance 32
-// only from the lower half of the lanes).  Per-atom sums leave through FP64 HBM atomics into single rows.
-constexpr int kGbSteps = AGBNP_GB_STEPS;  // rotations per work item: 64 = a whole off-diagonal tile, 32 = half, 16 = quarter
+// A workgroup of four waves owns one tile (I <= J).  In every wave lane l keeps atom i = 64 I + l and its sums in
+// registers and meets a quarter of block J in cyclic order: the static record of a j atom (position, charge, B,
+// 1/B) is read from a doubled copy of the block in LDS (the step number is an immediate offset, no address
+// arithmetic), the four running sums of the j atom travel round the wave by DPP wave rotation, so every (i, j)
+// pair of the tile meets exactly once and both ends are updated from one evaluation of the pair terms (half the
+// FP64 work of the row form, no vector memory in the loop).  A diagonal tile visits cyclic distances 1..32
+// (distance 32 only from the lower half of the lanes).  The sums of the four waves meet in LDS and leave as one
+// set of FP64 HBM atomics per tile.
 
-__device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 64)
+__device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 64); bound_ctrl: no "old" operand to set up
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x134, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x134, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x134, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x134, 0xf, 0xf, true);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ __launch_bounds__(64) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
-                                                 const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
-                                                 const double* __restrict__ alpha, double* __restrict__ born,
-                                                 double* __restrict__ born_fp, double* __restrict__ brw,
-                                                 double* __restrict__ e_atom, double* __restrict__ gb_fx,
-                                                 double* __restrict__ gb_fy, double* __restrict__ gb_fz,
-                                                 double* __restrict__ gb_y, double* __restrict__ egb_part) {
-  const int lane = threadIdx.x;
-  const int item = items[blockIdx.x];
-  const int I = item & 0xfff, J = (item >> 12) & 0xfff, part = (item >> 24) & 3;
-  const bool diag = I == J;
-  const int nsteps = diag ? (kGbSteps < 32 ? kGbSteps : 32) : kGbSteps;
-  const int start = (diag ? 1 : 0) + nsteps * part;  // cyclic offset of the first j met by lane l
-  const int i = 64 * I + lane;
-  const bool vi = i < n;
-  const int ic = vi ? i : n - 1;
-  const double4 pi = aposq[ic];
-  // Born radii from the finished descreening sums (every item recomputes them for its 128 atoms: a few dozen
-  // flops per atom against 32 x 64 pair evaluations, and one kernel launch less per evaluation)
-  const BornRadius bri = born_radius(inv_rvdw[ic], born_part[ic]);
-  const double2 bi = make_double2(bri.br, bri.inv_br);
-  const double qi = vi ? pi.w : 0.0;
-  if (diag && part == 0 && vi) {
-    // the diagonal item of a block publishes the per-atom results exactly once:
-    // B_i, f'_i, vdW energy + GB self energy, brw_i (ReferenceAGBNPKernels.cpp:477,513-533)
-    const double bh = bri.br + kHBRadius, bh3 = bh * bh * bh, al = alpha[i];
-    born[i] = bri.br;
-    born_fp[i] = bri.fp;
-    e_atom[i] = al / bh3 + kDielFactor * pi.w * pi.w * bri.inv_br;
-    brw[i] = -(1. / (4. * kPi)) * 3. * al * bri.br * bri.br * bri.fp / (bh3 * bh);
+// 2^y for y <= 0, relative error 4.4e-16 on the reduced interval, no special cases: the argument is clamped at
+// -96 (2^-96 is far below the resolution of every sum it enters) so the exponent arithmetic cannot underflow.
+// Round-to-nearest split through the 1.5*2^52 constant (the integer lands in the low mantissa word), degree-10
+// interpolant of 2^f on |f| <= 1/2, exponent added with integer arithmetic.
+__device__ __forceinline__ double exp2_nonpositive(double y) {
+  y = fmax(y, -96.0);
+  const double kShift = 6755399441055744.0;
+  const double t = y + kShift;
+  const double f = y - (t - kShift);
+  double p = 0x1.e6063f7217bc6p-28;
+  p = fma(p, f, 0x1.b675bca4eeebbp-24);
+  p = fma(p, f, 0x1.62bfd47773353p-20);
+  p = fma(p, f, 0x1.ffcb54062e698p-17);
+  p = fma(p, f, 0x1.430913096fd9fp-13);
+  p = fma(p, f, 0x1.5d87fe9d7a584p-10);
+  p = fma(p, f, 0x1.3b2ab6fba1ddap-7);
+  p = fma(p, f, 0x1.c6b08d703ce49p-5);
+  p = fma(p, f, 0x1.ebfbdff82c598p-3);
+  p = fma(p, f, 0x1.62e42fefa3a19p-1);
+  p = fma(p, f, 1.0);
+  const int n = __double2loint(t);
+  return __hiloint2double(__double2hiint(p) + (n << 20), __double2loint(p));
+}
+
+// 1/sqrt(u) for normal positive u: hardware seed and one third-order correction (error ~ seed error cubed)
+__device__ __forceinline__ double rsqrt_pos(double u) {
+  const double y0 = __builtin_amdgcn_rsq(u);
+  const double e = fma(-(u * y0), y0, 1.0);
+  return fma(y0 * e, fma(0.375, e, 0.5), y0);
+}
+
+// Epilogue shared by the two tile kernels: the four waves of a tile hold partial sums for the same 64 i atoms
+// (lane = atom) and, rotated, for the same 64 j atoms.  They meet in LDS and leave as ONE set of FP64 HBM
+// atomics per tile (8 rows of 64), added in a fixed order within the tile.  Float atomics execute at the memory
+// side at a fixed chip-wide byte rate, so the bytes they carry are what has to be kept small.
+struct TileSums {
+  double red[4][8][64];
+};
+__device__ __forceinline__ void tile_sums_store(TileSums& T, int wave, int lane, int jslot, const double (&vi)[4], const double (&vj)[4]) {
+  for (int q = 0; q < 4; q++) {
+    T.red[wave][q][lane] = vi[q];
+    T.red[wave][4 + q][jslot] = vj[q];
   }
-  const int j = 64 * J + ((lane + start) & 63);
-  const bool vj = j < n;
-  const int jc = vj ? j : n - 1;
-  const double4 pj0 = aposq[jc];
-  const BornRadius brj = born_radius(inv_rvdw[jc], born_part[jc]);
-  double xj = pj0.x, yj = pj0.y, zj = pj0.z, qj = vj ? pj0.w : 0.0, bj = brj.br, ibj = brj.inv_br;
+}
+__device__ __forceinline__ double tile_sums_fold(const TileSums& T, int row, int lane) {
+  return (T.red[0][row][lane] + T.red[1][row][lane]) + (T.red[2][row][lane] + T.red[3][row][lane]);
+}
+
+__global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
+                                                  const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
+                                                  const double* __restrict__ alpha, double* __restrict__ born,
+                                                  double* __restrict__ born_fp, double* __restrict__ brw,
+                                                  double* __restrict__ e_atom, double* __restrict__ gb_rows,
+                                                  double* __restrict__ egb_part) {
+  __shared__ double2 s_xy[128], s_zq[128], s_bb[128];  // block J twice over: entry m and m + 64 are atom 64 J + m
+  __shared__ double2 s_ixy[64], s_izq[64], s_ibc[64];   // block I: {x, y}, {z, q}, {B, -log2(e)/(4 B)}
+  __shared__ TileSums s_sums;
+  __shared__ double s_e[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = items[blockIdx.x];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff;
+  const bool diag = I == J;
+  // Born radii from the finished descreening sums (every tile recomputes them for its 128 atoms: a few dozen
+  // flops per atom against 4096 pair evaluations, and one kernel launch less per evaluation):
+  // wave 0 prepares block J, wave 1 block I
+  if (wave < 2) {
+    const int a = 64 * (wave == 0 ? J : I) + lane;
+    const bool va = a < n;
+    const int ac = va ? a : n - 1;
+    const double4 pa = aposq[ac];
+    const BornRadius bra = born_radius(inv_rvdw[ac], born_part[ac]);
+    const double qa = va ? pa.w : 0.0;  // zero charge switches a padded atom off
+    if (wave == 0) {
+      s_xy[lane] = s_xy[lane + 64] = make_double2(pa.x, pa.y);
+      s_zq[lane] = s_zq[lane + 64] = make_double2(pa.z, qa);
+      s_bb[lane] = s_bb[lane + 64] = make_double2(bra.br, bra.inv_br);
+    } else {
+      s_ixy[lane] = make_double2(pa.x, pa.y);
+      s_izq[lane] = make_double2(pa.z, qa);
+      s_ibc[lane] = make_double2(bra.br, (-0.25 * 1.4426950408889634074) * bra.inv_br);
+      if (diag && va) {
+        // the diagonal tile of a block publishes the per-atom results exactly once:
+        // B_i, f'_i, vdW energy + GB self energy, brw_i (ReferenceAGBNPKernels.cpp:477,513-533)
+        const double bh = bra.br + kHBRadius, bh3 = bh * bh * bh, al = alpha[a];
+        born[a] = bra.br;
+        born_fp[a] = bra.fp;
+        e_atom[a] = al / bh3 + kDielFactor * pa.w * pa.w * bra.inv_br;
+        brw[a] = -(1. / (4. * kPi)) * 3. * al * bra.br * bra.br * bra.fp / (bh3 * bh);
+      }
+    }
+  }
+  __syncthreads();
+  // the four waves take a quarter of the cyclic distances each (diagonal tile: distances 1..32, 8 per wave)
+  const int nsteps = diag ? 8 : 16;
+  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
+  const double2 ixy = s_ixy[lane], izq = s_izq[lane], ibc = s_ibc[lane];
+  const double xi = ixy.x, yi_ = ixy.y, zi = izq.x, qi = izq.y, bi = ibc.x, ci = ibc.y;
+  // diagonal tile, cyclic distance 32 (the last step of the last wave): the pair (l, l+32) would otherwise be
+  // met from both ends
+  const int masked_step = diag ? 32 - start : -1;
+  const double qlast = lane >= 32 ? 0.0 : qi;
+  const int base = (lane + start) & 63;
+  const double2* __restrict__ jxy = s_xy + base;
+  const double2* __restrict__ jzq = s_zq + base;
+  const double2* __restrict__ jbb = s_bb + base;
+  // sums in units that leave the constant factors to the epilogue:
+  //   e = sum qq f,  F_i = -2k sum D qq (1 - et/4) f^3,  Y = sum qq (B_i B_j + d^2/4) et f^3   (qq = q_i q_j)
   double fxi = 0, fyi = 0, fzi = 0, yi = 0, fxj = 0, fyj = 0, fzj = 0, yj_acc = 0, e = 0;
-#pragma unroll 2
+#pragma unroll 8
   for (int k = 0; k < nsteps; k++) {
-    const double dx = xj - pi.x, dy = yj - pi.y, dz = zj - pi.z;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    const double bb = bi.x * bj;
-    const double et = exp(-0.25 * d2 * (bi.y * ibj));  // exp(-d^2 / (4 B_i B_j))
-    const double fgb = rsqrt(d2 + bb * et);
-    const double fgb3 = fgb * fgb * fgb;
-    // diagonal tile, cyclic distance 32: the pair (l, l+32) would otherwise be met from both ends
-    const double qqf = (diag && start + k == 32 && lane >= 32) ? 0.0 : qi * qj;
-    const double qq = kDielFactor * qqf;
-    e += 2.0 * qq * fgb;
-    const double mw = -2.0 * qq * (1.0 - 0.25 * et) * fgb3;
-    const double gx = dx * mw, gy = dy * mw, gz = dz * mw;
-    fxi += gx;
-    fyi += gy;
-    fzi += gz;
-    fxj -= gx;
-    fyj -= gy;
-    fzj -= gz;
-    const double yt = qqf * (bb + 0.25 * d2) * et * fgb3;
+    const double2 xy = jxy[k], zq = jzq[k], bj = jbb[k];
+    const double dx = xy.x - xi, dy = xy.y - yi_, dz = zq.x - zi;
+    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const double bb = bi * bj.x;
+    const double et = exp2_nonpositive(d2 * (ci * bj.y));  // exp(-d^2 / (4 B_i B_j))
+    const double fgb = rsqrt_pos(fma(bb, et, d2));
+    const double qq = (k == masked_step ? qlast : qi) * zq.y;
+    const double s1 = qq * fgb;
+    e += s1;
+    const double s3 = s1 * (fgb * fgb);
+    const double mw = fma(-0.25, et, 1.0) * s3;
+    fxi = fma(dx, mw, fxi);
+    fyi = fma(dy, mw, fyi);
+    fzi = fma(dz, mw, fzi);
+    fxj = fma(-dx, mw, fxj);
+    fyj = fma(-dy, mw, fyj);
+    fzj = fma(-dz, mw, fzj);
+    const double yt = fma(0.25, d2, bb) * (et * s3);
     yi += yt;
     yj_acc += yt;
-    xj = rot1(xj);
-    yj = rot1(yj);
-    zj = rot1(zj);
-    qj = rot1(qj);
-    bj = rot1(bj);
-    ibj = rot1(ibj);
     fxj = rot1(fxj);
     fyj = rot1(fyj);
     fzj = rot1(fzj);
     yj_acc = rot1(yj_acc);
   }
-  if (vi) {
-    hbm_add(&gb_fx[i], fxi);
-    hbm_add(&gb_fy[i], fyi);
-    hbm_add(&gb_fz[i], fzi);
-    hbm_add(&gb_y[i], yi);
-  }
-  const int jend = 64 * J + ((lane + start + nsteps) & 63);  // whose sums this lane holds after the rotations
-  if (jend < n) {
-    hbm_add(&gb_fx[jend], fxj);
-    hbm_add(&gb_fy[jend], fyj);
-    hbm_add(&gb_fz[jend], fzj);
-    hbm_add(&gb_y[jend], yj_acc);
+  const double kf = -2.0 * kDielFactor;
+  {
+    const double vi4[4] = {kf * fxi, kf * fyi, kf * fzi, yi}, vj4[4] = {kf * fxj, kf * fyj, kf * fzj, yj_acc};
+    tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
   }
   e = wave_sum(e);
-  if (lane == 0) egb_part[blockIdx.x] = e;
+  if (lane == 0) s_e[wave] = e;
+  __syncthreads();
+  // thread (wave q, lane l) adds quantity q of atom l of block I and of block J: rows gb_fx, gb_fy, gb_fz, gb_y
+  double* __restrict__ row = gb_rows + (size_t)wave * n;
+  const int i = 64 * I + lane, j = 64 * J + lane;
+  if (i < n) hbm_add(&row[i], tile_sums_fold(s_sums, wave, lane));
+  if (j < n) hbm_add(&row[j], tile_sums_fold(s_sums, 4 + wave, lane));
+  if (threadIdx.x == 0) egb_part[blockIdx.x] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
-// ---- Born-radius chain rule, symmetric 64x64 tiles with range culling -------------------------------------
+// ---- Born-radius chain rule, 64x64 tiles in "pair order" with range culling ------------------------------
 // Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
 //   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
-// Same machinery as k_gb_tiles: block I in registers, the record and sums of block J travel by DPP rotation,
-// every unordered pair is met once and serves both directions (two table look-ups, one distance).
-// A work item whose two 64-atom bounding boxes are more than the table's 2 nm reach apart exits at once.
-__device__ __forceinline__ int rot1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+// Only heavy atoms descreen, so the atoms are walked in pair order (pslot): all heavy atoms first, then all
+// hydrogens, each group padded to whole blocks of 64.  That leaves two kinds of tiles and no per-lane type tests:
+//   heavy x heavy  symmetric tiles (I <= J), every unordered pair met once, both directions (two look-ups)
+//   heavy x H      full tiles, one direction (the heavy atom descreens the hydrogen, one look-up)
+//   H x H          nothing to do, never scheduled
+// which halves the table look-ups (the LDS pipe is what bounds this kernel).  Machinery as in k_gb_tiles:
+// block I in registers, the static record of block J from a doubled LDS copy, the sums of the j atom travel by
+// DPP rotation.  A work item whose two bounding boxes are more than the table's 2 nm reach apart exits at once.
+struct DbornLane {
+  double x, y, z, bw, s;   // the lane's own atom i
+  int row, tsr;            // screened type * ntj, screener type
+  double fxi, fyi, fzi, wui, fxj, fyj, fzj, wuj;
+};
 
-__global__ __launch_bounds__(256) void k_dborn_tiles(int n, int ntj, int lut_entries, int nitems, const int* __restrict__ items,
-                                                    const double* __restrict__ abox, const double4* __restrict__ aposq,
-                                                    const int2* __restrict__ ameta, const double* __restrict__ born,
-                                                    const double* __restrict__ born_fp, const double* __restrict__ brw,
-                                                    const double* __restrict__ gb_y, const double* __restrict__ scale,
-                                                    const double2* __restrict__ lut, double* __restrict__ db_fx,
-                                                    double* __restrict__ db_fy, double* __restrict__ db_fz,
-                                                    double* __restrict__ db_wu) {
+template <bool kBoth>
+__device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restrict__ s_lut, const double2* __restrict__ jxy,
+                                           const double2* __restrict__ jzw, const double2* __restrict__ jsm, int nsteps,
+                                           int masked_step, bool vi, bool lower, int ntj) {
+#pragma unroll 4
+  for (int k = 0; k < nsteps; k++) {
+    const double2 xy = jxy[k], zw = jzw[k], sm = jsm[k];
+    const double dx = xy.x - L.x, dy = xy.y - L.y, dz = zw.x - L.z;
+    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const int tj = __double2loint(sm.y);  // screened type | screener type << 16
+    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(sm.y) >= 0 && (k != masked_step || lower)) {
+      const double rinv = rsqrt_pos(d2);
+      const double d = d2 * rinv;
+      double q2, dq2;  // i descreens j
+      spline_value_deriv(s_lut, ((tj & 0xffff) * ntj + L.tsr) * kI4Nodes, d, q2, dq2);
+      L.wui = fma(zw.y, q2, L.wui);
+      double t = zw.y * L.s * dq2;
+      if (kBoth) {  // j descreens i
+        double q1, dq1;
+        spline_value_deriv(s_lut, (L.row + (tj >> 16)) * kI4Nodes, d, q1, dq1);
+        L.wuj = fma(L.bw, q1, L.wuj);
+        t = fma(L.bw * sm.x, dq1, t);
+      }
+      t *= rinv;
+      L.fxi = fma(dx, t, L.fxi);
+      L.fyi = fma(dy, t, L.fyi);
+      L.fzi = fma(dz, t, L.fzi);
+      L.fxj = fma(-dx, t, L.fxj);
+      L.fyj = fma(-dy, t, L.fyj);
+      L.fzj = fma(-dz, t, L.fzj);
+    }
+    L.fxj = rot1(L.fxj);
+    L.fyj = rot1(L.fyj);
+    L.fzj = rot1(L.fzj);
+    if (kBoth) L.wuj = rot1(L.wuj);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
+                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
+                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
+                                                    const double* __restrict__ born, const double* __restrict__ born_fp,
+                                                    const double* __restrict__ brw, const double* __restrict__ gb_y,
+                                                    const double* __restrict__ scale, const double2* __restrict__ lut,
+                                                    double* __restrict__ db_rows) {
   extern __shared__ double2 s_lut[];
-  // four waves = four work items share one copy of the spline tables
-  const int lane = threadIdx.x & 63;
-  const int item_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int item = items[item_id < nitems ? item_id : nitems - 1];
-  const int I = item & 0xfff, J = (item >> 12) & 0xfff, part = (item >> 24) & 3;
+  // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
+  __shared__ double2 s_rec[3][128];
+  __shared__ TileSums s_sums;
+  // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
+  // and the spline tables
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = items[blockIdx.x];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
-  bool in_range = item_id < nitems;
-  if (!diag) {  // wave-uniform range test on the two bounding boxes
+  const bool both = J < nhb;  // heavy x heavy
+  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
     double gap2 = 0.0;
     for (int d = 0; d < 3; d++) {
-      const double g = fmax(0.0, fmax(abox[6 * J + d] - abox[6 * I + 3 + d], abox[6 * I + d] - abox[6 * J + 3 + d]));
+      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
       gap2 += g * g;
     }
-    in_range = in_range && gap2 < kI4MaxA * kI4MaxA;
+    if (gap2 >= kI4MaxA * kI4MaxA) return;
   }
-  if (__syncthreads_or(in_range ? 1 : 0) == 0) return;  // the whole workgroup is out of range
   for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
-  __syncthreads();
-  if (!in_range) return;
-  const int nsteps = diag ? (kGbSteps < 32 ? kGbSteps : 32) : kGbSteps;
-  const int start = (diag ? 1 : 0) + nsteps * part;
-  const int i = 64 * I + lane;
-  const bool vi = i < n;
   // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
   // formed here from the finished GB sums instead of a per-atom kernel in between
   auto weights = [&](int a, double q) {
     const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
     return make_double2(brw[a] + bru, scale[a]);
   };
-  const double4 pi = aposq[vi ? i : n - 1];
-  const double2 wi = vi ? weights(i, pi.w) : make_double2(0.0, 0.0);  // zero weights switch a padded lane off
-  const int2 mi = ameta[vi ? i : n - 1];                    // {screened type, screener type or -1}
-  const int tsr_i = vi ? mi.y : -1;
-  const int j = 64 * J + ((lane + start) & 63);
-  const bool vj = j < n;
-  const double4 pj0 = aposq[vj ? j : n - 1];
-  const double2 wj0 = vj ? weights(j, pj0.w) : make_double2(0.0, 0.0);
-  const int2 mj0 = ameta[vj ? j : n - 1];
-  double xj = pj0.x, yj = pj0.y, zj = pj0.z, bwj = wj0.x, sj = wj0.y;
-  int tj = mj0.x | (((vj ? mj0.y : -1) + 1) << 16);  // screened type | (screener type + 1) << 16
-  int jid = vj ? j : -1;
-  double fxi = 0, fyi = 0, fzi = 0, wui = 0, fxj = 0, fyj = 0, fzj = 0, wuj = 0;
-#pragma unroll 2
-  for (int k = 0; k < nsteps; k++) {
-    const double dx = xj - pi.x, dy = yj - pi.y, dz = zj - pi.z;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    const bool once = !(diag && start + k == 32 && lane >= 32);  // diagonal tile, distance 32: one end only
-    if (d2 < kI4MaxA * kI4MaxA && vi && jid >= 0 && once) {
-      const double rinv = rsqrt(d2);
-      const double d = d2 * rinv;
-      const int tsd_j = tj & 0xffff, tsr_j = (tj >> 16) - 1;
-      double t = 0.0;
-      if (tsr_j >= 0) {  // j descreens i
-        double q1, dq1;
-        spline_value_deriv(s_lut, (mi.x * ntj + tsr_j) * kI4Nodes, d, q1, dq1);
-        wuj += wi.x * q1;
-        t += wi.x * sj * dq1;
-      }
-      if (tsr_i >= 0) {  // i descreens j
-        double q2, dq2;
-        spline_value_deriv(s_lut, (tsd_j * ntj + tsr_i) * kI4Nodes, d, q2, dq2);
-        wui += bwj * q2;
-        t += bwj * wi.y * dq2;
-      }
-      t *= rinv;
-      const double gx = dx * t, gy = dy * t, gz = dz * t;
-      fxi += gx;
-      fyi += gy;
-      fzi += gz;
-      fxj -= gx;
-      fyj -= gy;
-      fzj -= gz;
-    }
-    xj = rot1(xj);
-    yj = rot1(yj);
-    zj = rot1(zj);
-    bwj = rot1(bwj);
-    sj = rot1(sj);
-    tj = rot1i(tj);
-    jid = rot1i(jid);
-    fxj = rot1(fxj);
-    fyj = rot1(fyj);
-    fzj = rot1(fzj);
-    wuj = rot1(wuj);
+  if (wave == 0) {
+    const int aj = pslot[64 * J + lane];
+    const bool vj = aj >= 0;
+    const double4 pj = aposq[vj ? aj : 0];
+    const double2 wj = vj ? weights(aj, pj.w) : make_double2(0.0, 0.0);
+    const int2 mj = ameta[vj ? aj : 0];
+    // low word: screened type | screener type << 16 (only read in heavy x heavy tiles); high word: >= 0 for a real atom
+    const double packed = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
+    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(pj.x, pj.y);
+    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(pj.z, wj.x);
+    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, packed);
   }
-  if (vi) {
-    hbm_add(&db_fx[i], fxi);
-    hbm_add(&db_fy[i], fyi);
-    hbm_add(&db_fz[i], fzi);
-    hbm_add(&db_wu[i], wui);
+  const int nsteps = diag ? 8 : 16;
+  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
+  const int ai = pslot[64 * I + lane];
+  const bool vi = ai >= 0;
+  const double4 pi = aposq[vi ? ai : 0];
+  const double2 wi = vi ? weights(ai, pi.w) : make_double2(0.0, 0.0);
+  const int2 mi = ameta[vi ? ai : 0];  // {screened type, screener type}: block I is always a heavy block
+  DbornLane L;
+  L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
+  L.row = mi.x * ntj, L.tsr = mi.y;
+  L.fxi = L.fyi = L.fzi = L.wui = L.fxj = L.fyj = L.fzj = L.wuj = 0.0;
+  const int base = (lane + start) & 63;
+  const double2* __restrict__ jxy = s_rec[0] + base;
+  const double2* __restrict__ jzw = s_rec[1] + base;
+  const double2* __restrict__ jsm = s_rec[2] + base;
+  __syncthreads();
+  // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
+  if (both)
+    dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj);
+  else
+    dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj);
+  {
+    const double vi4[4] = {L.fxi, L.fyi, L.fzi, L.wui}, vj4[4] = {L.fxj, L.fyj, L.fzj, L.wuj};
+    tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
   }
-  if (jid >= 0) {  // after the rotations the lane holds the sums of atom jid
-    hbm_add(&db_fx[jid], fxj);
-    hbm_add(&db_fy[jid], fyj);
-    hbm_add(&db_fz[jid], fzj);
-    hbm_add(&db_wu[jid], wuj);
-  }
+  __syncthreads();
+  // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz, db_wu
+  double* __restrict__ row = db_rows + (size_t)wave * n;
+  if (vi) hbm_add(&row[ai], tile_sums_fold(s_sums, wave, lane));
+  const int aj = pslot[64 * J + lane];
+  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[aj], tile_sums_fold(s_sums, 4 + wave, lane));
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -584,7 +672,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_MARK(kKPrep);
-  const int n = P.n > kStatWords ? P.n : kStatWords;
+  const int n = std::max(std::max(P.n, P.nslots), (int)kStatWords);
   hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, P);
   return hipGetLastError();
 }
@@ -592,7 +680,7 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
 hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   const int nblk = (P.n + 63) / 64;
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
-  if (lds > 48 * 1024) {
+  if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -606,15 +694,14 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
                      (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
-  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(64), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.gb_fy,
-                     P.gb_fz, P.gb_y, P.egb_part);
+  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
-  hipLaunchKernelGGL(k_dborn_tiles, dim3((P.gb_items_count + 3) / 4), dim3(256), lds, st, P.n, P.ntj, P.lut_entries,
-                     P.gb_items_count, P.gb_items, (const double*)P.abox, (const double4*)P.aposq, P.ameta,
+  if (P.db_items_count > 0)
+    hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
-                     (const double*)P.scale, P.lut, P.db_fx, P.db_fy, P.db_fz, P.db_wu);
+                     (const double*)P.scale, P.lut, P.db_fx);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }
