@@ -5,7 +5,7 @@
 // execute() :139-149 -> agbnp_hip_execute_{host,device}, copyParametersToContext() :1796-1815 ->
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
-//   k_prep -> k_tree_cavity -> [k_scale -> k_born_pairs -> k_gb_tiles -> k_dborn_tiles -> k_tree_pseudo] -> k_outputs
+//   k_prep -> k_tree_cavity -> [k_born_tiles -> k_gb_tiles -> k_dborn_tiles -> k_tree_pseudo] -> k_outputs
 //                          \-> k_tree_large (second stream, joined in front of k_outputs)
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
@@ -87,14 +87,13 @@ struct agbnp_hip_context {
   // static device data
   DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items, d_db_items, d_pslot;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
-  DevBuf<int2> d_ameta, d_hmeta;
+  DevBuf<int2> d_ameta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
   DevBuf<double> d_pbox, d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
-  DevBuf<double4> d_aposq, d_hposs;
+  DevBuf<double4> d_aposq;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
-  DevBuf<double> d_scale;
   DevBuf<SubtreeHeader> d_hdr;
   DevBuf<ushort4> d_node_pool;
   DevBuf<int> d_atom_pool;
@@ -213,7 +212,6 @@ void wire_args(agbnp_hip_context* c) {
   P.inv_vol_h = c->d_inv_vol_h.p;
   P.gam_cav = c->d_gam_cav.p;
   P.ameta = c->d_ameta.p;
-  P.hmeta = c->d_hmeta.p;
   P.lut = c->d_lut.p;
   P.nti = c->lut.nscreened;
   P.ntj = c->lut.nscreener;
@@ -228,7 +226,6 @@ void wire_args(agbnp_hip_context* c) {
   P.nhb = (c->nh + 63) / 64;
   P.db_items = c->d_db_items.p;
   P.db_items_count = (int)c->d_db_items.count;
-  P.hposs = c->d_hposs.p;
   P.gx = c->d_gx.p;
   P.gy = c->d_gy.p;
   P.gz = c->d_gz.p;
@@ -242,7 +239,6 @@ void wire_args(agbnp_hip_context* c) {
   P.born_fp = c->d_born_fp.p;
   P.brw = c->d_brw.p;
   P.e_atom = c->d_e_atom.p;
-  P.scale = c->d_scale.p;
   const size_t row = (size_t)c->n;
   P.gb_fx = c->d_gbf.p;
   P.gb_fy = c->d_gbf.p + c->n;
@@ -290,16 +286,7 @@ void wire_args(agbnp_hip_context* c) {
 int allocate_work(agbnp_hip_context* c) {
   const int n = c->n, nh = c->nh;
   const size_t nhp = std::max(nh, 1);
-  // j-range splits: aim at ~2048 wavefronts per pair launch (256 CUs x 8)
   const int nblk = (n + 63) / 64;
-  // pair launches: workgroups of 4 waves (same 64 i-atoms, j range quartered), `want` workgroups per i-block
-  int target_waves = 4096;
-  if (const char* env = getenv("AGBNP_HIP_PAIR_WAVES")) target_waves = std::max(64, atoi(env));  // tuning knob
-  const int want = std::min(128, std::max(1, (target_waves / 4 + nblk - 1) / nblk));
-  c->P.achunk = std::max(16, (n + want - 1) / want);
-  c->P.asplits = (n + c->P.achunk - 1) / c->P.achunk;
-  c->P.hchunk = std::max(16, ((int)nhp + want - 1) / want);
-  c->P.hsplits = std::max(1, (nh + c->P.hchunk - 1) / c->P.hchunk);
   {
     // work items of the symmetric GB tile kernel: one workgroup per tile, off-diagonal tiles first
     if (nblk > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 particles are not supported by the tile index encoding");
@@ -348,7 +335,6 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
   HIP_TRY(c, c->d_aposq.alloc(n));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
-  HIP_TRY(c, c->d_hposs.alloc(nhp));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
   HIP_TRY(c, c->d_born_part.alloc((size_t)n));
@@ -356,8 +342,6 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_born_fp.alloc(n));
   HIP_TRY(c, c->d_brw.alloc(n));
   HIP_TRY(c, c->d_e_atom.alloc(n));
-  HIP_TRY(c, c->d_scale.alloc(n));
-  HIP_TRY(c, hipMemset(c->d_scale.p, 0, sizeof(double) * n));
   HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
@@ -515,11 +499,9 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   std::vector<int> h2a_pad = c->h2a;
   if (h2a_pad.empty()) h2a_pad.push_back(0);
   CREATE_TRY(c->d_h2a.upload(h2a_pad));
-  std::vector<int2> ameta(n), hmeta(std::max(c->nh, 1));
+  std::vector<int2> ameta(n);
   for (int i = 0; i < n; i++) ameta[i] = make_int2(c->lut.type_screened[i], c->lut.type_screener[i]);
-  for (int h = 0; h < c->nh; h++) hmeta[h] = make_int2(c->h2a[h], c->lut.type_screener[c->h2a[h]]);
   CREATE_TRY(c->d_ameta.upload(ameta));
-  CREATE_TRY(c->d_hmeta.upload(hmeta));
   const double dr = kI4MaxA / (kI4Nodes - 1);
   std::vector<double2> lut(std::max<size_t>(1, c->lut.y.size()));
   for (size_t k = 0; k < c->lut.y.size(); k++) lut[k] = make_double2(c->lut.y[k], c->lut.y2[k] * dr * dr / 6.0);
@@ -688,8 +670,8 @@ int agbnp_hip_set_profiling(agbnp_hip_context* c, int enabled) {
 int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
-  static const char* names[kKernelCount] = {"k_prep",       "k_tree_cavity", "k_tree_large",  "k_scale",  "k_born_pairs",
-                                            "k_gb_tiles",   "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
+  static const char* names[kKernelCount] = {"k_prep",     "k_tree_cavity", "k_tree_large",  "k_born_tiles",
+                                            "k_gb_tiles", "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 

@@ -21,7 +21,6 @@ struct PairArgs {
   const double* inv_vol_h;  // [nh] 1/(4 pi R^3/3), vdW radius
   const double* gam_cav;   // [nh] gamma/roffset
   const int2* ameta;       // [n] {screened type, screener type or -1}
-  const int2* hmeta;       // [nh] {atom index, screener type}
   const double2* lut;      // [nti*ntj*16] {y, y2*dr^2/6}
   int nti, ntj, lut_entries;
   // ---- geometry (SoA for the tree, packed records for the pair loops)
@@ -30,7 +29,6 @@ struct PairArgs {
   const int* pslot;        // [nslots] pair order: heavy atoms, padding (-1) to a block of 64, hydrogens, padding
   int nslots, nhb;         // slots (multiple of 64), heavy blocks
   double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
-  double4* hposs;          // [nh] {x,y,z,s_j}
   // ---- tree accumulators / outputs
   double *gx, *gy, *gz;    // [nh]
   double *sv_vdw, *sv_large;  // [nh]
@@ -40,18 +38,15 @@ struct PairArgs {
   int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
   int* status;
   // ---- pair-stage intermediates
-  double* born_part;       // [n] sum_j s_j Q (atomic sums of the j-range workgroups)
+  double* born_part;       // [n] sum_j s_j Q (atomic sums of the tiles)
   double *born, *born_fp, *brw, *e_atom;  // [n]
-  double* scale;           // [n] volume scaling factor s_i (0 for hydrogens)
   double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
   const int* gb_items;     // [gb_items_count] tiles of k_gb_tiles: I | J<<12 (64-atom blocks, atom order, I <= J)
   int gb_items_count;
-  const int* db_items;     // [db_items_count] tiles of k_dborn_tiles, same encoding over blocks of pair-order slots
+  const int* db_items;     // [db_items_count] tiles of k_born_tiles / k_dborn_tiles, same encoding over blocks of pair-order slots
   int db_items_count;
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force and W+U (atomic sums)
   double* egb_part;        // [egb_parts]
-  int hsplits, hchunk;     // split of the heavy-atom j range (Born)
-  int asplits, achunk;     // split of the all-atom j range (GB, dBorn)
   int egb_parts;
 };
 

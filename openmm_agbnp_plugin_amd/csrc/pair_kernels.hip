@@ -12,12 +12,13 @@
 //   :513-542  van der Waals energy, brw_i, bru_i
 //   :555-586  chain-rule forces through the Born radii and the U_j / W_j sums
 //
-// Machine mapping: "row form".  A wavefront owns 64 consecutive i-atoms (one per lane, everything in
-// registers) and walks a contiguous range of j-atoms whose records are wave-uniform, so they arrive
-// through the scalar cache (s_load) and cost no vector memory traffic or LDS; the j range is split
-// over blockIdx.y to fill the chip, each split writes its own partial row and the next per-atom kernel
-// adds the partial rows in a fixed order (no atomics -> bit-reproducible).  Every pair is evaluated
-// from both ends instead of scattering the reaction force; the I4 spline tables sit in LDS.
+// Machine mapping: every pair stage walks 64x64 atom tiles, one workgroup of four waves per tile.  Lane l of a
+// wave keeps atom i of block I and its sums in registers and meets the atoms of block J in cyclic order: their
+// static records come from a doubled copy of the block in LDS, their running sums travel round the wave by DPP
+// rotation, so every pair is evaluated once for both ends.  The sums of the four waves meet in LDS and leave
+// as one set of FP64 HBM atomics per tile (float atomics execute at the memory side at a fixed chip-wide byte
+// rate, so their bytes are kept small); the I4 spline tables sit in LDS.  The range-limited stages (Born sums,
+// chain rule) walk the atoms heavy-first, skip H x H tiles and cull tiles by bounding boxes.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,9 +27,6 @@
 #include "pair_kernels.h"
 
 namespace agbnp {
-
-constexpr int kPairWaves = 4;               // waves per pair-kernel workgroup; all work on the same 64 i-atoms
-constexpr int kPairBlock = 64 * kPairWaves;
 
 // ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, y2_k*dr^2/6}) ------------------
 __device__ __forceinline__ double spline_value(const double2* __restrict__ tab, int base, double d) {
@@ -113,75 +111,6 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
     P.sv_vdw[h] = 0.0;
     P.sv_large[h] = 0.0;
     P.gam[h] = P.gam_cav[h];
-  }
-}
-
-// ---- volume scaling factors (ReferenceAGBNPKernels.cpp:420-433) packed with the heavy positions ---------
-__global__ __launch_bounds__(256) void k_scale(PairArgs P) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= P.nh) return;
-  const double sj = P.sv_vdw[h] * P.inv_vol_h[h];
-  P.hposs[h] = make_double4(P.hx[h], P.hy[h], P.hz[h], sj);
-  P.scale[P.h2a[h]] = sj;  // hydrogens keep the 0 they were created with
-}
-
-// ---- inverse Born radii: partial sums over a j range ---------------------------------------------------
-__global__ __launch_bounds__(kPairBlock) void k_born_pairs(int n, int nh, int hchunk, int ntj, int lut_entries,
-                                                   const double4* __restrict__ aposq, const int2* __restrict__ ameta,
-                                                   const double4* __restrict__ hposs, const int2* __restrict__ hmeta,
-                                                   const double2* __restrict__ lut, double* __restrict__ born_part) {
-  extern __shared__ double2 s_lut[];
-  __shared__ double s_red[kPairWaves][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < lut_entries; t += kPairBlock) s_lut[t] = lut[t];
-  __syncthreads();
-  const int i = blockIdx.x * 64 + lane;
-  const bool valid = i < n;
-  const int ii = valid ? i : n - 1;
-  const double4 pi = aposq[ii];
-  const int tbase = ameta[ii].x * ntj;
-  // the block's j range is split once more over its waves (same 64 i-atoms in every wave)
-  const int sub = (hchunk + kPairWaves - 1) / kPairWaves;
-  const int jb = blockIdx.y * hchunk;
-  const int j0 = min(nh, jb + wave * sub);
-  const int j1 = min(min(nh, jb + hchunk), j0 + sub);
-  double sum = 0.0;
-  auto pair = [&](const double4& pj, const int2& mj) {
-    const double dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 < kI4MaxA * kI4MaxA && mj.x != i) {
-      const double d = sqrt(d2);
-      sum += pj.w * spline_value(s_lut, (tbase + mj.y) * kI4Nodes, d);
-    }
-  };
-  if (j0 < j1) {
-    // Scalar-load pipeline.  SMEM returns out of order, so only lgkmcnt(0) is a safe wait: retire the record of
-    // j (in flight since the previous half-iteration) BEFORE issuing the loads of j+1, then compute j while j+1
-    // is in flight.  The empty asm consumes the registers (forces the wait there), sched_barrier pins the order.
-    double4 pA = hposs[j0];
-    int2 mA = hmeta[j0];
-    int j = j0;
-    for (; j + 1 < j1; j += 2) {
-      asm volatile("; j landed" ::"s"(pA.x), "s"(mA.x));
-      const double4 pB = hposs[j + 1];
-      const int2 mB = hmeta[j + 1];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pA, mA);
-      asm volatile("; j+1 landed" ::"s"(pB.x), "s"(mB.x));
-      const int jn = j + 2 < j1 ? j + 2 : j + 1;
-      pA = hposs[jn];
-      mA = hmeta[jn];
-      __builtin_amdgcn_sched_barrier(0);
-      pair(pB, mB);
-    }
-    if (j < j1) pair(pA, mA);
-  }
-  s_red[wave][lane] = sum;
-  __syncthreads();
-  if (wave == 0 && valid) {
-    double t = s_red[0][lane];
-    for (int w = 1; w < kPairWaves; w++) t += s_red[w][lane];
-    hbm_add(&born_part[i], t);  // single row: the per-atom kernel that follows reads one value
   }
 }
 
@@ -373,6 +302,99 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   if (threadIdx.x == 0) egb_part[blockIdx.x] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
+// ---- descreening sums of the inverse Born radii, 64x64 tiles in "pair order" with range culling -------------
+// Reference loop (ReferenceAGBNPKernels.cpp:435-449): sum_i over all atoms, heavy j != i, d < 2 nm:
+//   born_part_i += s_j Q(d; type_i, type_j)       s_j = selfvol_j / (4 pi R_j^3 / 3)   (:420-433)
+// Only heavy atoms descreen, so the atoms are walked in pair order (pslot): all heavy atoms first, then all
+// hydrogens, each group padded to whole blocks of 64 (slot h of a heavy block IS heavy atom h).  Two kinds of tiles:
+//   heavy x heavy  symmetric tiles (I <= J), every unordered pair met once, both directions (two look-ups)
+//   heavy x H      full tiles, one direction (the heavy atom descreens the hydrogen, one look-up)
+// One workgroup = one tile, four waves of a quarter of the cyclic distances each; block I in registers, the
+// static record of block J from a doubled LDS copy, the running sum of the j atom travels by DPP rotation.  A
+// tile whose two bounding boxes are more than the table's 2 nm reach apart exits at once.
+template <bool kBoth>
+__device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const double2* __restrict__ s_lut,
+                                          const double2* __restrict__ jxy, const double2* __restrict__ jzs,
+                                          const double* __restrict__ jty, double xi, double yi, double zi, double si, int row,
+                                          int tsr, int nsteps, int masked_step, bool vi, bool lower, int ntj) {
+#pragma unroll 4
+  for (int k = 0; k < nsteps; k++) {
+    const double2 xy = jxy[k], zs = jzs[k];
+    const double ty = jty[k];
+    const double dx = xy.x - xi, dy = xy.y - yi, dz = zs.x - zi;
+    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const int tj = __double2loint(ty);  // screened type | screener type << 16
+    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(ty) >= 0 && (k != masked_step || lower)) {
+      const double d = d2 * rsqrt_pos(d2);
+      sum_j = fma(si, spline_value(s_lut, ((tj & 0xffff) * ntj + tsr) * kI4Nodes, d), sum_j);   // i descreens j
+      if (kBoth) sum_i = fma(zs.y, spline_value(s_lut, (row + (tj >> 16)) * kI4Nodes, d), sum_i);  // j descreens i
+    }
+    sum_j = rot1(sum_j);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
+                                                   const int* __restrict__ pslot, const double* __restrict__ pbox,
+                                                   const double* __restrict__ pos, const int2* __restrict__ ameta,
+                                                   const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
+                                                   const double2* __restrict__ lut, double* __restrict__ born_part) {
+  extern __shared__ double2 s_lut[];
+  __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
+  __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
+  __shared__ double s_red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = items[blockIdx.x];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff;
+  const bool diag = I == J;
+  const bool both = J < nhb;  // heavy x heavy
+  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    if (gap2 >= kI4MaxA * kI4MaxA) return;
+  }
+  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
+  auto scale_of = [&](int slot, bool valid) { return valid && slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0; };
+  if (wave == 0) {
+    const int slot = 64 * J + lane;
+    const int aj = pslot[slot];
+    const bool vj = aj >= 0;
+    const int ac = vj ? aj : 0;
+    const int2 mj = ameta[ac];
+    s_xy[lane] = s_xy[lane + 64] = make_double2(pos[3 * ac], pos[3 * ac + 1]);
+    s_zs[lane] = s_zs[lane + 64] = make_double2(pos[3 * ac + 2], scale_of(slot, vj));
+    s_ty[lane] = s_ty[lane + 64] = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
+  }
+  const int nsteps = diag ? 8 : 16;
+  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
+  const int islot = 64 * I + lane;
+  const int ai = pslot[islot];
+  const bool vi = ai >= 0;
+  const int aic = vi ? ai : 0;
+  const double xi = pos[3 * aic], yi = pos[3 * aic + 1], zi = pos[3 * aic + 2];
+  const double si = scale_of(islot, vi);
+  const int2 mi = ameta[aic];  // {screened type, screener type}: block I is always a heavy block
+  const int base = (lane + start) & 63;
+  double sum_i = 0.0, sum_j = 0.0;
+  __syncthreads();
+  // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
+  if (both)
+    born_walk<true>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, mi.x * ntj, mi.y, nsteps,
+                    diag ? 32 - start : -1, vi, lane < 32, ntj);
+  else
+    born_walk<false>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, 0, mi.y, nsteps, -1, vi, true, ntj);
+  s_red[wave][0][lane] = sum_i;
+  s_red[wave][1][(lane + start + nsteps) & 63] = sum_j;  // whose sum the lane holds after the rotations
+  __syncthreads();
+  if (wave < 2) {  // wave 0 adds the sums of block I, wave 1 those of block J
+    if (wave == 0 && !both) return;
+    const int a = wave == 0 ? ai : pslot[64 * J + lane];
+    if (a >= 0) hbm_add(&born_part[a], (s_red[0][wave][lane] + s_red[1][wave][lane]) + (s_red[2][wave][lane] + s_red[3][wave][lane]));
+  }
+}
+
 // ---- Born-radius chain rule, 64x64 tiles in "pair order" with range culling ------------------------------
 // Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
 //   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
@@ -433,8 +455,8 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
                                                     const double4* __restrict__ aposq, const int2* __restrict__ ameta,
                                                     const double* __restrict__ born, const double* __restrict__ born_fp,
                                                     const double* __restrict__ brw, const double* __restrict__ gb_y,
-                                                    const double* __restrict__ scale, const double2* __restrict__ lut,
-                                                    double* __restrict__ db_rows) {
+                                                    const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
+                                                    int nh, const double2* __restrict__ lut, double* __restrict__ db_rows) {
   extern __shared__ double2 s_lut[];
   // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
   __shared__ double2 s_rec[3][128];
@@ -457,15 +479,16 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
   // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
   // formed here from the finished GB sums instead of a per-atom kernel in between
-  auto weights = [&](int a, double q) {
+  // (slot h of a heavy block is heavy atom h: its volume scaling factor comes straight from the tree's self volume)
+  auto weights = [&](int a, int slot, double q) {
     const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
-    return make_double2(brw[a] + bru, scale[a]);
+    return make_double2(brw[a] + bru, slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0);
   };
   if (wave == 0) {
     const int aj = pslot[64 * J + lane];
     const bool vj = aj >= 0;
     const double4 pj = aposq[vj ? aj : 0];
-    const double2 wj = vj ? weights(aj, pj.w) : make_double2(0.0, 0.0);
+    const double2 wj = vj ? weights(aj, 64 * J + lane, pj.w) : make_double2(0.0, 0.0);
     const int2 mj = ameta[vj ? aj : 0];
     // low word: screened type | screener type << 16 (only read in heavy x heavy tiles); high word: >= 0 for a real atom
     const double packed = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   const int ai = pslot[64 * I + lane];
   const bool vi = ai >= 0;
   const double4 pi = aposq[vi ? ai : 0];
-  const double2 wi = vi ? weights(ai, pi.w) : make_double2(0.0, 0.0);
+  const double2 wi = vi ? weights(ai, 64 * I + lane, pi.w) : make_double2(0.0, 0.0);
   const int2 mi = ameta[vi ? ai : 0];  // {screened type, screener type}: block I is always a heavy block
   DbornLane L;
   L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
@@ -678,20 +701,17 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
 }
 
 hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
-  const int nblk = (P.n + 63) / 64;
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
   if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_pairs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  AGBNP_MARK(kKScale);
-  hipLaunchKernelGGL(k_scale, dim3((P.nh + 255) / 256 > 0 ? (P.nh + 255) / 256 : 1), dim3(256), 0, st, P);
-  AGBNP_CHECK_LAUNCH();
-  AGBNP_MARK(kKBornPairs);
-  hipLaunchKernelGGL(k_born_pairs, dim3(nblk, P.hsplits), dim3(kPairBlock), lds, st, P.n, P.nh, P.hchunk, P.ntj, P.lut_entries,
-                     (const double4*)P.aposq, P.ameta, (const double4*)P.hposs, P.hmeta, P.lut, P.born_part);
+  AGBNP_MARK(kKBornTiles);
+  if (P.db_items_count > 0)
+    hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
+                       (const double*)P.pbox, P.pos, P.ameta, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
   hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
@@ -701,7 +721,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
-                     (const double*)P.scale, P.lut, P.db_fx);
+                     (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }
