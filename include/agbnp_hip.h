@@ -76,7 +76,8 @@ int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
  * scalars: 0 E_vol1  1 E_vol2  2 E_atom (vdW + GB self)  3 E_GB pair  4 max subtree nodes
  *          5 total tree nodes  6 kernel variant  7 max local atoms
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
- *          3 self volume (enlarged radii) */
+ *          3 self volume (enlarged radii)
+ *          4 / 5 nodes / local atoms of the overlap subtree rooted at the atom (tree shape, capacity planning) */
 int agbnp_hip_set_diagnostics(agbnp_hip_context* ctx, int enabled); /* vector 3 is only collected when enabled */
 int agbnp_hip_get_scalar(agbnp_hip_context* ctx, int which, double* value);
 int agbnp_hip_get_vector(agbnp_hip_context* ctx, int which, double* out);

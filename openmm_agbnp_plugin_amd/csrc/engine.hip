@@ -629,6 +629,14 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
     case 3:
       if (!c->diagnostics) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "enlarged-radius self volumes need agbnp_hip_set_diagnostics(ctx, 1) before the evaluation");
       return heavy_to_atoms(c->d_sv_large.p, 0.0);
+    case 4:
+    case 5: {  // overlap-tree shape: nodes / local atoms of the subtree rooted at every heavy atom (0 for hydrogens)
+      std::vector<int2> sz(std::max(nh, 1));
+      HIP_TRY(c, hipMemcpy(sz.data(), c->d_sizes.p, sizeof(int2) * std::max(nh, 1), hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; i++) out[i] = 0.0;
+      for (int h = 0; h < nh; h++) out[c->h2a[h]] = which == 4 ? sz[h].x : sz[h].y;
+      return AGBNP_HIP_OK;
+    }
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown vector id");
   }
 }

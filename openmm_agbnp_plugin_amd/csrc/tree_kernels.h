@@ -391,12 +391,17 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   for (int c = tid; c < ncand; c += BS) {
     const double my = S.cand_vol[c];
     const int hj = S.cand_idx[c];
+    // four independent LDS reads per trip: the loop is bound by LDS latency, not by the compares
     int rank = 0;
-    for (int k = 0; k < ncand; k++) {
-      const double vk = S.cand_vol[k];
-      rank += vk > my ? 1 : 0;
-      if (vk == my && S.cand_idx[k] < hj) rank++;  // exact tie (incl. k == c: never counted): order by atom index
+    int k = 0;
+    auto before = [&](double vk, int kk) {  // exact tie (incl. kk == c: never counted): order by atom index
+      return (vk > my || (vk == my && S.cand_idx[kk] < hj)) ? 1 : 0;
+    };
+    for (; k + 4 <= ncand; k += 4) {
+      const double v0 = S.cand_vol[k], v1 = S.cand_vol[k + 1], v2 = S.cand_vol[k + 2], v3 = S.cand_vol[k + 3];
+      rank += (before(v0, k) + before(v1, k + 1)) + (before(v2, k + 2) + before(v3, k + 3));
     }
+    for (; k < ncand; k++) rank += before(S.cand_vol[k], k);
     const int slot = 1 + rank;  // level-2 node k <-> local atom k
     const int st = NCAP - 1 - c;
     const double x2 = S.nd[0][st], y2 = S.nd[1][st], z2 = S.nd[2][st], a2 = S.nd[3][st], v2 = S.nd[4][st], g2 = S.nd[5][st];

@@ -254,6 +254,10 @@ static hipError_t launch_tree(K kernel, int grid, size_t lds, const TreeArgs& A,
 
 hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
+#ifdef AGBNP_STAMPS  // diagnostic build only: time the largest subtrees alone (results are incomplete)
+  if (const char* env = getenv("AGBNP_DIAG_TREE_GRID"))
+    return launch_tree(k_tree_cavity<512, 64, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<512, 64>::kBytes, A, st);
+#endif
   switch (variant) {
     case 0: return launch_tree(k_tree_cavity<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kBytes, A, st);
     case 1: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kBytes, A, st);
