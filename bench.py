@@ -33,15 +33,14 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 def algorithmic_bytes(n_atoms, slots):
     """SURVEY.md s.8d:  B_alg = S*128*8 + T*4096*4 + N*104  per AGBNP1 evaluation, and its split over the
-    kernels: tree sweeps 5 (cavity kernel: build W, rescan R+W, vol-2 R, accumulators) + 1
-    (enlarged-radius replay: vol-1 R) + 2 (pseudo-volume replay); one 64x64 pair-tile pass each for the 2-body
+    kernels: tree sweeps 6 (cavity kernel: build W, vol-1 R, rescan R+W, vol-2 R, accumulators) + 2
+    (pseudo-volume replay); one 64x64 pair-tile pass each for the 2-body
     search (cavity kernel), Born, GB and dBorn; per-atom I/O in prep/outputs."""
     nb = (n_atoms + 63) // 64
     tiles = nb * (nb + 1) // 2
     node, tile, atom = slots * 128, tiles * 4096, n_atoms * 104
     per_kernel = {
-        "k_tree_cavity": 5 * node + tile,
-        "k_tree_large": node,
+        "k_tree_cavity": 6 * node + tile,
         "k_tree_pseudo": 2 * node,
         "k_born_tiles": tile,
         "k_gb_tiles": tile,

@@ -51,7 +51,7 @@ enum StatusWord {
 
 // kernel ids of one evaluation, in launch order (bench/profiling support)
 enum KernelId {
-  kKPrep = 0, kKTreeCavity, kKTreeLarge, kKBornTiles, kKGbTiles, kKDbornTiles, kKTreePseudo, kKOutputs, kKernelCount
+  kKPrep = 0, kKTreeCavity, kKBornTiles, kKGbTiles, kKDbornTiles, kKTreePseudo, kKOutputs, kKernelCount
 };
 
 }  // namespace agbnp

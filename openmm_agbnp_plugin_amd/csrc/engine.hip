@@ -6,7 +6,6 @@
 // agbnp_hip_update_parameters.  All device work of one evaluation is enqueued on one stream:
 //
 //   k_prep -> k_tree_cavity -> [k_born_tiles -> k_gb_tiles -> k_dborn_tiles -> k_tree_pseudo] -> k_outputs
-//                          \-> k_tree_large (second stream, joined in front of k_outputs)
 //
 // (bracketed part only for version 1).  There is no CPU fallback: without a HIP device every entry
 // point that computes fails with AGBNP_HIP_ERR_DEVICE.
@@ -33,7 +32,6 @@ int tree_variant_node_cap(int variant);
 int tree_variant_atom_cap(int variant);
 hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
 hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
-hipError_t launch_tree_large(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
 
 using namespace agbnp;
@@ -81,8 +79,6 @@ struct agbnp_hip_context {
   int variant = 0;
   hipStream_t stream = nullptr;
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_tree_built = nullptr, ev_large_done = nullptr;
 
   // static device data
   DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items, d_db_items, d_pslot;
@@ -368,25 +364,11 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   HIP_TRY(c, launch_prep(c->P, st, tl));
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
   HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->T, st));
-  // The enlarged-radius cavity pass only feeds the outputs.  With per-kernel timing on (or nothing to hide it
-  // under: version 0, global-scratch variant) it runs in line; otherwise it is forked to the second stream and
-  // joined in front of the outputs, so it overlaps the compute-bound pair kernels.
-  const bool fork_large = !tl && c->version == 1 && c->variant != kGlobalVariant;
-  if (fork_large) {
-    HIP_TRY(c, hipEventRecord(c->ev_tree_built, st));
-    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_tree_built, 0));
-    HIP_TRY(c, launch_tree_large(c->variant, kGlobalGrid, c->T, c->aux_stream));
-    HIP_TRY(c, hipEventRecord(c->ev_large_done, c->aux_stream));
-  } else {
-    if (tl) HIP_TRY(c, tl->mark(kKTreeLarge, st));
-    HIP_TRY(c, launch_tree_large(c->variant, kGlobalGrid, c->T, st));
-  }
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
     HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->T, st));
   }
-  if (fork_large) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_large_done, 0));
   HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
   return AGBNP_HIP_OK;
 }
@@ -491,9 +473,6 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   } while (0)
   CREATE_TRY(hipSetDevice(device));
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-  CREATE_TRY(hipEventCreateWithFlags(&c->ev_tree_built, hipEventDisableTiming));
-  CREATE_TRY(hipEventCreateWithFlags(&c->ev_large_done, hipEventDisableTiming));
 
   CREATE_TRY(c->d_a2h.upload(c->a2h));
   std::vector<int> h2a_pad = c->h2a;
@@ -678,8 +657,8 @@ int agbnp_hip_set_profiling(agbnp_hip_context* c, int enabled) {
 int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
-  static const char* names[kKernelCount] = {"k_prep",     "k_tree_cavity", "k_tree_large",  "k_born_tiles",
-                                            "k_gb_tiles", "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
+  static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_born_tiles", "k_gb_tiles",
+                                            "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 
@@ -723,12 +702,6 @@ void agbnp_hip_destroy(agbnp_hip_context* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
-  if (c->aux_stream) {
-    (void)hipStreamSynchronize(c->aux_stream);
-    (void)hipStreamDestroy(c->aux_stream);
-  }
-  if (c->ev_tree_built) (void)hipEventDestroy(c->ev_tree_built);
-  if (c->ev_large_done) (void)hipEventDestroy(c->ev_large_done);
   for (hipEvent_t e : c->timeline.events) (void)hipEventDestroy(e);
   delete c;
 }

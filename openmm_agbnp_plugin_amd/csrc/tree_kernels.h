@@ -557,7 +557,9 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
 // Adds the gradient (at[6..8]) and, if asked, the self volumes (at[9]) of every non-root local atom;
 // returns sum_n c_n gamma_n V_n in *e_sum and sum_n c_n V_n in *w_sum over the nodes below the root (valid on
 // every lane when WITH_ENERGY).  nd[6] (task volumes during the build) carries the atom paths.
-template <int NCAP, int ACAP, int BS, bool WITH_ENERGY>
+// FRESH_BUILD: the node slots still hold the Gaussians and gamma sums the build left there (same radii), so step
+// (1) only lays down the atom paths.
+template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
 __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
                             double* w_sum) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
@@ -565,7 +567,8 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
   unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
   // (1) top-down: Gaussians, gammas and atom paths (byte k = local atom added at level k+2)
   if (tid == 0) {
-    for (int k = 0; k < 6; k++) S.nd[k][0] = S.at[k][0];
+    if (!FRESH_BUILD)
+      for (int k = 0; k < 6; k++) S.nd[k][0] = S.at[k][0];
     path[0] = 0ull;
   }
   __syncthreads();
@@ -575,6 +578,10 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     for (int n = b + tid; n < e; n += BS) {
       const int p = S.npar[n];
       const int la = S.nla[n];
+      if (FRESH_BUILD) {
+        path[n] = path[p] | ((unsigned long long)la << (8 * (L - 2)));
+        continue;
+      }
       Merged m;
       dev_merge(S.nd[0][p], S.nd[1][p], S.nd[2][p], S.nd[3][p], S.nd[4][p], S.at[0][la], S.at[1][la], S.at[2][la],
                 S.at[3][la], S.at[4][la], m);

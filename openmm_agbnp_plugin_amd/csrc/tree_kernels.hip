@@ -88,9 +88,24 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       }
     }
     STAMP(1);
-    // Pass 1 (enlarged radii) is NOT done here: nothing downstream needs it before the outputs, so it runs as
-    // k_tree_replay<kReplayLarge> on a second stream underneath the pair kernels.  Switch the local atoms to vdW
-    // radii, nu = -gamma/roffset, and go straight to pass 2, whose self volumes the Born stage is waiting for.
+    // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
+    // The node slots still hold the Gaussians of the build, so only the atom paths are laid down before the
+    // gather.  Its gradient stays in the local accumulators and leaves together with that of pass 2.
+    double e_sum, w_sum;
+    {
+      const bool want_sv1 = A.sv_large != nullptr;
+      volume_pass<NCAP, ACAP, BS, true, true>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum);
+      // level-1 node: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
+      if (tid == 0) A.epart[2 * hi] = e_sum + S.at[5][0] * S.at[4][0];
+      if (want_sv1) {  // diagnostics: enlarged-radius self volumes
+        for (int la = tid; la < natoms; la += BS) {
+          glb_add(&A.sv_large[S.at_gidx[la]], la == 0 ? w_sum + S.at[4][0] : S.at[9][la]);
+          S.at[9][la] = 0.0;
+        }
+      }
+    }
+    STAMP(2);
+    // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
       S.at[3][la] = A.a_vdw[hj];
@@ -99,7 +114,6 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     }
     __syncthreads();
     STAMP(3);
-    double e_sum, w_sum;
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
     volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum);
@@ -124,16 +138,11 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   }
 }
 
-// Replay of a stored subtree topology: Gaussians are recomputed top-down and one volume pass runs.
-//   kReplayPseudo : reference steps K+L (ReferenceAGBNPKernels.cpp:718-747), vdW radii, nu_i = (W_i+U_i)/V_i formed
-//                   on the fly from the chain-rule sums, gradient only.  The reference does two passes (W then U);
-//                   the pass is linear in nu, so one pass with the sum gives the same gradient.
-//   kReplayLarge  : reference steps A-B (:293-339), enlarged radii, nu = +gamma/roffset: cavity energy E1 and its
-//                   gradient (and the enlarged-radius self volumes when diagnostics are on).
-enum ReplayMode { kReplayPseudo = 0, kReplayLarge = 1 };
-
-template <int NCAP, int ACAP, int BS, bool GLOBAL, int MODE>
-__global__ __launch_bounds__(BS, BS / 64) void k_tree_replay(TreeArgs A) {
+// Replay of a stored subtree topology with vdW radii: reference steps K+L (ReferenceAGBNPKernels.cpp:718-747),
+// nu_i = (W_i+U_i)/V_i formed on the fly from the chain-rule sums, gradient only.  The reference does two passes
+// (W then U); the pass is linear in nu, so one pass with the sum gives the same gradient.
+template <int NCAP, int ACAP, int BS, bool GLOBAL>
+__global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
@@ -142,15 +151,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_replay(TreeArgs A) {
     const int hi = A.order[slot];
     const SubtreeHeader* H = &A.hdr[hi];
     const int nnodes = H->nnodes, natoms = H->natoms;
-    if (nnodes <= 0) continue;  // not built (capacity overflow: the evaluation is repeated by the host)
-    const bool want_sv1 = MODE == kReplayLarge && A.sv_large != nullptr;
-    if (nnodes == 1) {  // a lone atom: no position-dependent volume, only its own sphere
-      if (MODE == kReplayLarge && tid == 0) {
-        A.epart[2 * hi] = A.gam[hi] * A.v_large[hi];
-        if (want_sv1) glb_add(&A.sv_large[hi], A.v_large[hi]);
-      }
-      continue;
-    }
+    if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
     const size_t pool_off = (size_t)hi * NCAP, atom_off = (size_t)hi * ACAP;
     if (tid < 10) S.lvl[tid] = H->lvl[tid];
     for (int n = tid; n < nnodes; n += BS) {
@@ -166,15 +167,9 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_replay(TreeArgs A) {
       S.at[0][la] = A.hx[hj];
       S.at[1][la] = A.hy[hj];
       S.at[2][la] = A.hz[hj];
-      if (MODE == kReplayPseudo) {
-        S.at[3][la] = A.a_vdw[hj];
-        S.at[4][la] = A.v_vdw[hj];
-        S.at[5][la] = A.db_wu[A.h2a[hj]] * A.inv_vol_h[hj];
-      } else {
-        S.at[3][la] = A.a_large[hj];
-        S.at[4][la] = A.v_large[hj];
-        S.at[5][la] = A.gam[hj];
-      }
+      S.at[3][la] = A.a_vdw[hj];
+      S.at[4][la] = A.v_vdw[hj];
+      S.at[5][la] = A.db_wu[A.h2a[hj]] * A.inv_vol_h[hj];
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
       S.at[8][la] = 0.0;
@@ -182,17 +177,14 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_replay(TreeArgs A) {
     }
     __syncthreads();
     double e_sum = 0.0, w_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, MODE == kReplayLarge>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum);
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum);
     root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
       glb_add(&A.gx[hj], S.at[6][la]);
       glb_add(&A.gy[hj], S.at[7][la]);
       glb_add(&A.gz[hj], S.at[8][la]);
-      if (want_sv1) glb_add(&A.sv_large[hj], la == 0 ? w_sum + S.at[4][0] : S.at[9][la]);
     }
-    // level-1 node: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
-    if (MODE == kReplayLarge && tid == 0) A.epart[2 * hi] = e_sum + S.at[5][0] * S.at[4][0];
     __syncthreads();
   }
 }
@@ -267,24 +259,15 @@ hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, h
   }
 }
 
-template <int MODE>
-static hipError_t launch_tree_replay_mode(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
+hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
   switch (variant) {
-    case 0: return launch_tree(k_tree_replay<512, 64, kBS, false, MODE>, A.nh, TreeStore<512, 64>::kBytes, A, st);
-    case 1: return launch_tree(k_tree_replay<1024, 128, kBS, false, MODE>, A.nh, TreeStore<1024, 128>::kBytes, A, st);
-    case 2: return launch_tree(k_tree_replay<2048, 256, kBS, false, MODE>, A.nh, TreeStore<2048, 256>::kBytes, A, st);
+    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kBytes, A, st);
+    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kBytes, A, st);
+    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, A.nh, TreeStore<2048, 256>::kBytes, A, st);
     default:
-      return launch_tree(k_tree_replay<kGlobalNodeCap, kGlobalAtomCap, kBS, true, MODE>, global_grid < A.nh ? global_grid : A.nh, 0, A,
-                         st);
+      return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
-}
-
-hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
-  return launch_tree_replay_mode<kReplayPseudo>(variant, global_grid, A, st);
-}
-hipError_t launch_tree_large(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
-  return launch_tree_replay_mode<kReplayLarge>(variant, global_grid, A, st);
 }
 
 }  // namespace agbnp

@@ -18,8 +18,6 @@ def per_kernel(path, counter):
         if r["Counter_Name"] == counter and "agbnp::" in r["Kernel_Name"]:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("agbnp::", "")
             base = name.split("<")[0]
-            if base == "k_tree_replay":  # the last template argument is the mode: 0 pseudo-volume pass, 1 enlarged-radius pass
-                base = "k_tree_pseudo" if name.rstrip(">").rstrip().endswith("0") else "k_tree_large"
             d[base].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 
