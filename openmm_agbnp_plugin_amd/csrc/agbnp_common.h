@@ -26,13 +26,13 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kToKjMol = 4.184 * 332.0 / 10.0;
 constexpr double kDielFactor = kToKjMol * (-0.5) * (1. / 1.0 - 1. / 80.0);
 
-// Per-subtree header of the stored overlap-tree topology (written by the build kernel,
-// consumed by the pseudo-volume pass).
+// Header of the stored overlap-tree topology of one work slot (written by the build kernel, consumed by the
+// pseudo-volume pass, which walks the same slots in the same order: one load tells it everything).
 struct SubtreeHeader {
-  int nnodes;      // nodes in the subtree including the level-1 root
+  int nnodes;      // nodes in the subtree including the level-1 root (0: not built)
   int natoms;      // local atoms (root + its level-2 partners)
-  int pool_off;    // offset (in nodes) of the topology records in the node pool
-  int atom_off;    // offset (in ints) of the local->heavy index map in the atom pool
+  int root;        // heavy index of the subtree's root atom
+  int reserved;
   int lvl[10];     // lvl[L] = first node of level L (L = 1..8), lvl[9] = nnodes sentinel; lvl[0] unused
 };
 

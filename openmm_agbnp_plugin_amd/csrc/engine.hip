@@ -91,7 +91,7 @@ struct agbnp_hip_context {
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
   DevBuf<SubtreeHeader> d_hdr;
-  DevBuf<ushort4> d_node_pool;
+  DevBuf<unsigned long long> d_node_pool;
   DevBuf<int> d_atom_pool;
   DevBuf<char> d_scratch;
   // host-API staging

@@ -45,7 +45,7 @@ struct PairArgs {
   int gb_items_count;
   const int* db_items;     // [db_items_count] tiles of k_born_tiles / k_dborn_tiles, same encoding over blocks of pair-order slots
   int db_items_count;
-  double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force and W+U (atomic sums)
+  double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force by atom, W+U by heavy index (atomic sums)
   double* egb_part;        // [egb_parts]
   int egb_parts;
 };

@@ -522,11 +522,12 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
     tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
   }
   __syncthreads();
-  // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz, db_wu
+  // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz by atom,
+  // row db_wu by heavy index (= the slot of a heavy block: only heavy atoms collect W+U, and the tree reads it so)
   double* __restrict__ row = db_rows + (size_t)wave * n;
-  if (vi) hbm_add(&row[ai], tile_sums_fold(s_sums, wave, lane));
+  if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], tile_sums_fold(s_sums, wave, lane));
   const int aj = pslot[64 * J + lane];
-  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[aj], tile_sums_fold(s_sums, 4 + wave, lane));
+  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], tile_sums_fold(s_sums, 4 + wave, lane));
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------

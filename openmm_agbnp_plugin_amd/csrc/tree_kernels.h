@@ -44,7 +44,7 @@ struct TreeArgs {
   const double *a_large, *v_large, *a_vdw, *v_vdw;  // Gaussian exponent / volume per heavy atom
   const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam)
   // pass 3 (pseudo-volume): nu_i = (W_i + U_i) / V_i (ReferenceAGBNPKernels.cpp:718-722,738-742), formed on the fly
-  const double* db_wu;      // [n] W+U per atom
+  const double* db_wu;      // [nh] W+U per heavy atom
   const double* inv_vol_h;  // [nh]
   const int* h2a;           // [nh]
   double rcut2;       // conservative squared cutoff of the 2-body overlap search
@@ -54,9 +54,9 @@ struct TreeArgs {
   double* sv_large;   // [nh] self volumes with enlarged radii (diagnostic; may be null)
   double* sv_vdw;     // [nh] self volumes with vdW radii
   double* epart;      // [2*nh] cavity energies E1,E2 per subtree
-  SubtreeHeader* hdr;  // [nh]
+  SubtreeHeader* hdr;  // [nh] by work slot
   int2* sizes;         // [nh] {nodes, local atoms} of every subtree, compact copy for the bookkeeping block
-  ushort4* node_pool;  // [nh][NCAP] topology records, fixed stride per subtree (variant-dependent)
+  unsigned long long* node_pool;  // [nh][NCAP] atom path of every node (all a replay needs), fixed stride per subtree
   int* atom_pool;      // [nh][ACAP] local atom -> heavy index
   int* status;  // [kStatWords]
   char* scratch;  // GLOBAL variant: per-workgroup slab
@@ -556,51 +556,81 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
 // ---- one volume pass over a built subtree for the radii / gammas currently in the local atom table ------------
 // Adds the gradient (at[6..8]) and, if asked, the self volumes (at[9]) of every non-root local atom;
 // returns sum_n c_n gamma_n V_n in *e_sum and sum_n c_n V_n in *w_sum over the nodes below the root (valid on
-// every lane when WITH_ENERGY).  nd[6] (task volumes during the build) carries the atom paths.
-// FRESH_BUILD: the node slots still hold the Gaussians and gamma sums the build left there (same radii), so step
-// (1) only lays down the atom paths.
+// every lane when WITH_ENERGY).  nd[6] (task volumes during the build) carries the atom paths: byte k of a
+// node's path is the local atom added at level k+2, so a node knows its whole atom list without its parent.
+//
+// Step (1+2) is node-parallel and needs no level ordering:
+//   FRESH_BUILD  the node slots still hold the Gaussians and gamma sums the build left there (same radii); a
+//                node walks its ancestor chain once to lay down its path.
+//   otherwise    a node recomputes its Gaussian directly from its atoms.  The reference's chain of pairwise
+//                merges (gaussvol.cpp:60-93 applied along the path) telescopes:
+//                  A_k = a_1+..+a_k,  c_k = (A_{k-1} c_{k-1} + a_k r_k)/A_k,  df_k = A_{k-1} a_k / A_k
+//                  G   = (prod v_i) * ((prod a_i) / (A_K pi^(K-1)))^(3/2) * exp(-sum_k df_k |c_{k-1} - r_k|^2)
+//                (same atom order as the reference's path; one sqrt and one exp per node instead of one per level),
+//                so the six level barriers of a top-down rescan disappear and a replay needs nothing but the paths.
+__device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
+  const double t[8] = {1.0,
+                       kPi,
+                       kPi * kPi,
+                       kPi * kPi * kPi,
+                       kPi * kPi * kPi * kPi,
+                       kPi * kPi * kPi * kPi * kPi,
+                       kPi * kPi * kPi * kPi * kPi * kPi,
+                       kPi * kPi * kPi * kPi * kPi * kPi * kPi};
+  return t[k];
+}
+
 template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
 __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
                             double* w_sum) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
   unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
-  // (1) top-down: Gaussians, gammas and atom paths (byte k = local atom added at level k+2)
-  if (tid == 0) {
-    if (!FRESH_BUILD)
-      for (int k = 0; k < 6; k++) S.nd[k][0] = S.at[k][0];
-    path[0] = 0ull;
-  }
-  __syncthreads();
-  for (int L = 2; L <= kMaxOrder; L++) {
-    const int b = S.lvl[L], e = S.lvl[L + 1];
-    if (b >= e) break;
-    for (int n = b + tid; n < e; n += BS) {
-      const int p = S.npar[n];
-      const int la = S.nla[n];
-      if (FRESH_BUILD) {
-        path[n] = path[p] | ((unsigned long long)la << (8 * (L - 2)));
-        continue;
-      }
-      Merged m;
-      dev_merge(S.nd[0][p], S.nd[1][p], S.nd[2][p], S.nd[3][p], S.nd[4][p], S.at[0][la], S.at[1][la], S.at[2][la],
-                S.at[3][la], S.at[4][la], m);
-      S.nd[0][n] = m.x;
-      S.nd[1][n] = m.y;
-      S.nd[2][n] = m.z;
-      S.nd[3][n] = m.a;
-      S.nd[4][n] = m.v;
-      S.nd[5][n] = S.nd[5][p] + S.at[5][la];
-      path[n] = path[p] | ((unsigned long long)la << (8 * (L - 2)));
-    }
-    __syncthreads();
-  }
-  // (2) node-parallel: exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n, gamma slot <- w_n = c_n s(G_n) G_n
+  AGBNP_BUILD_STAMP_BEGIN();
+  // (1+2) node-parallel: centre slots <- c_n, exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n,
+  //       gamma slot <- w_n = c_n s(G_n) G_n   (c_n = +-1/level)
   double e_part = 0.0, w_part = 0.0;
   for (int n = 1 + tid; n < nnodes; n += BS) {
-    const int level = 2 + ((63 - __clzll(path[n])) >> 3);
+    int level;
+    double g, gam;
+    if (FRESH_BUILD) {
+      unsigned long long pw = 0ull;
+      level = 1;
+      for (int p = n; p != 0; p = S.npar[p]) {  // leaf to root: the deepest atom is met first
+        pw = (pw << 8) | (unsigned long long)S.nla[p];
+        level++;
+      }
+      path[n] = pw;
+      g = S.nd[4][n];
+      gam = S.nd[5][n];
+    } else {
+      double A = S.at[3][0], cx = S.at[0][0], cy = S.at[1][0], cz = S.at[2][0];
+      double pv = S.at[4][0], pa = A, E = 0.0;
+      gam = S.at[5][0];
+      level = 1;
+      for (unsigned long long pw = path[n]; pw; pw >>= 8) {
+        const int la = (int)(pw & 0xffull);
+        const double xk = S.at[0][la], yk = S.at[1][la], zk = S.at[2][la], ak = S.at[3][la];
+        const double dx = xk - cx, dy = yk - cy, dz = zk - cz;
+        const double inv = fast_rcp(A + ak);
+        const double wk = ak * inv;  // a_k / A_k
+        E = fma(A * wk, fma(dz, dz, fma(dy, dy, dx * dx)), E);
+        cx = fma(dx, wk, cx);  // (A c + a_k r_k) / (A + a_k)
+        cy = fma(dy, wk, cy);
+        cz = fma(dz, wk, cz);
+        A += ak;
+        pa *= ak;
+        pv *= S.at[4][la];
+        gam += S.at[5][la];
+        level++;
+      }
+      const double q = pa * fast_rcp(A * pi_power(level - 1));
+      g = pv * (q * sqrt(q)) * exp(-E);
+      S.nd[0][n] = cx;
+      S.nd[1][n] = cy;
+      S.nd[2][n] = cz;
+    }
     const double cp = ((level & 1) ? 1.0 : -1.0) / (double)level;
-    const double g = S.nd[4][n], gam = S.nd[5][n];
     double sp;
     const double sw = dev_switch(g, sp);
     const double w = cp * sw * g;
@@ -627,6 +657,7 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     *e_sum = es;
     *w_sum = ws;
   }
+  AGBNP_BUILD_STAMP(7);
   // (3) atom-owned gather.  The 256 lanes form (atom, slice) pairs: A = 16/32/64 atoms per round (the smallest
   // power of two that covers the subtree's local atoms) times BS/A slices of the node list, so small subtrees
   // (most of them) walk the nodes 16 ways instead of 4.  Slices are folded inside a wave by lane exchanges and
@@ -695,6 +726,7 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     }
   }
   __syncthreads();
+  AGBNP_BUILD_STAMP(14);
 }
 
 // ---- after the passes: the root atom's gradient = -(sum of the other local atoms' gradients) ----------------

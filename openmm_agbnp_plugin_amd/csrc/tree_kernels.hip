@@ -35,6 +35,22 @@ __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase;
 #define STAMP(i)
 #define STAMP_FLUSH()
 #endif
+// -DAGBNP_STAMPS_PSEUDO moves the stamps from k_tree_cavity to k_tree_pseudo
+#if defined(AGBNP_STAMPS_PSEUDO)
+#define CSTAMP_BEGIN()
+#define CSTAMP(i)
+#define CSTAMP_FLUSH()
+#define PSTAMP_BEGIN() STAMP_BEGIN()
+#define PSTAMP(i) STAMP(i)
+#define PSTAMP_FLUSH() STAMP_FLUSH()
+#else
+#define CSTAMP_BEGIN() STAMP_BEGIN()
+#define CSTAMP(i) STAMP(i)
+#define CSTAMP_FLUSH() STAMP_FLUSH()
+#define PSTAMP_BEGIN()
+#define PSTAMP(i)
+#define PSTAMP_FLUSH()
+#endif
 
 // Build + cavity passes of one heavy atom's subtree (reference steps A-D of
 // platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).
@@ -45,7 +61,11 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
 
+#ifdef AGBNP_DIAG_SKIP  // timing experiment only: leave the largest subtrees out (results are incomplete)
+  for (int slot = blockIdx.x + AGBNP_DIAG_SKIP; slot < A.nh; slot += gridDim.x) {
+#else
   for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
+#endif
     const int hi = A.order[slot];  // longest-processing-time-first: big subtrees start early, small ones fill the tail
     for (int la = tid; la < ACAP; la += BS) {
       S.at[6][la] = 0.0;
@@ -54,40 +74,22 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       S.at[9][la] = 0.0;
     }
     __syncthreads();
-    STAMP_BEGIN();
+    CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
     const int rc = build_subtree<NCAP, ACAP, BS>(S, A, tid, hi, &nnodes, &natoms);
-    STAMP(0);
+    CSTAMP(0);
     if (rc != kBuildOk) {
       if (tid == 0) {
         atomicAdd(&A.status[rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow], 1);
-        A.hdr[hi].nnodes = 0;
-        A.hdr[hi].natoms = 0;
+        A.hdr[slot].nnodes = 0;
+        A.hdr[slot].natoms = 0;
         A.sizes[hi] = make_int2(0, 0);
       }
       __syncthreads();
       continue;
     }
 
-    // ---- topology out (8 B/node) for the pseudo-volume pass: fixed stride per subtree, no allocation traffic
-    {
-      const size_t pool_off = (size_t)hi * NCAP, atom_off = (size_t)hi * ACAP;
-      for (int n = tid; n < nnodes; n += BS)
-        A.node_pool[pool_off + n] = make_ushort4(S.nla[n], S.npar[n], S.ncs[n], S.ncc[n]);
-      for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
-      if (tid == 0) {
-        SubtreeHeader h;
-        h.nnodes = nnodes;
-        h.natoms = natoms;
-        h.pool_off = 0;
-        h.atom_off = 0;
-        h.lvl[0] = 0;
-        for (int L = 1; L <= 9; L++) h.lvl[L] = S.lvl[L];
-        A.hdr[hi] = h;
-        A.sizes[hi] = make_int2(nnodes, natoms);
-      }
-    }
-    STAMP(1);
+    CSTAMP(1);
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
     // The node slots still hold the Gaussians of the build, so only the atom paths are laid down before the
     // gather.  Its gradient stays in the local accumulators and leaves together with that of pass 2.
@@ -104,7 +106,26 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         }
       }
     }
-    STAMP(2);
+    // ---- topology out for the pseudo-volume pass: the atom paths (8 B/node) and the local atom list are all a
+    // replay needs; fixed stride per subtree, no allocation traffic
+    {
+      const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
+      const unsigned long long* path = reinterpret_cast<const unsigned long long*>(S.nd[6]);
+      for (int n = 1 + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
+      for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
+      if (tid == 0) {
+        SubtreeHeader h;
+        h.nnodes = nnodes;
+        h.natoms = natoms;
+        h.root = hi;
+        h.reserved = 0;
+        h.lvl[0] = 0;
+        for (int L = 1; L <= 9; L++) h.lvl[L] = S.lvl[L];
+        A.hdr[slot] = h;
+        A.sizes[hi] = make_int2(nnodes, natoms);
+      }
+    }
+    CSTAMP(2);
     // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
@@ -113,15 +134,15 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       S.at[5][la] = -S.at[5][la];
     }
     __syncthreads();
-    STAMP(3);
+    CSTAMP(3);
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
     volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum);
-    STAMP(4);
+    CSTAMP(4);
     const double e2 = e_sum + S.at[5][0] * S.at[4][0];
     const double sv2_root = w_sum + S.at[4][0];
     root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
-    STAMP(5);
+    CSTAMP(5);
 
     // ---- flush per-atom sums
     for (int la = tid; la < natoms; la += BS) {
@@ -133,8 +154,8 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     }
     if (tid == 0) A.epart[2 * hi + 1] = e2;
     __syncthreads();
-    STAMP(6);
-    STAMP_FLUSH();
+    CSTAMP(6);
+    CSTAMP_FLUSH();
   }
 }
 
@@ -148,18 +169,14 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
   for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
-    const int hi = A.order[slot];
-    const SubtreeHeader* H = &A.hdr[hi];
+    PSTAMP_BEGIN();
+    const SubtreeHeader* H = &A.hdr[slot];  // written by k_tree_cavity's workgroup of the same slot
     const int nnodes = H->nnodes, natoms = H->natoms;
     if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
-    const size_t pool_off = (size_t)hi * NCAP, atom_off = (size_t)hi * ACAP;
-    if (tid < 10) S.lvl[tid] = H->lvl[tid];
-    for (int n = tid; n < nnodes; n += BS) {
-      const ushort4 t = A.node_pool[pool_off + n];
-      S.nla[n] = t.x;
-      S.npar[n] = t.y;
-      S.ncs[n] = t.z;
-      S.ncc[n] = t.w;
+    const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
+    {
+      unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
+      for (int n = 1 + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
     }
     for (int la = tid; la < natoms; la += BS) {
       const int hj = A.atom_pool[atom_off + la];
@@ -169,15 +186,17 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       S.at[2][la] = A.hz[hj];
       S.at[3][la] = A.a_vdw[hj];
       S.at[4][la] = A.v_vdw[hj];
-      S.at[5][la] = A.db_wu[A.h2a[hj]] * A.inv_vol_h[hj];
+      S.at[5][la] = A.db_wu[hj] * A.inv_vol_h[hj];
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
       S.at[8][la] = 0.0;
       S.at[9][la] = 0.0;
     }
     __syncthreads();
+    PSTAMP(0);
     double e_sum = 0.0, w_sum = 0.0;
     volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum);
+    PSTAMP(1);
     root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
@@ -186,6 +205,8 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       glb_add(&A.gz[hj], S.at[8][la]);
     }
     __syncthreads();
+    PSTAMP(2);
+    PSTAMP_FLUSH();
   }
 }
 

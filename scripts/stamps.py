@@ -20,10 +20,13 @@ for k in range(reps):
     ctx.setPositions(s.jittered(k)); ctx.getState()
 lib.agbnp_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64) / reps
-names = {0: "build (total)", 1: "topology out", 2: "sweep 1", 3: "switch radii", 4: "rescan", 5: "sweep 2", 6: "flush",
+pseudo = os.environ.get("AGBNP_STAMPS_PSEUDO") is not None  # library built with -DAGBNP_STAMPS_PSEUDO
+names = {0: "build (total)", 1: "(unused)", 2: "pass 1 + topology out", 3: "switch radii", 4: "pass 2", 5: "root gradient", 6: "flush",
          8: " build: level-2 scan", 9: " build: level-2 rank+create", 10: " build: phase0 (tasks/scan/map)", 11: " build: phase1 (volumes)",
          12: " build: phase2 (count/scan)", 13: " build: phase3 (rank+create)",
-         7: " sweeps: reads+merge (first round/level)", 14: " sweeps: children loop", 15: " sweeps: rcp+atomics+writes+barrier"}
+         7: " passes: node step (1+2)", 14: " passes: gather"}
+if pseudo:
+    names = {0: "load paths + atoms", 1: "volume pass", 2: "root gradient + flush", 7: " pass: node step (1+2)", 14: " pass: gather"}
 mx = (C.c_ulonglong * 16)()
 lib.agbnp_debug_stamps_max(mx, 1)
 mx = np.array(list(mx), dtype=np.float64)
