@@ -32,7 +32,7 @@ struct SubtreeHeader {
   int nnodes;      // nodes in the subtree including the level-1 root (0: not built)
   int natoms;      // local atoms (root + its level-2 partners)
   int root;        // heavy index of the subtree's root atom
-  int reserved;
+  int npairs;      // (atom, node) membership pairs stored for the replay
   int lvl[10];     // lvl[L] = first node of level L (L = 1..8), lvl[9] = nnodes sentinel; lvl[0] unused
 };
 

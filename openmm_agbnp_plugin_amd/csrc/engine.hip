@@ -92,6 +92,7 @@ struct agbnp_hip_context {
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
   DevBuf<SubtreeHeader> d_hdr;
   DevBuf<unsigned long long> d_node_pool;
+  DevBuf<unsigned short> d_pair_pool;
   DevBuf<int> d_atom_pool;
   DevBuf<char> d_scratch;
   // host-API staging
@@ -183,6 +184,11 @@ int ensure_scratch(agbnp_hip_context* c) {
     HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
     c->T.node_pool = c->d_node_pool.p;
   }
+  const size_t need_pairs = c->variant == 0 ? 4 * need_nodes : 0;  // membership pairs of the 512-node variant
+  if (c->d_pair_pool.count < need_pairs) {
+    HIP_TRY(c, c->d_pair_pool.alloc(need_pairs));
+    c->T.pair_pool = c->d_pair_pool.p;
+  }
   if (c->d_atom_pool.count < need_atoms) {
     HIP_TRY(c, c->d_atom_pool.alloc(need_atoms));
     c->T.atom_pool = c->d_atom_pool.p;
@@ -269,6 +275,7 @@ void wire_args(agbnp_hip_context* c) {
   T.epart = c->d_epart.p;
   T.hdr = c->d_hdr.p;
   T.node_pool = c->d_node_pool.p;
+  T.pair_pool = c->d_pair_pool.p;
   T.atom_pool = c->d_atom_pool.p;
   P.sizes = c->d_sizes.p;
   T.sizes = c->d_sizes.p;

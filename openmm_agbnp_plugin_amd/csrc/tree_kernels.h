@@ -58,6 +58,7 @@ struct TreeArgs {
   int2* sizes;         // [nh] {nodes, local atoms} of every subtree, compact copy for the bookkeeping block
   unsigned long long* node_pool;  // [nh][NCAP] atom path of every node (all a replay needs), fixed stride per subtree
   int* atom_pool;      // [nh][ACAP] local atom -> heavy index
+  unsigned short* pair_pool;  // [nh][4 NCAP] (atom, node) membership pairs sorted by atom (LDS variants up to 512 nodes)
   int* status;  // [kStatWords]
   char* scratch;  // GLOBAL variant: per-workgroup slab
   size_t scratch_stride;
@@ -83,6 +84,13 @@ struct TreeStore {
   unsigned short *nla, *npar, *ncs, *ncc;  // [NCAP]
   unsigned short *tstart, *cbase;          // [kTreeBlock + 2] per-batch task start / child base
   unsigned long long* kmask;               // [TCAP/64] per 64 tasks of a batch: which ones survive the switch
+  // (atom, node) membership pairs sorted by atom, one 16-bit word each (atom << 9 | node): the gather of a volume
+  // pass walks this list instead of testing every node against every atom.  Built once per subtree after the
+  // build, when the four 16-bit topology arrays are dead: the list lives in their place.
+  static constexpr bool kPairGather = NCAP <= 512 && ACAP <= 128;
+  static constexpr int PCAP = 4 * NCAP;
+  unsigned short* pairs;  // [PCAP]
+  int* pcnt;              // [ACAP] per-atom counts / fill cursors while the list is built (overlays cand_vol)
 #ifdef AGBNP_STAMPS
   unsigned long long* stamps;  // [16] diagnostic build only
   static constexpr size_t kStampBytes = 16 * sizeof(unsigned long long) + 8;
@@ -94,6 +102,40 @@ struct TreeStore {
                                    sizeof(int) * (2 * (size_t)ACAP + 24) +
                                    sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + 8 +
                                    sizeof(unsigned long long) * (TCAP / 64) + kStampBytes;
+
+  // A replay (volume pass from stored atom paths) touches only the node rows 0-3, 5, 6, the local atom table and the
+  // per-wave partial sums: 3/4 of the full footprint, so five replay workgroups fit a CU instead of four.  (The
+  // variants whose gather may take several rounds keep row 4 as the exchange area of its cross-wave fold.)
+  static constexpr int kReplayRows = ACAP <= 64 ? 6 : 7;
+  static constexpr size_t kReplayBytes = sizeof(double) * (kReplayRows * (size_t)NCAP + 10 * (size_t)ACAP + 8) +
+                                         sizeof(int) * (size_t)ACAP + kStampBytes +
+                                         (kPairGather ? sizeof(unsigned short) * (size_t)PCAP + 16 : 0);
+  __device__ __forceinline__ void carve_replay(char* base) {
+    double* d = reinterpret_cast<double*>(base);
+    if (kReplayRows == 7) {
+      for (int k = 0; k < 7; k++) nd[k] = d + (size_t)k * NCAP;
+    } else {
+      for (int k = 0; k < 7; k++) nd[k] = d + (size_t)(k < 4 ? k : k - 1) * NCAP;  // row 4 (unswitched volume) is not stored
+      nd[4] = nullptr;
+    }
+    d += kReplayRows * (size_t)NCAP;
+    for (int k = 0; k < 10; k++) at[k] = d + (size_t)k * ACAP;
+    d += 10 * (size_t)ACAP;
+    misc = d;
+    d += 8;
+#ifdef AGBNP_STAMPS
+    stamps = reinterpret_cast<unsigned long long*>(d);
+    d += 17;
+#endif
+    at_gidx = reinterpret_cast<int*>(d);
+    pairs = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(at_gidx + ACAP) + 15) & ~(uintptr_t)15);  // 16-byte stores
+    pcnt = nullptr;
+    cand_vol = nullptr;
+    cand_idx = nullptr;
+    lvl = ctl = nullptr;
+    nla = npar = ncs = ncc = tstart = cbase = nullptr;
+    kmask = nullptr;
+  }
 
   __device__ __forceinline__ void carve(char* base) {
     double* d = reinterpret_cast<double*>(base);
@@ -115,6 +157,8 @@ struct TreeStore {
     ctl = ip;
     ip += 12;
     unsigned short* sp = reinterpret_cast<unsigned short*>(ip);
+    pairs = sp;
+    pcnt = reinterpret_cast<int*>(cand_vol);
     nla = sp;
     npar = sp + NCAP;
     ncs = sp + 2 * (size_t)NCAP;
@@ -580,13 +624,21 @@ __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
   return t[k];
 }
 
+// *npairs: length of the (atom, node) pair list; written by a FRESH_BUILD pass (which builds the list), read by the
+// others.  Returns false (workgroup-uniform) if the list does not fit: the caller reports a capacity overflow.
 template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
-__device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
-                            double* w_sum) {
+__device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
+                            double* w_sum, int* npairs) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
+  constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
+  constexpr int PCAP = TreeStore<NCAP, ACAP>::PCAP;
   unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
   AGBNP_BUILD_STAMP_BEGIN();
+  if (FRESH_BUILD && kPairs) {
+    for (int la = tid; la < ACAP; la += BS) S.pcnt[la] = 0;
+    __syncthreads();
+  }
   // (1+2) node-parallel: centre slots <- c_n, exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n,
   //       gamma slot <- w_n = c_n s(G_n) G_n   (c_n = +-1/level)
   double e_part = 0.0, w_part = 0.0;
@@ -597,7 +649,9 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
       unsigned long long pw = 0ull;
       level = 1;
       for (int p = n; p != 0; p = S.npar[p]) {  // leaf to root: the deepest atom is met first
-        pw = (pw << 8) | (unsigned long long)S.nla[p];
+        const int la = S.nla[p];
+        pw = (pw << 8) | (unsigned long long)la;
+        if (kPairs) atomicAdd(&S.pcnt[la], 1);
         level++;
       }
       path[n] = pw;
@@ -658,10 +712,69 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     *w_sum = ws;
   }
   AGBNP_BUILD_STAMP(7);
-  // (3) atom-owned gather.  The 256 lanes form (atom, slice) pairs: A = 16/32/64 atoms per round (the smallest
-  // power of two that covers the subtree's local atoms) times BS/A slices of the node list, so small subtrees
-  // (most of them) walk the nodes 16 ways instead of 4.  Slices are folded inside a wave by lane exchanges and
-  // across waves through four LDS rows; every atom is finally updated by exactly one lane: no atomics.
+  if (kPairs) {
+    if (FRESH_BUILD) {
+      // counting sort of the (atom, node) memberships by atom: counts -> exclusive offsets (wave 0, two atoms per
+      // lane) -> every node drops its own entries at its atoms' cursors
+      static_assert(!kPairs || ACAP <= 128, "two atoms per lane");
+      if (tid < 64) {
+        const int a0 = 2 * tid, a1 = 2 * tid + 1;
+        const int c0 = a0 < ACAP ? S.pcnt[a0] : 0, c1 = a1 < ACAP ? S.pcnt[a1] : 0;
+        const int incl = wave_inclusive_scan(c0 + c1);
+        if (a0 < ACAP) S.pcnt[a0] = incl - c0 - c1;
+        if (a1 < ACAP) S.pcnt[a1] = incl - c1;
+        if (tid == 63) S.ctl[4] = incl;
+      }
+      __syncthreads();
+      const int total = S.ctl[4];
+      *npairs = total;
+      if (total > PCAP) return false;
+      for (int n = 1 + tid; n < nnodes; n += BS)
+        for (unsigned long long pw = path[n]; pw; pw >>= 8) {
+          const int la = (int)(pw & 0xffull);
+          S.pairs[atomicAdd(&S.pcnt[la], 1)] = (unsigned short)((la << 9) | n);
+        }
+      __syncthreads();
+    }
+    // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom), sums
+    // the terms of a run of the same atom in registers and adds the run to the atom's accumulators with LDS FP64
+    // atomics: work proportional to the memberships (about three per node), independent of how many local
+    // atoms the subtree has, and balanced over the lanes whatever the shape of the tree.
+    const int total = *npairs;
+    const int chunk = (total + BS - 1) / BS;
+    int k = tid * chunk;
+    const int kend = k + chunk < total ? k + chunk : total;
+    int cur = -1;
+    double xa = 0.0, ya = 0.0, za = 0.0, ea = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
+    auto flush = [&]() {
+      lds_add(&S.at[6][cur], gx);
+      lds_add(&S.at[7][cur], gy);
+      lds_add(&S.at[8][cur], gz);
+      if (with_selfvol) lds_add(&S.at[9][cur], sv);
+    };
+    for (; k < kend; k++) {
+      const int pr = S.pairs[k];
+      const int a = pr >> 9, n = pr & 511;
+      const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
+      if (a != cur) {
+        if (cur >= 0) flush();
+        cur = a;
+        xa = S.at[0][a], ya = S.at[1][a], za = S.at[2][a], ea = S.at[3][a];
+        gx = gy = gz = sv = 0.0;
+      }
+      const double am = cf * ea;
+      gx = fma(am, xa - cx, gx);
+      gy = fma(am, ya - cy, gy);
+      gz = fma(am, za - cz, gz);
+      sv += wn;
+    }
+    if (cur >= 0) flush();
+    __syncthreads();
+    AGBNP_BUILD_STAMP(14);
+    return true;
+  }
+  // (3) atom-owned gather (variants too large for 16-bit pair words).  The 256 lanes form (atom, slice) pairs:
+  // A = 16/32/64 atoms per round (the smallest
   {
     const int A = natoms <= 16 ? 16 : (natoms <= 32 ? 32 : 64);
     const int nslices = BS / A;
@@ -727,6 +840,7 @@ __device__ void volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
   }
   __syncthreads();
   AGBNP_BUILD_STAMP(14);
+  return true;
 }
 
 // ---- after the passes: the root atom's gradient = -(sum of the other local atoms' gradients) ----------------

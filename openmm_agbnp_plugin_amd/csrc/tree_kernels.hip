@@ -94,9 +94,23 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     // The node slots still hold the Gaussians of the build, so only the atom paths are laid down before the
     // gather.  Its gradient stays in the local accumulators and leaves together with that of pass 2.
     double e_sum, w_sum;
+    int npairs = 0;
+    // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
+    // LDS variants: one atom per lane)
+    const int hj_mine = tid < natoms ? S.at_gidx[tid] : hi;
+    const double a_vdw_mine = A.a_vdw[hj_mine], v_vdw_mine = A.v_vdw[hj_mine];
     {
       const bool want_sv1 = A.sv_large != nullptr;
-      volume_pass<NCAP, ACAP, BS, true, true>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum);
+      if (!volume_pass<NCAP, ACAP, BS, true, true>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum, &npairs)) {
+        if (tid == 0) {  // the membership list does not fit: same protocol as a node overflow
+          atomicAdd(&A.status[kStatNodeOverflow], 1);
+          A.hdr[slot].nnodes = 0;
+          A.hdr[slot].natoms = 0;
+          A.sizes[hi] = make_int2(0, 0);
+        }
+        __syncthreads();
+        continue;
+      }
       // level-1 node: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
       if (tid == 0) A.epart[2 * hi] = e_sum + S.at[5][0] * S.at[4][0];
       if (want_sv1) {  // diagnostics: enlarged-radius self volumes
@@ -113,12 +127,16 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       const unsigned long long* path = reinterpret_cast<const unsigned long long*>(S.nd[6]);
       for (int n = 1 + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
       for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
+      if (TreeStore<NCAP, ACAP>::kPairGather) {
+        const size_t pair_off = (size_t)slot * TreeStore<NCAP, ACAP>::PCAP;
+        for (int k = tid; k < npairs; k += BS) A.pair_pool[pair_off + k] = S.pairs[k];
+      }
       if (tid == 0) {
         SubtreeHeader h;
         h.nnodes = nnodes;
         h.natoms = natoms;
         h.root = hi;
-        h.reserved = 0;
+        h.npairs = npairs;
         h.lvl[0] = 0;
         for (int L = 1; L <= 9; L++) h.lvl[L] = S.lvl[L];
         A.hdr[slot] = h;
@@ -127,17 +145,25 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     }
     CSTAMP(2);
     // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
-    for (int la = tid; la < natoms; la += BS) {
-      const int hj = S.at_gidx[la];
-      S.at[3][la] = A.a_vdw[hj];
-      S.at[4][la] = A.v_vdw[hj];
-      S.at[5][la] = -S.at[5][la];
+    if (ACAP <= BS) {
+      if (tid < natoms) {
+        S.at[3][tid] = a_vdw_mine;
+        S.at[4][tid] = v_vdw_mine;
+        S.at[5][tid] = -S.at[5][tid];
+      }
+    } else {
+      for (int la = tid; la < natoms; la += BS) {
+        const int hj = S.at_gidx[la];
+        S.at[3][la] = A.a_vdw[hj];
+        S.at[4][la] = A.v_vdw[hj];
+        S.at[5][la] = -S.at[5][la];
+      }
     }
     __syncthreads();
     CSTAMP(3);
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
-    volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum);
+    volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum, &npairs);
     CSTAMP(4);
     const double e2 = e_sum + S.at[5][0] * S.at[4][0];
     const double sv2_root = w_sum + S.at[4][0];
@@ -166,20 +192,45 @@ template <int NCAP, int ACAP, int BS, bool GLOBAL>
 __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
-  S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
+  S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
   for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
     PSTAMP_BEGIN();
+    // One round trip to the stored topology: the paths and the local atom list are requested together with the
+    // header (capacity-strided slots: reading past the subtree's own entries is harmless, the values are masked
+    // below), a second one to the per-atom parameters.
     const SubtreeHeader* H = &A.hdr[slot];  // written by k_tree_cavity's workgroup of the same slot
-    const int nnodes = H->nnodes, natoms = H->natoms;
-    if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
     const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
+    static_assert(GLOBAL || (NCAP <= 8 * BS && ACAP <= BS), "prefetch registers");
+    unsigned long long pw[GLOBAL ? 1 : (NCAP + BS - 1) / BS];
+    int hj_pre = 0;
+    constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
+    constexpr int kPairWords = kPairs ? TreeStore<NCAP, ACAP>::PCAP / 8 : 1;  // 16-byte words of the pair list
+    static_assert(!kPairs || kPairWords <= BS, "one 16-byte word of the pair list per lane");
+    uint4 pair_word = make_uint4(0, 0, 0, 0);
+    if (kPairs && tid < kPairWords)
+      pair_word = reinterpret_cast<const uint4*>(A.pair_pool + (size_t)slot * TreeStore<NCAP, ACAP>::PCAP)[tid];
+    if (!GLOBAL) {
+#pragma unroll
+      for (int k = 0; k < (NCAP + BS - 1) / BS; k++) pw[k] = tid + k * BS < NCAP ? A.node_pool[pool_off + tid + k * BS] : 0ull;
+      hj_pre = tid < ACAP ? A.atom_pool[atom_off + tid] : 0;
+    }
+    const int nnodes = H->nnodes, natoms = H->natoms;
+    int npairs = H->npairs;
+    if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
+    if (kPairs && tid < kPairWords) reinterpret_cast<uint4*>(S.pairs)[tid] = pair_word;
     {
       unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
-      for (int n = 1 + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
+      if (GLOBAL) {
+        for (int n = 1 + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
+      } else {
+#pragma unroll
+        for (int k = 0; k < (NCAP + BS - 1) / BS; k++)
+          if (tid + k * BS >= 1 && tid + k * BS < nnodes) path[tid + k * BS] = pw[k];
+      }
     }
     for (int la = tid; la < natoms; la += BS) {
-      const int hj = A.atom_pool[atom_off + la];
+      const int hj = GLOBAL ? A.atom_pool[atom_off + la] : hj_pre;
       S.at_gidx[la] = hj;
       S.at[0][la] = A.hx[hj];
       S.at[1][la] = A.hy[hj];
@@ -195,7 +246,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     __syncthreads();
     PSTAMP(0);
     double e_sum = 0.0, w_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum);
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum, &npairs);
     PSTAMP(1);
     root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     for (int la = tid; la < natoms; la += BS) {
@@ -283,9 +334,9 @@ hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, h
 hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kBytes, A, st);
-    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kBytes, A, st);
-    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, A.nh, TreeStore<2048, 256>::kBytes, A, st);
+    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kReplayBytes, A, st);
+    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kReplayBytes, A, st);
+    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, A.nh, TreeStore<2048, 256>::kReplayBytes, A, st);
     default:
       return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
