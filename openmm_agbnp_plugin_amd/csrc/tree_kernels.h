@@ -108,8 +108,8 @@ struct TreeStore {
   // variants whose gather may take several rounds keep row 4 as the exchange area of its cross-wave fold.)
   static constexpr int kReplayRows = ACAP <= 64 ? 6 : 7;
   static constexpr size_t kReplayBytes = sizeof(double) * (kReplayRows * (size_t)NCAP + 10 * (size_t)ACAP + 8) +
-                                         sizeof(int) * (size_t)ACAP + kStampBytes +
-                                         (kPairGather ? sizeof(unsigned short) * (size_t)PCAP + 16 : 0);
+                                         sizeof(int) * (size_t)ACAP + kStampBytes;
+  static_assert(!kPairGather || sizeof(unsigned short) * PCAP <= sizeof(double) * NCAP, "pair list fits the path row");
   __device__ __forceinline__ void carve_replay(char* base) {
     double* d = reinterpret_cast<double*>(base);
     if (kReplayRows == 7) {
@@ -128,7 +128,7 @@ struct TreeStore {
     d += 17;
 #endif
     at_gidx = reinterpret_cast<int*>(d);
-    pairs = reinterpret_cast<unsigned short*>((reinterpret_cast<uintptr_t>(at_gidx + ACAP) + 15) & ~(uintptr_t)15);  // 16-byte stores
+    pairs = reinterpret_cast<unsigned short*>(nd[6]);  // a replay drops the pair list over the atom paths once the node step is done
     pcnt = nullptr;
     cand_vol = nullptr;
     cand_idx = nullptr;
@@ -628,7 +628,7 @@ __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
 // others.  Returns false (workgroup-uniform) if the list does not fit: the caller reports a capacity overflow.
 template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
 __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
-                            double* w_sum, int* npairs) {
+                            double* w_sum, int* npairs, const uint4* pair_word = nullptr) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
   constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
@@ -734,6 +734,10 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
           const int la = (int)(pw & 0xffull);
           S.pairs[atomicAdd(&S.pcnt[la], 1)] = (unsigned short)((la << 9) | n);
         }
+      __syncthreads();
+    }
+    if (pair_word) {  // replay: the pair list arrives in registers and takes the place of the atom paths
+      if (tid < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid] = *pair_word;
       __syncthreads();
     }
     // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom), sums

@@ -218,7 +218,6 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     const int nnodes = H->nnodes, natoms = H->natoms;
     int npairs = H->npairs;
     if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
-    if (kPairs && tid < kPairWords) reinterpret_cast<uint4*>(S.pairs)[tid] = pair_word;
     {
       unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
       if (GLOBAL) {
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     __syncthreads();
     PSTAMP(0);
     double e_sum = 0.0, w_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum, &npairs);
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum, &npairs, kPairs ? &pair_word : nullptr);
     PSTAMP(1);
     root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
     for (int la = tid; la < natoms; la += BS) {
