@@ -28,26 +28,35 @@
 
 namespace agbnp {
 
-// ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, y2_k*dr^2/6}) ------------------
-__device__ __forceinline__ double spline_value(const double2* __restrict__ tab, int base, double d) {
-  const double t = d * ((kI4Nodes - 1) / kI4MaxA);
-  int k = (int)t;
+// ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, z_k = y2_k*dr^2/6}) -------------------
+// Natural cubic spline of the reference (AGBNPUtils.h:104-115 -> SplineFitter): on interval k, with t in [0,1),
+//   S = (1-t) y_k + t y_k+1 + ((1-t)^3 - (1-t)) z_k + (t^3 - t) z_k+1
+// expanded in powers of t (same polynomial, fewer operations than the a/b form):
+//   S = y_k + t (dy - 2 z_k - z_k+1) + 3 z_k t^2 + (z_k+1 - z_k) t^3,     dy = y_k+1 - y_k
+struct SplineCubic {
+  double c0, c1, c2, c3, t;
+};
+__device__ __forceinline__ SplineCubic spline_cubic(const double2* __restrict__ tab, int base, double d) {
+  const double u = d * ((kI4Nodes - 1) / kI4MaxA);
+  int k = (int)u;
   k = k > kI4Nodes - 2 ? kI4Nodes - 2 : k;
-  const double a = (double)(k + 1) - t;
-  const double b = 1.0 - a;
   const double2 lo = tab[base + k], hi = tab[base + k + 1];
-  return a * lo.x + b * hi.x + (a * a * a - a) * lo.y + (b * b * b - b) * hi.y;
+  SplineCubic c;
+  c.t = u - (double)k;
+  c.c0 = lo.x;
+  c.c1 = (hi.x - lo.x) - fma(2.0, lo.y, hi.y);
+  c.c2 = 3.0 * lo.y;
+  c.c3 = hi.y - lo.y;
+  return c;
+}
+__device__ __forceinline__ double spline_value(const double2* __restrict__ tab, int base, double d) {
+  const SplineCubic c = spline_cubic(tab, base, d);
+  return fma(fma(fma(c.c3, c.t, c.c2), c.t, c.c1), c.t, c.c0);
 }
 __device__ __forceinline__ void spline_value_deriv(const double2* __restrict__ tab, int base, double d, double& val, double& der) {
-  const double invdr = (kI4Nodes - 1) / kI4MaxA;
-  const double t = d * invdr;
-  int k = (int)t;
-  k = k > kI4Nodes - 2 ? kI4Nodes - 2 : k;
-  const double a = (double)(k + 1) - t;
-  const double b = 1.0 - a;
-  const double2 lo = tab[base + k], hi = tab[base + k + 1];
-  val = a * lo.x + b * hi.x + (a * a * a - a) * lo.y + (b * b * b - b) * hi.y;
-  der = ((hi.x - lo.x) + (1.0 - 3.0 * a * a) * lo.y + (3.0 * b * b - 1.0) * hi.y) * invdr;
+  const SplineCubic c = spline_cubic(tab, base, d);
+  val = fma(fma(fma(c.c3, c.t, c.c2), c.t, c.c1), c.t, c.c0);
+  der = fma(fma(3.0 * c.c3, c.t, 2.0 * c.c2), c.t, c.c1) * ((kI4Nodes - 1) / kI4MaxA);
 }
 
 __device__ __forceinline__ void hbm_add(double* p, double v) {  // global_atomic_add_f64
@@ -205,9 +214,15 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
                                                   double* __restrict__ born_fp, double* __restrict__ brw,
                                                   double* __restrict__ e_atom, double* __restrict__ gb_rows,
                                                   double* __restrict__ egb_part) {
-  __shared__ double2 s_xy[128], s_zq[128], s_bb[128];  // block J twice over: entry m and m + 64 are atom 64 J + m
-  __shared__ double2 s_ixy[64], s_izq[64], s_ibc[64];   // block I: {x, y}, {z, q}, {B, -log2(e)/(4 B)}
-  __shared__ TileSums s_sums;
+  // one LDS area, two lives: the atom records during the walk, the sums of the four waves after it
+  __shared__ __align__(16) char s_area[sizeof(TileSums)];
+  static_assert(sizeof(TileSums) >= sizeof(double2) * (3 * 128 + 3 * 64), "records fit the area of the sums");
+  double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over: entry m and m + 64 are atom 64 J + m
+  double2* const s_zq = s_xy + 128;
+  double2* const s_bb = s_zq + 128;
+  double2* const s_ixy = s_bb + 128;                          // block I: {x, y}, {z, q}, {B, -log2(e)/(4 B)}
+  double2* const s_izq = s_ixy + 64;
+  double2* const s_ibc = s_izq + 64;
   __shared__ double s_e[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = items[blockIdx.x];
@@ -287,6 +302,8 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
     yj_acc = rot1(yj_acc);
   }
   const double kf = -2.0 * kDielFactor;
+  __syncthreads();  // every wave is done with the records
+  TileSums& s_sums = *reinterpret_cast<TileSums*>(s_area);
   {
     const double vi4[4] = {kf * fxi, kf * fyi, kf * fzi, yi}, vj4[4] = {kf * fxj, kf * fyj, kf * fzj, yj_acc};
     tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
@@ -460,7 +477,6 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   extern __shared__ double2 s_lut[];
   // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
   __shared__ double2 s_rec[3][128];
-  __shared__ TileSums s_sums;
   // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
   // and the spline tables
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -517,6 +533,8 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
     dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj);
   else
     dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj);
+  __syncthreads();  // every wave is done with the spline tables: their LDS now carries the sums of the four waves
+  TileSums& s_sums = *reinterpret_cast<TileSums*>(s_lut);
   {
     const double vi4[4] = {L.fxi, L.fyi, L.fzi, L.wui}, vj4[4] = {L.fxj, L.fyj, L.fzj, L.wuj};
     tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
@@ -720,7 +738,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
   if (P.db_items_count > 0)
-    hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
+    hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
                      (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx);
   AGBNP_CHECK_LAUNCH();
