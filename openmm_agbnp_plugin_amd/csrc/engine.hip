@@ -372,7 +372,7 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
   HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->T, st));
   if (c->version == 1) {
-    HIP_TRY(c, launch_pair_stages(c->P, st, tl));
+    HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
     HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->T, st));
   }

@@ -72,7 +72,7 @@ struct Timeline {
 };
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
-hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl);
+hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl);
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl);
 

@@ -412,146 +412,11 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   }
 }
 
-// ---- Born-radius chain rule, 64x64 tiles in "pair order" with range culling ------------------------------
-// Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
-//   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
-// Only heavy atoms descreen, so the atoms are walked in pair order (pslot): all heavy atoms first, then all
-// hydrogens, each group padded to whole blocks of 64.  That leaves two kinds of tiles and no per-lane type tests:
-//   heavy x heavy  symmetric tiles (I <= J), every unordered pair met once, both directions (two look-ups)
-//   heavy x H      full tiles, one direction (the heavy atom descreens the hydrogen, one look-up)
-//   H x H          nothing to do, never scheduled
-// which halves the table look-ups (the LDS pipe is what bounds this kernel).  Machinery as in k_gb_tiles:
-// block I in registers, the static record of block J from a doubled LDS copy, the sums of the j atom travel by
-// DPP rotation.  A work item whose two bounding boxes are more than the table's 2 nm reach apart exits at once.
-struct DbornLane {
-  double x, y, z, bw, s;   // the lane's own atom i
-  int row, tsr;            // screened type * ntj, screener type
-  double fxi, fyi, fzi, wui, fxj, fyj, fzj, wuj;
-};
-
-template <bool kBoth>
-__device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restrict__ s_lut, const double2* __restrict__ jxy,
-                                           const double2* __restrict__ jzw, const double2* __restrict__ jsm, int nsteps,
-                                           int masked_step, bool vi, bool lower, int ntj) {
-#pragma unroll 4
-  for (int k = 0; k < nsteps; k++) {
-    const double2 xy = jxy[k], zw = jzw[k], sm = jsm[k];
-    const double dx = xy.x - L.x, dy = xy.y - L.y, dz = zw.x - L.z;
-    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-    const int tj = __double2loint(sm.y);  // screened type | screener type << 16
-    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(sm.y) >= 0 && (k != masked_step || lower)) {
-      const double rinv = rsqrt_pos(d2);
-      const double d = d2 * rinv;
-      double q2, dq2;  // i descreens j
-      spline_value_deriv(s_lut, ((tj & 0xffff) * ntj + L.tsr) * kI4Nodes, d, q2, dq2);
-      L.wui = fma(zw.y, q2, L.wui);
-      double t = zw.y * L.s * dq2;
-      if (kBoth) {  // j descreens i
-        double q1, dq1;
-        spline_value_deriv(s_lut, (L.row + (tj >> 16)) * kI4Nodes, d, q1, dq1);
-        L.wuj = fma(L.bw, q1, L.wuj);
-        t = fma(L.bw * sm.x, dq1, t);
-      }
-      t *= rinv;
-      L.fxi = fma(dx, t, L.fxi);
-      L.fyi = fma(dy, t, L.fyi);
-      L.fzi = fma(dz, t, L.fzi);
-      L.fxj = fma(-dx, t, L.fxj);
-      L.fyj = fma(-dy, t, L.fyj);
-      L.fzj = fma(-dz, t, L.fzj);
-    }
-    L.fxj = rot1(L.fxj);
-    L.fyj = rot1(L.fyj);
-    L.fzj = rot1(L.fzj);
-    if (kBoth) L.wuj = rot1(L.wuj);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
-                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
-                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
-                                                    const double* __restrict__ born, const double* __restrict__ born_fp,
-                                                    const double* __restrict__ brw, const double* __restrict__ gb_y,
-                                                    const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
-                                                    int nh, const double2* __restrict__ lut, double* __restrict__ db_rows) {
-  extern __shared__ double2 s_lut[];
-  // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
-  __shared__ double2 s_rec[3][128];
-  // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
-  // and the spline tables
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = items[blockIdx.x];
-  const int I = item & 0xfff, J = (item >> 12) & 0xfff;
-  const bool diag = I == J;
-  const bool both = J < nhb;  // heavy x heavy
-  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
-    double gap2 = 0.0;
-    for (int d = 0; d < 3; d++) {
-      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
-      gap2 += g * g;
-    }
-    if (gap2 >= kI4MaxA * kI4MaxA) return;
-  }
-  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
-  // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
-  // formed here from the finished GB sums instead of a per-atom kernel in between
-  // (slot h of a heavy block is heavy atom h: its volume scaling factor comes straight from the tree's self volume)
-  auto weights = [&](int a, int slot, double q) {
-    const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
-    return make_double2(brw[a] + bru, slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0);
-  };
-  if (wave == 0) {
-    const int aj = pslot[64 * J + lane];
-    const bool vj = aj >= 0;
-    const double4 pj = aposq[vj ? aj : 0];
-    const double2 wj = vj ? weights(aj, 64 * J + lane, pj.w) : make_double2(0.0, 0.0);
-    const int2 mj = ameta[vj ? aj : 0];
-    // low word: screened type | screener type << 16 (only read in heavy x heavy tiles); high word: >= 0 for a real atom
-    const double packed = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
-    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(pj.x, pj.y);
-    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(pj.z, wj.x);
-    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, packed);
-  }
-  const int nsteps = diag ? 8 : 16;
-  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
-  const int ai = pslot[64 * I + lane];
-  const bool vi = ai >= 0;
-  const double4 pi = aposq[vi ? ai : 0];
-  const double2 wi = vi ? weights(ai, 64 * I + lane, pi.w) : make_double2(0.0, 0.0);
-  const int2 mi = ameta[vi ? ai : 0];  // {screened type, screener type}: block I is always a heavy block
-  DbornLane L;
-  L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
-  L.row = mi.x * ntj, L.tsr = mi.y;
-  L.fxi = L.fyi = L.fzi = L.wui = L.fxj = L.fyj = L.fzj = L.wuj = 0.0;
-  const int base = (lane + start) & 63;
-  const double2* __restrict__ jxy = s_rec[0] + base;
-  const double2* __restrict__ jzw = s_rec[1] + base;
-  const double2* __restrict__ jsm = s_rec[2] + base;
-  __syncthreads();
-  // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
-  if (both)
-    dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj);
-  else
-    dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj);
-  __syncthreads();  // every wave is done with the spline tables: their LDS now carries the sums of the four waves
-  TileSums& s_sums = *reinterpret_cast<TileSums*>(s_lut);
-  {
-    const double vi4[4] = {L.fxi, L.fyi, L.fzi, L.wui}, vj4[4] = {L.fxj, L.fyj, L.fzj, L.wuj};
-    tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
-  }
-  __syncthreads();
-  // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz by atom,
-  // row db_wu by heavy index (= the slot of a heavy block: only heavy atoms collect W+U, and the tree reads it so)
-  double* __restrict__ row = db_rows + (size_t)wave * n;
-  if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], tile_sums_fold(s_sums, wave, lane));
-  const int aj = pslot[64 * J + lane];
-  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], tile_sums_fold(s_sums, 4 + wave, lane));
-}
-
-// ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
-//   blocks [0, nfb)  forces: F = -grad(tree) + sum of the pair partial rows, ADDED to the caller's buffer
-//   block  nfb       energy: fixed-order sum of every energy partial, ADDED to the caller's scalar
-//   block  nfb+1     bookkeeping for the NEXT evaluation: tree statistics and the largest-first subtree order
+constexpr size_t kRoleScratchBytes = 4352;  // LDS the two roles borrow from their host kernel's dynamic area
+// ---- two single-workgroup roles that only need what the GB stage has left behind; they ride as the first two
+// workgroups of the chain-rule launch (version 1) or of the output launch (version 0), off the critical path.
+//   energy:      fixed-order sum of every energy partial, ADDED to the caller's scalar
+//   bookkeeping: tree statistics and the largest-first subtree order of the NEXT evaluation
 __device__ __forceinline__ double block_sum_256(double v, double* red4) {
   v = wave_sum(v);
   const int t = threadIdx.x;
@@ -562,68 +427,51 @@ __device__ __forceinline__ double block_sum_256(double v, double* red4) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double* __restrict__ force_out,
-                                                 double* __restrict__ energy_out, double* __restrict__ components) {
-  const int nfb = (P.n + 255) / 256;
+__device__ void energy_role(const PairArgs& P, int version, double* __restrict__ energy_out, double* __restrict__ components,
+                            char* scratch) {  // scratch: kRoleScratchBytes of LDS
   const int t = threadIdx.x;
-  if ((int)blockIdx.x < nfb) {
-    const int i = blockIdx.x * 256 + t;
-    if (i >= P.n) return;
-    double fx = 0, fy = 0, fz = 0;
-    const int h = P.a2h[i];
-    if (h >= 0) {  // cavity + pseudo-volume gradients -> force
-      fx = -P.gx[h];
-      fy = -P.gy[h];
-      fz = -P.gz[h];
-    }
-    if (version == 1) {
-      fx += P.gb_fx[i] + P.db_fx[i];
-      fy += P.gb_fy[i] + P.db_fy[i];
-      fz += P.gb_fz[i] + P.db_fz[i];
-    }
-    force_out[3 * i] += fx;
-    force_out[3 * i + 1] += fy;
-    force_out[3 * i + 2] += fz;
-    return;
-  }
-  if ((int)blockIdx.x == nfb) {
-    __shared__ double red4[4];
-    // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
-    // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
-    auto strided_sum = [&](const double* __restrict__ a, int count, int stride, int offset) {
-      double acc = 0.0;
-      for (int base = 0; base < count; base += 256 * 8) {
-        double v[8];
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const int k = base + b * 256 + t;
-          v[b] = k < count ? a[(size_t)k * stride + offset] : 0.0;
+    double* red4 = reinterpret_cast<double*>(scratch);
+      // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
+      // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
+      auto strided_sum = [&](const double* __restrict__ a, int count, int stride, int offset) {
+        double acc = 0.0;
+        for (int base = 0; base < count; base += 256 * 8) {
+          double v[8];
+  #pragma unroll
+          for (int b = 0; b < 8; b++) {
+            const int k = base + b * 256 + t;
+            v[b] = k < count ? a[(size_t)k * stride + offset] : 0.0;
+          }
+  #pragma unroll
+          for (int b = 0; b < 8; b++) acc += v[b];
         }
-#pragma unroll
-        for (int b = 0; b < 8; b++) acc += v[b];
+        return acc;
+      };
+      const double ecav1 = strided_sum(P.epart, P.nh, 2, 0), ecav2 = strided_sum(P.epart, P.nh, 2, 1);
+      double eatom = 0, egb = 0;
+      if (version == 1) {
+        eatom = strided_sum(P.e_atom, P.n, 1, 0);
+        egb = strided_sum(P.egb_part, P.egb_parts, 1, 0);
       }
-      return acc;
-    };
-    const double ecav1 = strided_sum(P.epart, P.nh, 2, 0), ecav2 = strided_sum(P.epart, P.nh, 2, 1);
-    double eatom = 0, egb = 0;
-    if (version == 1) {
-      eatom = strided_sum(P.e_atom, P.n, 1, 0);
-      egb = strided_sum(P.egb_part, P.egb_parts, 1, 0);
-    }
-    const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
-    const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
-    if (t == 0) {
-      components[0] = o0;
-      components[1] = o1;
-      components[2] = o2;
-      components[3] = o3;
-      energy_out[0] += o0 + o1 + o2 + o3;
-    }
-    return;
-  }
-  // ---- bookkeeping block
+      const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
+      const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
+      if (t == 0) {
+        components[0] = o0;
+        components[1] = o1;
+        components[2] = o2;
+        components[3] = o3;
+        energy_out[0] += o0 + o1 + o2 + o3;
+      }
+}
+
+__device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
+  const int t = threadIdx.x;
   constexpr int kBins = 512, kBatch = 8;
-  __shared__ int hist[kBins], start[kBins], part[4], imax[8];
+  int* hist = reinterpret_cast<int*>(scratch);
+  int* start = hist + kBins;
+  int* part = start + kBins;
+  int* imax = part + 4;
+  static_assert(sizeof(int) * (2 * kBins + 12) <= kRoleScratchBytes, "role scratch");
   for (int k = t; k < kBins; k += 256) hist[k] = 0;
   __syncthreads();
   int tot = 0, mx = 0, ma = 0;
@@ -697,6 +545,182 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   }
 }
 
+// ---- Born-radius chain rule, 64x64 tiles in "pair order" with range culling ------------------------------
+// Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
+//   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
+// Only heavy atoms descreen, so the atoms are walked in pair order (pslot): all heavy atoms first, then all
+// hydrogens, each group padded to whole blocks of 64.  That leaves two kinds of tiles and no per-lane type tests:
+//   heavy x heavy  symmetric tiles (I <= J), every unordered pair met once, both directions (two look-ups)
+//   heavy x H      full tiles, one direction (the heavy atom descreens the hydrogen, one look-up)
+//   H x H          nothing to do, never scheduled
+// which halves the table look-ups (the LDS pipe is what bounds this kernel).  Machinery as in k_gb_tiles:
+// block I in registers, the static record of block J from a doubled LDS copy, the sums of the j atom travel by
+// DPP rotation.  A work item whose two bounding boxes are more than the table's 2 nm reach apart exits at once.
+struct DbornLane {
+  double x, y, z, bw, s;   // the lane's own atom i
+  int row, tsr;            // screened type * ntj, screener type
+  double fxi, fyi, fzi, wui, fxj, fyj, fzj, wuj;
+};
+
+template <bool kBoth>
+__device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restrict__ s_lut, const double2* __restrict__ jxy,
+                                           const double2* __restrict__ jzw, const double2* __restrict__ jsm, int nsteps,
+                                           int masked_step, bool vi, bool lower, int ntj) {
+#pragma unroll 4
+  for (int k = 0; k < nsteps; k++) {
+    const double2 xy = jxy[k], zw = jzw[k], sm = jsm[k];
+    const double dx = xy.x - L.x, dy = xy.y - L.y, dz = zw.x - L.z;
+    const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    const int tj = __double2loint(sm.y);  // screened type | screener type << 16
+    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(sm.y) >= 0 && (k != masked_step || lower)) {
+      const double rinv = rsqrt_pos(d2);
+      const double d = d2 * rinv;
+      double q2, dq2;  // i descreens j
+      spline_value_deriv(s_lut, ((tj & 0xffff) * ntj + L.tsr) * kI4Nodes, d, q2, dq2);
+      L.wui = fma(zw.y, q2, L.wui);
+      double t = zw.y * L.s * dq2;
+      if (kBoth) {  // j descreens i
+        double q1, dq1;
+        spline_value_deriv(s_lut, (L.row + (tj >> 16)) * kI4Nodes, d, q1, dq1);
+        L.wuj = fma(L.bw, q1, L.wuj);
+        t = fma(L.bw * sm.x, dq1, t);
+      }
+      t *= rinv;
+      L.fxi = fma(dx, t, L.fxi);
+      L.fyi = fma(dy, t, L.fyi);
+      L.fzi = fma(dz, t, L.fzi);
+      L.fxj = fma(-dx, t, L.fxj);
+      L.fyj = fma(-dy, t, L.fyj);
+      L.fzj = fma(-dz, t, L.fzj);
+    }
+    L.fxj = rot1(L.fxj);
+    L.fyj = rot1(L.fyj);
+    L.fzj = rot1(L.fzj);
+    if (kBoth) L.wuj = rot1(L.wuj);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
+                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
+                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
+                                                    const double* __restrict__ born, const double* __restrict__ born_fp,
+                                                    const double* __restrict__ brw, const double* __restrict__ gb_y,
+                                                    const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
+                                                    int nh, const double2* __restrict__ lut, double* __restrict__ db_rows,
+                                                    PairArgs P, double* __restrict__ energy_out,
+                                                    double* __restrict__ components) {
+  // the first two workgroups carry the energy sum and the bookkeeping of the next evaluation (see above)
+  extern __shared__ double2 s_lut[];
+  if (blockIdx.x == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_lut));
+  if (blockIdx.x == 1) return bookkeeping_role(P, reinterpret_cast<char*>(s_lut));
+  // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
+  __shared__ double2 s_rec[3][128];
+  // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
+  // and the spline tables
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = items[blockIdx.x - 2];
+  const int I = item & 0xfff, J = (item >> 12) & 0xfff;
+  const bool diag = I == J;
+  const bool both = J < nhb;  // heavy x heavy
+  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    if (gap2 >= kI4MaxA * kI4MaxA) return;
+  }
+  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
+  // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
+  // formed here from the finished GB sums instead of a per-atom kernel in between
+  // (slot h of a heavy block is heavy atom h: its volume scaling factor comes straight from the tree's self volume)
+  auto weights = [&](int a, int slot, double q) {
+    const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
+    return make_double2(brw[a] + bru, slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0);
+  };
+  if (wave == 0) {
+    const int aj = pslot[64 * J + lane];
+    const bool vj = aj >= 0;
+    const double4 pj = aposq[vj ? aj : 0];
+    const double2 wj = vj ? weights(aj, 64 * J + lane, pj.w) : make_double2(0.0, 0.0);
+    const int2 mj = ameta[vj ? aj : 0];
+    // low word: screened type | screener type << 16 (only read in heavy x heavy tiles); high word: >= 0 for a real atom
+    const double packed = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
+    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(pj.x, pj.y);
+    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(pj.z, wj.x);
+    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, packed);
+  }
+  const int nsteps = diag ? 8 : 16;
+  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
+  const int ai = pslot[64 * I + lane];
+  const bool vi = ai >= 0;
+  const double4 pi = aposq[vi ? ai : 0];
+  const double2 wi = vi ? weights(ai, 64 * I + lane, pi.w) : make_double2(0.0, 0.0);
+  const int2 mi = ameta[vi ? ai : 0];  // {screened type, screener type}: block I is always a heavy block
+  DbornLane L;
+  L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
+  L.row = mi.x * ntj, L.tsr = mi.y;
+  L.fxi = L.fyi = L.fzi = L.wui = L.fxj = L.fyj = L.fzj = L.wuj = 0.0;
+  const int base = (lane + start) & 63;
+  const double2* __restrict__ jxy = s_rec[0] + base;
+  const double2* __restrict__ jzw = s_rec[1] + base;
+  const double2* __restrict__ jsm = s_rec[2] + base;
+  __syncthreads();
+  // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
+  if (both)
+    dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj);
+  else
+    dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj);
+  __syncthreads();  // every wave is done with the spline tables: their LDS now carries the sums of the four waves
+  TileSums& s_sums = *reinterpret_cast<TileSums*>(s_lut);
+  {
+    const double vi4[4] = {L.fxi, L.fyi, L.fzi, L.wui}, vj4[4] = {L.fxj, L.fyj, L.fzj, L.wuj};
+    tile_sums_store(s_sums, wave, lane, (lane + start + nsteps) & 63, vi4, vj4);  // jslot: whose sums the lane holds now
+  }
+  __syncthreads();
+  // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz by atom,
+  // row db_wu by heavy index (= the slot of a heavy block: only heavy atoms collect W+U, and the tree reads it so)
+  double* __restrict__ row = db_rows + (size_t)wave * n;
+  if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], tile_sums_fold(s_sums, wave, lane));
+  const int aj = pslot[64 * J + lane];
+  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], tile_sums_fold(s_sums, 4 + wave, lane));
+}
+
+// ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
+//   blocks [0, nfb)  forces: F = -grad(tree) + sum of the pair partial rows, ADDED to the caller's buffer
+//   block  nfb       energy: fixed-order sum of every energy partial, ADDED to the caller's scalar
+//   block  nfb+1     bookkeeping for the NEXT evaluation: tree statistics and the largest-first subtree order
+
+__global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double* __restrict__ force_out,
+                                                 double* __restrict__ energy_out, double* __restrict__ components) {
+  // version 0 has no pair stages to carry the two single-workgroup roles: they are the first two workgroups here
+  extern __shared__ char s_role[];  // kRoleScratchBytes when version != 1
+  int blk = blockIdx.x;
+  if (version != 1) {
+    if (blk == 0) return energy_role(P, version, energy_out, components, s_role);
+    if (blk == 1) return bookkeeping_role(P, s_role);
+    blk -= 2;
+  }
+  const int t = threadIdx.x;
+  const int i = blk * 256 + t;
+  if (i >= P.n) return;
+  double fx = 0, fy = 0, fz = 0;
+  const int h = P.a2h[i];
+  if (h >= 0) {  // cavity + pseudo-volume gradients -> force
+    fx = -P.gx[h];
+    fy = -P.gy[h];
+    fz = -P.gz[h];
+  }
+  if (version == 1) {
+    fx += P.gb_fx[i] + P.db_fx[i];
+    fy += P.gb_fy[i] + P.db_fy[i];
+    fz += P.gb_fz[i] + P.db_fz[i];
+  }
+  force_out[3 * i] += fx;
+  force_out[3 * i + 1] += fy;
+  force_out[3 * i + 2] += fz;
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------
 #define AGBNP_CHECK_LAUNCH()             \
   do {                                   \
@@ -719,7 +743,7 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   return hipGetLastError();
 }
 
-hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
+hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl) {
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
   if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -737,10 +761,10 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
                      (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
-  if (P.db_items_count > 0)
-    hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
+  // (+ 2: the energy and bookkeeping workgroups; with no heavy atom there is no tile but the roles still run)
+  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 2), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
-                     (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx);
+                     (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }
@@ -748,7 +772,7 @@ hipError_t launch_pair_stages(const PairArgs& P, hipStream_t st, Timeline* tl) {
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl) {
   AGBNP_MARK(kKOutputs);
-  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + 2), dim3(256), 0, st, P, version, force_out, energy_out, components);
+  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), version == 1 ? 0 : kRoleScratchBytes, st, P, version, force_out, energy_out, components);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);
   return hipSuccess;
