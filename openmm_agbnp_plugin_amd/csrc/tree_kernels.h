@@ -532,7 +532,13 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
       // phase 2 (wave 0): children per node, their base slots
       if (tid < 64) {
         int c = 0;
-        if (tid < nin) c = __popcll(kept_bits(S.kmask, S.tstart[tid], S.tstart[tid + 1]));
+        if (tid < nin) {
+          // a node has up to ACAP - 2 younger siblings: 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
+          const int ts = S.tstart[tid], te = S.tstart[tid + 1];
+          c = __popcll(kept_bits(S.kmask, ts, ACAP <= 64 || te - ts <= 63 ? te : ts + 63));
+          if (ACAP > 64)
+            for (int s0 = ts + 63; s0 < te; s0 += 63) c += __popcll(kept_bits(S.kmask, s0, s0 + 63 < te ? s0 + 63 : te));
+        }
         const int cincl = wave_inclusive_scan(c);
         const int cb = tail + cincl - c;
         if (tid < nin) {
@@ -557,10 +563,14 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
           const int kk = nb + j;
           const int ts = S.tstart[j], te = S.tstart[j + 1];
           int rank = 0;
-          for (unsigned long long m = kept_bits(S.kmask, ts, te); m; m &= m - 1) {  // kept siblings only
-            const int u = ts + __builtin_ctzll(m);
-            const double vu = tvol[u];
-            rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
+          for (int s0 = ts; s0 < te; s0 += 63) {  // 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
+            const int s1 = (ACAP <= 64 || s0 + 63 >= te) ? te : s0 + 63;
+            for (unsigned long long m = kept_bits(S.kmask, s0, s1); m; m &= m - 1) {  // kept siblings only
+              const int u = s0 + __builtin_ctzll(m);
+              const double vu = tvol[u];
+              rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
+            }
+            if (ACAP <= 64) break;
           }
           const int cb = S.cbase[j];
           const int slot = cb + rank;

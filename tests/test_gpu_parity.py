@@ -346,6 +346,50 @@ def test_random_clusters(gpu_required, seed):
         assert_close(e, f, eo, fo, tol=1e-6)
 
 
+def _lattice_cluster(n, spacing, seed, radii, hydrogen_fraction=0.3):
+    rng = np.random.default_rng(seed)
+    grid = np.stack(np.meshgrid(*[np.arange(6)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    pos = grid * spacing + rng.normal(0, 0.02, (n, 3))
+    ish = (rng.random(n) < hydrogen_fraction).astype(np.int32)
+    radius = np.where(ish == 1, 0.121, rng.choice(radii, n))
+    gamma = np.where(ish == 1, 0.0, 0.117 * 418.4)
+    from openmm_agbnp_plugin_amd.systems import vdw_alpha_from_radius
+    return P.AGBNPSystem(f"cluster{spacing}_{seed}", pos, radius, gamma, vdw_alpha_from_radius(radius), rng.normal(0, 0.4, n), ish)
+
+
+@pytest.mark.parametrize("n,spacing,seed,variant,min_local_atoms", [
+    (150, 0.24, 1, 1, 0),    # largest subtree 751 nodes  -> (1024, 128) LDS variant
+    (150, 0.22, 1, 2, 0),    # 1878 nodes                 -> (2048, 256) LDS variant
+    (180, 0.18, 2, 3, 65),   # 19425 nodes and a subtree with 68 local atoms (a node with more than 63 younger
+                             # siblings: the survivor masks of the expansion span several words) -> HBM-scratch variant
+])
+def test_every_capacity_variant_is_exact(gpu_required, n, spacing, seed, variant, min_local_atoms):
+    """Denser-than-protein clusters land on the larger tree variants; each must give the oracle's numbers, not
+    just be a stepping stone of the capacity negotiation."""
+    sysm = _lattice_cluster(n, spacing, seed, [0.17, 0.18, 0.19, 0.2])
+    e, f, ctx = gpu_eval(sysm, 1)
+    eo, fo = Oracle(*sysm.params(), version=1).execute(sysm.pos)
+    assert_close(e, f, eo, fo)
+    assert int(ctx.kernel.scalar("variant")) == variant
+    assert int(ctx.kernel.scalar("max_local_atoms")) >= min_local_atoms
+    # same tree as the reference: heavy level-1 nodes + everything below (the oracle's level 1 also lists hydrogens)
+    o = Oracle(*sysm.params(), version=0)
+    o.execute(sysm.pos)
+    nheavy = int(np.sum(sysm.ishydrogen == 0))
+    assert int(ctx.kernel.scalar("total_nodes")) == nheavy + sum(o.tree_stats()["level_counts"][2:])
+
+
+def test_many_radius_types_spill_the_default_lds_allowance(gpu_required):
+    """15 distinct heavy radii + the hydrogen radius: 16 x 15 type pairs x 16 knots x 16 B = 61 KB of spline tables,
+    beyond the default dynamic-LDS allowance of a workgroup (the launchers must raise it) but inside the budget."""
+    radii = list(np.round(np.linspace(0.150, 0.206, 15), 4))
+    sysm = _lattice_cluster(200, 0.27, 5, radii, hydrogen_fraction=0.4)
+    assert len(set(np.round(sysm.radius, 4))) == 16
+    e, f, ctx = gpu_eval(sysm, 1)
+    eo, fo = Oracle(*sysm.params(), version=1).execute(sysm.pos)
+    assert_close(e, f, eo, fo)
+
+
 def test_absurd_density_is_a_clean_capacity_error(gpu_required):
     """Atoms packed far beyond any physical density make the overlap tree explode (> 32768 nodes under one
     atom): the engine must climb through its variants and then fail with a message, not crash or hang."""
