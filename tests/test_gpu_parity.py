@@ -155,6 +155,37 @@ def test_device_resident_entry_point(gpu_required, systems):
     assert np.abs((frc.cpu().numpy() - 1.5) / 3 - fo).max() < TIGHT
 
 
+def test_evaluation_is_graph_capturable(gpu_required, systems):
+    """One evaluation = seven kernel launches on the caller's stream, no host synchronisation, no allocation after
+    the first call: it can be captured into a HIP graph and replayed on new positions (MD inner loops)."""
+    torch = pytest.importorskip("torch")
+    s = systems("trpcage")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(s.pos, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # warm-up outside the capture: scratch allocation, capacity negotiation
+        k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), side.cuda_stream)
+        assert k.finish(side.cuda_stream) is False
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        frc.zero_()
+        ene.zero_()
+        k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    oracle = Oracle(*s.params(), version=1)
+    for step in range(3):
+        geometry = s.jittered(step)
+        pos.copy_(torch.tensor(geometry, dtype=torch.float64))
+        graph.replay()
+        torch.cuda.synchronize()
+        eo, fo = oracle.execute(geometry)
+        assert abs(ene.item() - eo) < TIGHT
+        assert np.abs(frc.cpu().numpy() - fo).max() < TIGHT
+
+
 def test_update_parameters_in_context(gpu_required, systems):
     s = systems("trpcage")
     force = P.AGBNPForce.from_arrays(*s.params(), version=1)
