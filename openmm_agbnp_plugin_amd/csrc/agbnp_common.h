@@ -26,14 +26,14 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kToKjMol = 4.184 * 332.0 / 10.0;
 constexpr double kDielFactor = kToKjMol * (-0.5) * (1. / 1.0 - 1. / 80.0);
 
-// Header of the stored overlap-tree topology of one work slot (written by the build kernel, consumed by the
-// pseudo-volume pass, which walks the same slots in the same order: one load tells it everything).
+// Header of the stored overlap-tree topology of one work slot = one forest of up to 8 subtrees (written by the build
+// kernel, consumed by the pseudo-volume pass, which walks the same slots: one load tells it everything).
 struct SubtreeHeader {
-  int nnodes;      // nodes in the subtree including the level-1 root (0: not built)
-  int natoms;      // local atoms (root + its level-2 partners)
-  int root;        // heavy index of the subtree's root atom
-  int npairs;      // (atom, node) membership pairs stored for the replay
-  int lvl[10];     // lvl[L] = first node of level L (L = 1..8), lvl[9] = nnodes sentinel; lvl[0] unused
+  int nnodes;       // nodes of the forest including the level-1 roots (0: not built)
+  int natoms;       // local atoms (roots first, then the level-2 partners of root 0, of root 1, ...)
+  int nroots;       // subtrees in the forest
+  int npairs;       // (atom, node) membership pairs stored for the replay
+  int partners[8];  // level-2 partners of every root
 };
 
 // status/overflow word indices (device int array)
@@ -46,6 +46,8 @@ enum StatusWord {
   kStatPoolUsed = 5,       // nodes allocated from the pool
   kStatAtomPoolUsed = 6,   // ints allocated from the atom pool
   kStatTotalNodes = 7,     // total nodes (all subtrees)
+  kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
+  kStatForests = 9,        // forests of the evaluation (diagnostic)
   kStatWords = 16
 };
 

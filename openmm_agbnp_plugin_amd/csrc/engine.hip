@@ -81,7 +81,7 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_gb_items, d_db_items, d_pslot;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
   DevBuf<int2> d_ameta;
   DevBuf<double2> d_lut;
@@ -105,6 +105,7 @@ struct agbnp_hip_context {
   double kernel_ms[kKernelCount] = {0};
   long kernel_launches[kKernelCount] = {0};
   int last_status[kStatWords] = {0};
+  int tree_slots[4] = {1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   double last_components[4] = {0, 0, 0, 0};
   bool have_results = false;
   bool diagnostics = false;
@@ -281,6 +282,20 @@ void wire_args(agbnp_hip_context* c) {
   T.sizes = c->d_sizes.p;
   P.order = c->d_order.p;
   T.order = c->d_order.p;
+  {
+    const size_t nhp1 = std::max(c->nh, 1);
+    P.forest_start = c->d_forest.p;
+    P.nforests = c->d_forest.p + nhp1 + 1;
+    P.cur_nforests = c->d_forest.p + nhp1 + 2;
+    P.pack_state = c->d_forest.p + nhp1 + 3;
+    P.tree_node_cap = tree_variant_node_cap(c->variant);
+    P.tree_atom_cap = tree_variant_atom_cap(c->variant);
+    static const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
+    P.pack_enabled = no_pack ? 0 : 1;
+    T.forest_start = c->d_forest.p;
+    T.nforests = c->d_forest.p + nhp1 + 1;
+    T.cur_nforests = c->d_forest.p + nhp1 + 2;
+  }
   T.status = c->d_status.p;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
@@ -353,6 +368,15 @@ int allocate_work(agbnp_hip_context* c) {
     std::vector<int> ident(nhp);
     for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
     HIP_TRY(c, c->d_order.upload(ident));
+    // packing of the first evaluation: one subtree per work slot (nothing is known about the tree yet)
+    // layout: [0, nh] forest_start, [nh+1] number of forests, [nh+2] the count the running evaluation took
+    // [nh+3] how often a packed forest has overflowed so far
+    std::vector<int> forest(nhp + 4);
+    for (size_t k = 0; k <= nhp; k++) forest[k] = (int)k;
+    forest[nhp + 1] = nh;
+    forest[nhp + 2] = nh;
+    forest[nhp + 3] = 0;
+    HIP_TRY(c, c->d_forest.upload(forest));
   }
   HIP_TRY(c, c->d_hdr.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nhp));
@@ -367,6 +391,9 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   int rc = ensure_scratch(c);
   if (rc != AGBNP_HIP_OK) return rc;
   c->P.pos = d_pos;
+  c->P.tree_node_cap = tree_variant_node_cap(c->variant);  // the packing of the next evaluation is sized for the variant in use
+  c->P.tree_atom_cap = tree_variant_atom_cap(c->variant);
+  c->P.tree_slots = c->tree_slots[c->variant];
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   HIP_TRY(c, launch_prep(c->P, st, tl));
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
@@ -397,6 +424,12 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
+  if (s[kStatPackOverflow] && !s[kStatNodeOverflow] && !s[kStatAtomOverflow]) {
+    // a packed forest outgrew its store: the device has already fallen back to one subtree per slot and tightened
+    // its packing thresholds; same capacity variant, run the evaluation again
+    *repeat = 1;
+    return AGBNP_HIP_OK;
+  }
   if (s[kStatNodeOverflow] || s[kStatAtomOverflow]) {
     if (c->variant >= kGlobalVariant)
       return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 255 partners per heavy atom)");
@@ -479,6 +512,15 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
     if (e__ != hipSuccess) return bail(AGBNP_HIP_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__), c); \
   } while (0)
   CREATE_TRY(hipSetDevice(device));
+  {
+    // resident tree workgroups per capacity variant: what one "round" of the forest packing is
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    c->tree_slots[0] = 4 * cus;
+    c->tree_slots[1] = 2 * cus;
+    c->tree_slots[2] = cus;
+    c->tree_slots[3] = kGlobalGrid;
+  }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
   CREATE_TRY(c->d_a2h.upload(c->a2h));
@@ -584,6 +626,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 5: *value = c->last_status[kStatTotalNodes]; break;
     case 6: *value = c->variant; break;
     case 7: *value = c->last_status[kStatMaxAtoms]; break;
+    case 8: *value = c->last_status[kStatForests]; break;
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;

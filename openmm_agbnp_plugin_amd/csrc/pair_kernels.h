@@ -36,6 +36,12 @@ struct PairArgs {
   double* epart;           // [2nh]
   const int2* sizes;       // [nh] {nodes, local atoms} per subtree, written by the tree kernel
   int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
+  int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
+  int* nforests;           // [1] work slots of the NEXT evaluation
+  const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
+  int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
+  int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
+  int tree_slots;          // tree workgroups resident on the device at once (a 'round')
   int* status;
   // ---- pair-stage intermediates
   double* born_part;       // [n] sum_j s_j Q (atomic sums of the tiles)

@@ -447,7 +447,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         }
         return acc;
       };
-      const double ecav1 = strided_sum(P.epart, P.nh, 2, 0), ecav2 = strided_sum(P.epart, P.nh, 2, 1);
+      const int nslots = P.cur_nforests[0];  // cavity energies are per work slot
+    const double ecav1 = strided_sum(P.epart, nslots, 2, 0), ecav2 = strided_sum(P.epart, nslots, 2, 1);
       double eatom = 0, egb = 0;
       if (version == 1) {
         eatom = strided_sum(P.e_atom, P.n, 1, 0);
@@ -464,15 +465,38 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
       }
 }
 
+// Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes
+// predict the next step's work): tree statistics, the subtrees sorted by weight (largest first), and their packing
+// into forests = work slots of the tree kernels.
+//   weight w = max(nodes / Tn, local atoms / Ta, 1/8) in units of 1/1024, with Tn, Ta = 90 % of the store's capacity.
+//   A subtree with w > 1/2 is a forest of its own.  The others (sorted, descending) are dealt over Fs forests in
+//   serpentine order (0, 1, .., Fs-1, Fs-1, .., 0, 0, 1, ..), which balances the forests to within one item.  Fs is the
+//   smallest count that keeps the mean fill at or below 85 % and the roots per forest at or below 8 -- raised, if need
+//   be, so that the total number of forests just fills a whole number of rounds of resident workgroups: the
+//   kernels are bound by latency per workgroup, so F workgroups of n nodes cost about ceil(F / resident) * (a + b n),
+//   and a round that is only partly filled costs as much as a full one.
+// A forest that overflows anyway (kStatPackOverflow) makes the host repeat the evaluation on the one-subtree-per-slot
+// packing written here, and every such event lowers the capacities assumed here by 15 % for good (pack_state);
+// after six of them packing stays off.
 __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   const int t = threadIdx.x;
   constexpr int kBins = 512, kBatch = 8;
-  int* hist = reinterpret_cast<int*>(scratch);
-  int* start = hist + kBins;
-  int* part = start + kBins;
-  int* imax = part + 4;
-  static_assert(sizeof(int) * (2 * kBins + 12) <= kRoleScratchBytes, "role scratch");
-  for (int k = t; k < kBins; k += 256) hist[k] = 0;
+  constexpr unsigned kUnit = 1024, kLone = 512;  // kLone is a multiple of 4: lone subtrees are whole bins
+  unsigned long long* comb = reinterpret_cast<unsigned long long*>(scratch);  // [kBins] count << 32 | weight
+  unsigned long long* part = comb + kBins;                                       // [4]
+  int* imax = reinterpret_cast<int*>(part + 4);                                  // [16]
+  static_assert(sizeof(unsigned long long) * (kBins + 4) + sizeof(int) * 16 <= kRoleScratchBytes, "role scratch");
+  for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
+  const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
+  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0);
+  const bool pack = P.pack_enabled && !overflow && level < 6;
+  float share = 0.9f;
+  for (int k = 0; k < level; k++) share *= 0.85f;
+  const float inv_tn = (float)kUnit / (share * (float)P.tree_node_cap), inv_ta = (float)kUnit / (share * (float)P.tree_atom_cap);
+  auto weight = [&](int2 sz) -> unsigned {  // 128..2047
+    const float w = fmaxf(fmaxf((float)sz.x * inv_tn, (float)sz.y * inv_ta), (float)(kUnit / 8));
+    return (unsigned)fminf(w, 2047.0f);
+  };
   __syncthreads();
   int tot = 0, mx = 0, ma = 0;
   for (int base = 0; base < P.nh; base += 256 * kBatch) {
@@ -488,8 +512,8 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
         tot += sz[b].x;
         mx = sz[b].x > mx ? sz[b].x : mx;
         ma = sz[b].y > ma ? sz[b].y : ma;
-        const int key = kBins - 1 - (sz[b].x >> 2);
-        atomicAdd(&hist[key < 0 ? 0 : key], 1);
+        const unsigned w = weight(sz[b]);
+        atomicAdd(&comb[kBins - 1 - (w >> 2)], (1ull << 32) | w);
       }
     }
   }
@@ -499,46 +523,80 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
     ma = max(ma, __shfl_xor(ma, off, 64));
   }
   if ((t & 63) == 0) {
-    part[t >> 6] = tot;
     imax[t >> 6] = mx;
     imax[4 + (t >> 6)] = ma;
+    imax[8 + (t >> 6)] = tot;
   }
   __syncthreads();
   if (t == 0) {
-    P.status[kStatTotalNodes] = part[0] + part[1] + part[2] + part[3];
+    P.status[kStatTotalNodes] = (imax[8] + imax[9]) + (imax[10] + imax[11]);
     P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
     P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
+    P.pack_state[0] = level;
   }
-  // exclusive scan of the histogram (bins are in descending size order): thread t owns bins 2t, 2t+1
-  const int h0 = hist[2 * t], h1 = hist[2 * t + 1];
-  int incl = h0 + h1;
+  // exclusive scan of the (count, weight) histogram (bins are in descending weight order): thread t owns bins 2t, 2t+1
+  const unsigned long long h0 = comb[2 * t], h1 = comb[2 * t + 1];
+  unsigned long long incl = h0 + h1;
   for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
+    const unsigned long long v = __shfl_up(incl, off, 64);
     if ((t & 63) >= off) incl += v;
   }
   __syncthreads();
   if ((t & 63) == 63) part[t >> 6] = incl;
   __syncthreads();
-  int before = 0;
+  unsigned long long before = 0ull;
   for (int w = 0; w < (t >> 6); w++) before += part[w];
-  const int excl = before + incl - (h0 + h1);
-  start[2 * t] = excl;
-  start[2 * t + 1] = excl + h0;
+  const unsigned long long excl = before + incl - (h0 + h1);
+  comb[2 * t] = excl;
+  comb[2 * t + 1] = excl + h0;
+  // the first bin of the packable subtrees (weight <= kLone): everything sorted before it is a forest of its own
+  constexpr int kFirstSmallBin = kBins - 1 - (int)(kLone >> 2);
+  if (2 * t == kFirstSmallBin || 2 * t + 1 == kFirstSmallBin) {
+    const unsigned long long e = (2 * t == kFirstSmallBin) ? excl : excl + h0;
+    imax[12] = (int)(e >> 32);                      // lone subtrees
+    imax[13] = (int)(unsigned)(e & 0xffffffffull);  // their weight
+  }
+  if (t == 255) imax[14] = (int)(unsigned)((excl + h0 + h1) & 0xffffffffull);  // total weight
   __syncthreads();
-  // largest-first processing order of the next evaluation (geometry changes little between MD steps, so this
-  // step's sizes predict the next step's work)
+  const int nlone = pack ? imax[12] : P.nh;
+  const int nsmall = P.nh - nlone;
+  int fs = 0;  // forests of the packable subtrees
+  if (nsmall > 0) {
+    const unsigned wsmall = (unsigned)imax[14] - (unsigned)imax[13];
+    const int fmin = max((int)((wsmall + 869u) / 870u), (nsmall + 7) / 8);  // mean fill <= 85 %, at most 8 roots
+    const int round = max(1, (P.tree_slots * 31) / 32);                       // a round of resident workgroups, 3 % spare
+    const int rounds = (nlone + fmin + round - 1) / round;                    // whole rounds that hold fmin
+    fs = min(nsmall, max(fmin, rounds * round - nlone));
+  }
+  const int nf = nlone + fs;
+  const int full = fs > 0 ? nsmall / fs : 0, rem = fs > 0 ? nsmall % fs : 0;  // full serpentine rounds, items of the last one
+  auto small_start = [&](int f) {  // first position (among the packable subtrees) of small forest f
+    return f * full + ((full & 1) ? max(0, f - (fs - rem)) : min(f, rem));
+  };
+  for (int f = t; f <= nf; f += 256) P.forest_start[f] = f < nlone ? f : (f < nf ? nlone + small_start(f - nlone) : P.nh);
+  if (t == 0) {
+    P.nforests[0] = nf;
+    P.status[kStatForests] = nf;
+  }
+  // sorted order; a packable subtree goes to its place inside its forest
   for (int base = 0; base < P.nh; base += 256 * kBatch) {
-    int nn[kBatch];
+    int2 sz[kBatch];
 #pragma unroll
     for (int b = 0; b < kBatch; b++) {
       const int h = base + b * 256 + t;
-      nn[b] = h < P.nh ? P.sizes[h].x : -1;
+      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
     }
 #pragma unroll
     for (int b = 0; b < kBatch; b++) {
-      if (nn[b] >= 0) {
-        const int key = kBins - 1 - (nn[b] >> 2);
-        const int pos = atomicAdd(&start[key < 0 ? 0 : key], 1);
+      if (sz[b].x >= 0) {
+        const unsigned w = weight(sz[b]);
+        const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], (1ull << 32) | w);
+        int pos = (int)(v >> 32);  // position in descending weight order
+        if (pos >= nlone) {
+          const int k = pos - nlone, r = k / fs, idx = k - r * fs;
+          const int f = (r & 1) ? fs - 1 - idx : idx;
+          pos = nlone + small_start(f) + r;
+        }
         P.order[pos] = base + b * 256 + t;
       }
     }

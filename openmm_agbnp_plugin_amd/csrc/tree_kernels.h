@@ -39,7 +39,10 @@ namespace agbnp {
 
 struct TreeArgs {
   int nh;  // heavy atoms
-  const int* order;            // [nh] subtree processing order (largest subtree of the previous evaluation first)
+  const int* order;            // [nh] subtrees sorted by the previous evaluation's node count, descending
+  const int* forest_start;     // [nh+1] work slot s builds the subtrees order[forest_start[s] .. forest_start[s+1])
+  const int* nforests;         // [1] work slots in use (rewritten for the NEXT evaluation while this one's pair stages run)
+  int* cur_nforests;           // [1] copy taken by k_tree_cavity: the count the later kernels of THIS evaluation use
   const double *hx, *hy, *hz;  // heavy-atom positions (SoA, heavy index)
   const double *a_large, *v_large, *a_vdw, *v_vdw;  // Gaussian exponent / volume per heavy atom
   const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam)
@@ -65,6 +68,12 @@ struct TreeArgs {
 };
 
 constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of the BS template parameter)
+// A workgroup builds a FOREST: up to kMaxRoots subtrees (of different heavy atoms) side by side in one store, level
+// by level.  Every phase of the expansion and of the volume passes is bound by latency, not by work, so a forest of a
+// few hundred nodes costs little more than one subtree of a hundred.
+constexpr int kMaxRoots = 8;
+constexpr int kRootWords = 4 * kMaxRoots + 8;
+enum RootWord { kRtHeavy = 0, kRtCount = kMaxRoots, kRtBase = 2 * kMaxRoots, kRtNodes = 3 * kMaxRoots, kRtNum = 4 * kMaxRoots };
 
 // ---- LDS / scratch carve-out -----------------------------------------------------------------
 template <int NCAP, int ACAP>
@@ -81,6 +90,8 @@ struct TreeStore {
   int* at_gidx;      // [ACAP]
   int* lvl;          // [12]
   int* ctl;          // [12] workgroup control words (counters, scan partials)
+  int* rt;           // [kRootWords] the roots of the forest in this store: heavy index, partner count, first partner
+                     // slot, node count (kMaxRoots each), then the number of roots
   unsigned short *nla, *npar, *ncs, *ncc;  // [NCAP]
   unsigned short *tstart, *cbase;          // [kTreeBlock + 2] per-batch task start / child base
   unsigned long long* kmask;               // [TCAP/64] per 64 tasks of a batch: which ones survive the switch
@@ -99,7 +110,7 @@ struct TreeStore {
 #endif
 
   static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 8) +
-                                   sizeof(int) * (2 * (size_t)ACAP + 24) +
+                                   sizeof(int) * (2 * (size_t)ACAP + 24 + kRootWords) +
                                    sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + 8 +
                                    sizeof(unsigned long long) * (TCAP / 64) + kStampBytes;
 
@@ -108,7 +119,7 @@ struct TreeStore {
   // variants whose gather may take several rounds keep row 4 as the exchange area of its cross-wave fold.)
   static constexpr int kReplayRows = ACAP <= 64 ? 6 : 7;
   static constexpr size_t kReplayBytes = sizeof(double) * (kReplayRows * (size_t)NCAP + 10 * (size_t)ACAP + 8) +
-                                         sizeof(int) * (size_t)ACAP + kStampBytes;
+                                         sizeof(int) * ((size_t)ACAP + kRootWords) + kStampBytes;
   static_assert(!kPairGather || sizeof(unsigned short) * PCAP <= sizeof(double) * NCAP, "pair list fits the path row");
   __device__ __forceinline__ void carve_replay(char* base) {
     double* d = reinterpret_cast<double*>(base);
@@ -128,6 +139,7 @@ struct TreeStore {
     d += 17;
 #endif
     at_gidx = reinterpret_cast<int*>(d);
+    rt = at_gidx + ACAP;
     pairs = reinterpret_cast<unsigned short*>(nd[6]);  // a replay drops the pair list over the atom paths once the node step is done
     pcnt = nullptr;
     cand_vol = nullptr;
@@ -156,6 +168,8 @@ struct TreeStore {
     ip += 12;
     ctl = ip;
     ip += 12;
+    rt = ip;
+    ip += kRootWords;
     unsigned short* sp = reinterpret_cast<unsigned short*>(ip);
     pairs = sp;
     pcnt = reinterpret_cast<int*>(cand_vol);
@@ -349,104 +363,150 @@ __device__ __forceinline__ unsigned long long kept_bits(const unsigned long long
 
 enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
 
-// ---- build the subtree of heavy atom `hi` (large radii) ---------------------------------------------
-// returns BuildResult (workgroup-uniform); on success *nnodes_out / *natoms_out are set
+// ---- build the forest of the heavy atoms roots[0..m) (large radii) -----------------------------------------
+// Node and local-atom numbering: 0..m-1 are the roots (level 1), then the level-2 nodes of root 0, of root 1, ...
+// (level-2 node k <-> local atom k), then level 3 of all trees, and so on: levels are contiguous over the whole
+// forest, sibling lists never mix trees.  returns BuildResult (workgroup-uniform); on success *nnodes_out /
+// *natoms_out are set.
 template <int NCAP, int ACAP, int BS>
-__device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, int hi, int* nnodes_out,
-                             int* natoms_out) {
+__device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, const int* __restrict__ roots, int m,
+                            int* nnodes_out, int* natoms_out) {
   constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
   AGBNP_BUILD_STAMP_BEGIN();
-  const double rx = A.hx[hi], ry = A.hy[hi], rz = A.hz[hi];
-  const double ra = A.a_large[hi], rv = A.v_large[hi], rg = A.gam[hi];
+  if (tid < m) {
+    const int hi = roots[tid];
+    const double rx = A.hx[hi], ry = A.hy[hi], rz = A.hz[hi];
+    const double ra = A.a_large[hi], rv = A.v_large[hi], rg = A.gam[hi];
+    S.at[0][tid] = rx;
+    S.at[1][tid] = ry;
+    S.at[2][tid] = rz;
+    S.at[3][tid] = ra;
+    S.at[4][tid] = rv;
+    S.at[5][tid] = rg;
+    S.at_gidx[tid] = hi;
+    S.nd[0][tid] = rx;
+    S.nd[1][tid] = ry;
+    S.nd[2][tid] = rz;
+    S.nd[3][tid] = ra;
+    S.nd[4][tid] = rv;
+    S.nd[5][tid] = rg;
+    S.nla[tid] = (unsigned short)tid;
+    S.npar[tid] = 0xFFFF;
+    S.rt[kRtHeavy + tid] = hi;
+    S.rt[kRtCount + tid] = 0;
+    S.rt[kRtNodes + tid] = 0;
+  }
   if (tid == 0) {
-    S.at[0][0] = rx;
-    S.at[1][0] = ry;
-    S.at[2][0] = rz;
-    S.at[3][0] = ra;
-    S.at[4][0] = rv;
-    S.at[5][0] = rg;
-    S.at_gidx[0] = hi;
-    S.nd[0][0] = rx;
-    S.nd[1][0] = ry;
-    S.nd[2][0] = rz;
-    S.nd[3][0] = ra;
-    S.nd[4][0] = rv;
-    S.nd[5][0] = rg;
-    S.nla[0] = 0;
-    S.npar[0] = 0xFFFF;
-    S.ncs[0] = 1;
-    S.ncc[0] = 0;
-    S.ctl[0] = 0;  // level-2 candidate counter
+    S.ctl[0] = 0;  // level-2 candidate counter of the whole forest
+    S.rt[kRtNum] = m;
   }
   __syncthreads();
 
-  // ---- level 2: all heavy atoms with a larger index whose overlap with the root survives the switch.
-  // Each wave compacts its hits (ballot + mbcnt) and reserves room with one LDS add; a hit parks its atom
-  // record in the (still unused) upper node slots so that ranking never goes back to HBM.
-  // Two candidates per lane and trip, every field requested up front: one HBM/L2 round trip per 2*BS atoms
-  // instead of three dependent ones (position -> exponent/volume -> gamma) per BS atoms.
-  auto consider = [&](int hj, bool valid, double xj, double yj, double zj, double aj, double vj, double gj) {
-    bool keep = false;
-    double sv = 0.0;
-    if (valid) {
-      const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
-      const double d2 = dx * dx + dy * dy + dz * dz;
-      if (d2 < A.rcut2) {
-        sv = dev_merge_volume(rx, ry, rz, ra, rv, xj, yj, zj, aj, vj);
-        keep = sv > kMinGvol;
-      }
-    }
-    const unsigned long long mask = __ballot(keep);
-    if (mask) {
-      int wbase = 0;
-      if ((tid & 63) == 0) wbase = atomicAdd(&S.ctl[0], __popcll(mask));
-      wbase = __builtin_amdgcn_readfirstlane(wbase);
-      if (keep) {
-        const int p = wbase + lane_prefix(mask);
-        if (p < ACAP - 1) {
-          S.cand_vol[p] = sv;
-          S.cand_idx[p] = hj;
-          const int st = NCAP - 1 - p;  // staging slot (level-2 nodes land in 1..ncand <= ACAP-1 < NCAP-ACAP)
-          S.nd[0][st] = xj;
-          S.nd[1][st] = yj;
-          S.nd[2][st] = zj;
-          S.nd[3][st] = aj;
-          S.nd[4][st] = vj;
-          S.nd[5][st] = gj;
-        }
-      }
+  // ---- level 2: for every root, all heavy atoms with a larger index whose overlap with the root survives the
+  // switch.  The candidate ranges of the roots are laid end to end and walked two per lane and trip, every field
+  // requested up front (one L2 round trip per 2*BS candidates); a hit takes a slot with an LDS counter and parks
+  // its atom record in the (still unused) upper node slots so that ranking never goes back to HBM.
+  int off[kMaxRoots + 1];  // candidate offsets of the roots in the concatenated range (registers, m <= kMaxRoots)
+  off[0] = 0;
+#pragma unroll
+  for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? A.nh - 1 - S.rt[kRtHeavy + q] : 0);
+  const int ncandidates = off[kMaxRoots];
+  auto locate = [&](int c, int& q, int& hj) {  // concatenated index -> (root, heavy atom)
+    q = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
+    int o = off[0];
+#pragma unroll
+    for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
+    hj = S.rt[kRtHeavy + q] + 1 + (c - o);
+  };
+  auto consider = [&](int q, int hj, bool valid, double xj, double yj, double zj, double aj, double vj, double gj) {
+    if (!valid) return;
+    const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
+    const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 >= A.rcut2) return;
+    const double sv = dev_merge_volume(rx, ry, rz, S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj);
+    if (!(sv > kMinGvol)) return;
+    const int p = atomicAdd(&S.ctl[0], 1);
+    atomicAdd(&S.rt[kRtCount + q], 1);
+    if (p < ACAP - m) {
+      S.cand_vol[p] = sv;
+      S.cand_idx[p] = hj | (q << 24);
+      const int st = NCAP - 1 - p;  // staging slot (roots and level-2 nodes land below ACAP <= NCAP - ACAP)
+      S.nd[0][st] = xj;
+      S.nd[1][st] = yj;
+      S.nd[2][st] = zj;
+      S.nd[3][st] = aj;
+      S.nd[4][st] = vj;
+      S.nd[5][st] = gj;
     }
   };
-  for (int base = hi + 1; base < A.nh; base += 2 * BS) {
-    const int h0 = base + tid, h1 = base + BS + tid;
-    const bool v0 = h0 < A.nh, v1 = h1 < A.nh;
-    const int c0 = v0 ? h0 : hi, c1 = v1 ? h1 : hi;
-    const double x0 = A.hx[c0], y0 = A.hy[c0], z0 = A.hz[c0], a0 = A.a_large[c0], w0 = A.v_large[c0], g0 = A.gam[c0];
-    const double x1 = A.hx[c1], y1 = A.hy[c1], z1 = A.hz[c1], a1 = A.a_large[c1], w1 = A.v_large[c1], g1 = A.gam[c1];
-    consider(h0, v0, x0, y0, z0, a0, w0, g0);
-    if (base + BS < A.nh) consider(h1, v1, x1, y1, z1, a1, w1, g1);
+  for (int base = 0; base < ncandidates; base += 2 * BS) {
+    const int c0 = base + tid, c1 = base + BS + tid;
+    const bool v0 = c0 < ncandidates, v1 = c1 < ncandidates;
+    int q0, h0, q1, h1;
+    locate(v0 ? c0 : 0, q0, h0);
+    locate(v1 ? c1 : 0, q1, h1);
+    if (!v0) h0 = S.rt[kRtHeavy];  // any valid address
+    if (!v1) h1 = S.rt[kRtHeavy];
+    const double x0 = A.hx[h0], y0 = A.hy[h0], z0 = A.hz[h0], a0 = A.a_large[h0], w0 = A.v_large[h0], g0 = A.gam[h0];
+    const double x1 = A.hx[h1], y1 = A.hy[h1], z1 = A.hz[h1], a1 = A.a_large[h1], w1 = A.v_large[h1], g1 = A.gam[h1];
+    consider(q0, h0, v0, x0, y0, z0, a0, w0, g0);
+    consider(q1, h1, v1, x1, y1, z1, a1, w1, g1);
   }
   __syncthreads();
   AGBNP_BUILD_STAMP(8);
   const int ncand = S.ctl[0];
-  if (ncand > ACAP - 1) return kBuildAtomOverflow;
-  if (1 + ncand > NCAP) return kBuildNodeOverflow;
-  // rank by switched volume (descending; exact ties by atom index) and create local atoms + level-2 nodes
+  if (m + ncand > ACAP) return kBuildAtomOverflow;
+  if (m + ncand > NCAP) return kBuildNodeOverflow;
+  // first partner slot of every root (all lanes compute it: m <= kMaxRoots LDS reads)
+  int cntq[kMaxRoots], baseq[kMaxRoots];
+  {
+    int run = m;
+#pragma unroll
+    for (int q = 0; q < kMaxRoots; q++) {
+      cntq[q] = q < m ? S.rt[kRtCount + q] : 0;
+      baseq[q] = run;
+      run += cntq[q];
+    }
+  }
+  if (tid < m) {
+    int bq = 0, cq = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxRoots; q++) {
+      bq = (q == tid) ? baseq[q] : bq;
+      cq = (q == tid) ? cntq[q] : cq;
+    }
+    S.rt[kRtBase + tid] = bq;
+    S.ncs[tid] = (unsigned short)bq;  // first child
+    S.ncc[tid] = (unsigned short)cq;
+  }
+  // rank inside the root's candidates by switched volume (descending; exact ties by atom index) and create local
+  // atoms + level-2 nodes
   for (int c = tid; c < ncand; c += BS) {
     const double my = S.cand_vol[c];
-    const int hj = S.cand_idx[c];
+    const int packed = S.cand_idx[c];
+    const int q = packed >> 24, hj = packed & 0xffffff;
     // four independent LDS reads per trip: the loop is bound by LDS latency, not by the compares
     int rank = 0;
     int k = 0;
-    auto before = [&](double vk, int kk) {  // exact tie (incl. kk == c: never counted): order by atom index
-      return (vk > my || (vk == my && S.cand_idx[kk] < hj)) ? 1 : 0;
+    auto before = [&](double vk, int ik) {  // same root, larger volume; exact tie (incl. itself: never counted): atom index
+      return ((ik >> 24) == q && (vk > my || (vk == my && (ik & 0xffffff) < hj))) ? 1 : 0;
     };
     for (; k + 4 <= ncand; k += 4) {
       const double v0 = S.cand_vol[k], v1 = S.cand_vol[k + 1], v2 = S.cand_vol[k + 2], v3 = S.cand_vol[k + 3];
-      rank += (before(v0, k) + before(v1, k + 1)) + (before(v2, k + 2) + before(v3, k + 3));
+      const int i0 = S.cand_idx[k], i1 = S.cand_idx[k + 1], i2 = S.cand_idx[k + 2], i3 = S.cand_idx[k + 3];
+      rank += (before(v0, i0) + before(v1, i1)) + (before(v2, i2) + before(v3, i3));
     }
-    for (; k < ncand; k++) rank += before(S.cand_vol[k], k);
-    const int slot = 1 + rank;  // level-2 node k <-> local atom k
+    for (; k < ncand; k++) rank += before(S.cand_vol[k], S.cand_idx[k]);
+    int bq = 0, cq = 0;
+#pragma unroll
+    for (int r = 0; r < kMaxRoots; r++) {
+      bq = (r == q) ? baseq[r] : bq;
+      cq = (r == q) ? cntq[r] : cq;
+    }
+    const int slot = bq + rank;  // level-2 node k <-> local atom k
     const int st = NCAP - 1 - c;
     const double x2 = S.nd[0][st], y2 = S.nd[1][st], z2 = S.nd[2][st], a2 = S.nd[3][st], v2 = S.nd[4][st], g2 = S.nd[5][st];
     S.at[0][slot] = x2;
@@ -456,24 +516,23 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
     S.at[4][slot] = v2;
     S.at[5][slot] = g2;
     S.at_gidx[slot] = hj;
-    Merged m;
-    dev_merge(rx, ry, rz, ra, rv, x2, y2, z2, a2, v2, m);
-    S.nd[0][slot] = m.x;
-    S.nd[1][slot] = m.y;
-    S.nd[2][slot] = m.z;
-    S.nd[3][slot] = m.a;
-    S.nd[4][slot] = m.v;
-    S.nd[5][slot] = rg + g2;
+    Merged mg;
+    dev_merge(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], x2, y2, z2, a2, v2, mg);
+    S.nd[0][slot] = mg.x;
+    S.nd[1][slot] = mg.y;
+    S.nd[2][slot] = mg.z;
+    S.nd[3][slot] = mg.a;
+    S.nd[4][slot] = mg.v;
+    S.nd[5][slot] = S.at[5][q] + g2;
     S.nla[slot] = (unsigned short)slot;
-    S.npar[slot] = 0;
-    S.ncs[slot] = (unsigned short)(1 + ncand);  // until the node is expanded: end of its sibling list
+    S.npar[slot] = (unsigned short)q;
+    S.ncs[slot] = (unsigned short)(bq + cq);  // until the node is expanded: end of its sibling list
     S.ncc[slot] = 0;
   }
   if (tid == 0) {
-    S.ncc[0] = (unsigned short)ncand;
     S.lvl[1] = 0;
-    S.lvl[2] = 1;
-    S.lvl[3] = 1 + ncand;
+    S.lvl[2] = m;
+    S.lvl[3] = m + ncand;
   }
   __syncthreads();
 
@@ -481,7 +540,7 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   // ---- levels 3..8: level-synchronous expansion in batches of <= BS nodes / <= TCAP tasks
   unsigned char* tmap = reinterpret_cast<unsigned char*>(S.cand_vol);  // task -> node (index inside the batch)
   double* tvol = S.nd[6];                                                // task -> switched volume (0 = rejected)
-  int tail = 1 + ncand;
+  int tail = m + ncand;
   int L = 2;
   for (; L < kMaxOrder; L++) {
     const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
@@ -603,7 +662,7 @@ __device__ int build_subtree(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, 
   }
   __syncthreads();
   *nnodes_out = tail;
-  *natoms_out = 1 + ncand;
+  *natoms_out = m + ncand;
   return kBuildOk;
 }
 
@@ -637,8 +696,8 @@ __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
 // *npairs: length of the (atom, node) pair list; written by a FRESH_BUILD pass (which builds the list), read by the
 // others.  Returns false (workgroup-uniform) if the list does not fit: the caller reports a capacity overflow.
 template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
-__device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes, int natoms, bool with_selfvol, double* e_sum,
-                            double* w_sum, int* npairs, const uint4* pair_word = nullptr) {
+__device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int nnodes, int natoms, bool with_selfvol,
+                            double* e_sum, int* npairs, const uint4* pair_word = nullptr) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
   constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
@@ -651,28 +710,35 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
   }
   // (1+2) node-parallel: centre slots <- c_n, exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n,
   //       gamma slot <- w_n = c_n s(G_n) G_n   (c_n = +-1/level)
-  double e_part = 0.0, w_part = 0.0;
-  for (int n = 1 + tid; n < nnodes; n += BS) {
-    int level;
+  // A node's path word: bytes 0..6 = the local atoms added at levels 2..8, byte 7 = its root (local atom < m).
+  constexpr unsigned long long kPartners = 0x00ffffffffffffffull;
+  double e_part = 0.0;
+  for (int n = m + tid; n < nnodes; n += BS) {
+    int level, rootq;
     double g, gam;
     if (FRESH_BUILD) {
       unsigned long long pw = 0ull;
       level = 1;
-      for (int p = n; p != 0; p = S.npar[p]) {  // leaf to root: the deepest atom is met first
+      int p = n;
+      for (; p >= m; p = S.npar[p]) {  // leaf to root: the deepest atom is met first
         const int la = S.nla[p];
         pw = (pw << 8) | (unsigned long long)la;
         if (kPairs) atomicAdd(&S.pcnt[la], 1);
         level++;
       }
-      path[n] = pw;
+      rootq = p;
+      path[n] = pw | ((unsigned long long)rootq << 56);
+      atomicAdd(&S.rt[kRtNodes + rootq], 1);
       g = S.nd[4][n];
       gam = S.nd[5][n];
     } else {
-      double A = S.at[3][0], cx = S.at[0][0], cy = S.at[1][0], cz = S.at[2][0];
-      double pv = S.at[4][0], pa = A, E = 0.0;
-      gam = S.at[5][0];
+      const unsigned long long pwr = path[n];
+      rootq = (int)(pwr >> 56);
+      double A = S.at[3][rootq], cx = S.at[0][rootq], cy = S.at[1][rootq], cz = S.at[2][rootq];
+      double pv = S.at[4][rootq], pa = A, E = 0.0;
+      gam = S.at[5][rootq];
       level = 1;
-      for (unsigned long long pw = path[n]; pw; pw >>= 8) {
+      for (unsigned long long pw = pwr & kPartners; pw; pw >>= 8) {
         const int la = (int)(pw & 0xffull);
         const double xk = S.at[0][la], yk = S.at[1][la], zk = S.at[2][la], ak = S.at[3][la];
         const double dx = xk - cx, dy = yk - cy, dz = zk - cz;
@@ -701,25 +767,17 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
     S.nd[5][n] = w;
     e_part += gam * w;
-    w_part += w;
+    if (with_selfvol) lds_add(&S.at[9][rootq], w);  // the root is in every node of its tree
   }
   if (WITH_ENERGY) {
     e_part = wave_sum_f64(e_part);
-    w_part = wave_sum_f64(w_part);
-    if ((tid & 63) == 0) {
-      S.misc[2 * (tid >> 6)] = e_part;
-      S.misc[2 * (tid >> 6) + 1] = w_part;
-    }
+    if ((tid & 63) == 0) S.misc[tid >> 6] = e_part;
   }
   __syncthreads();
   if (WITH_ENERGY) {
-    double es = 0.0, ws = 0.0;
-    for (int w = 0; w < BS / 64; w++) {  // fixed order
-      es += S.misc[2 * w];
-      ws += S.misc[2 * w + 1];
-    }
+    double es = 0.0;
+    for (int w = 0; w < BS / 64; w++) es += S.misc[w];  // fixed order
     *e_sum = es;
-    *w_sum = ws;
   }
   AGBNP_BUILD_STAMP(7);
   if (kPairs) {
@@ -739,8 +797,8 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
       const int total = S.ctl[4];
       *npairs = total;
       if (total > PCAP) return false;
-      for (int n = 1 + tid; n < nnodes; n += BS)
-        for (unsigned long long pw = path[n]; pw; pw >>= 8) {
+      for (int n = m + tid; n < nnodes; n += BS)
+        for (unsigned long long pw = path[n] & kPartners; pw; pw >>= 8) {
           const int la = (int)(pw & 0xffull);
           S.pairs[atomicAdd(&S.pcnt[la], 1)] = (unsigned short)((la << 9) | n);
         }
@@ -795,14 +853,14 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
     const int slice = tid / A, al = tid - slice * A;
     for (int abase = 0; abase < natoms; abase += A) {
       const int a = abase + al;
-      const bool live = a >= 1 && a < natoms;  // the root atom is done by translation invariance
+      const bool live = a >= m && a < natoms;  // the root atoms are done by translation invariance
       const int aa_idx = live ? a : 0;
       const double xa = S.at[0][aa_idx], ya = S.at[1][aa_idx], za = S.at[2][aa_idx], ea = S.at[3][aa_idx];
       const unsigned long long pat = 0x0101010101010101ull * (unsigned long long)aa_idx;
       double gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
       // branch-free body: the six LDS reads of a node are independent of the membership test, so a trip costs
       // one LDS round trip instead of two (path -> test -> record)
-      for (int n = 1 + slice; n < nnodes; n += nslices) {
+      for (int n = m + slice; n < nnodes; n += nslices) {
         const unsigned long long x = path[n] ^ pat;
         const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
         const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
@@ -857,12 +915,14 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int nnodes,
   return true;
 }
 
-// ---- after the passes: the root atom's gradient = -(sum of the other local atoms' gradients) ----------------
+// ---- after the passes: a root's gradient = -(sum of its partners' gradients) (translation invariance of its tree)
 template <int NCAP, int ACAP, int BS>
-__device__ void root_gradient_from_invariance(const TreeStore<NCAP, ACAP>& S, int tid, int natoms) {
-  if (tid < 64) {
+__device__ void root_gradients_from_invariance(const TreeStore<NCAP, ACAP>& S, int tid, int m) {
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int q = wave; q < m; q += BS / 64) {  // one wave per root
+    const int b = S.rt[kRtBase + q], e = b + S.rt[kRtCount + q];
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int la = 1 + tid; la < natoms; la += 64) {
+    for (int la = b + lane; la < e; la += 64) {
       sx += S.at[6][la];
       sy += S.at[7][la];
       sz += S.at[8][la];
@@ -870,10 +930,10 @@ __device__ void root_gradient_from_invariance(const TreeStore<NCAP, ACAP>& S, in
     sx = wave_sum_f64(sx);
     sy = wave_sum_f64(sy);
     sz = wave_sum_f64(sz);
-    if (tid == 0) {
-      S.at[6][0] = -sx;
-      S.at[7][0] = -sy;
-      S.at[8][0] = -sz;
+    if (lane == 0) {
+      S.at[6][q] = -sx;
+      S.at[7][q] = -sy;
+      S.at[8][q] = -sz;
     }
   }
   __syncthreads();

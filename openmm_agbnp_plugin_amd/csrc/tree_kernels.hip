@@ -52,21 +52,23 @@ __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase;
 #define PSTAMP_FLUSH()
 #endif
 
-// Build + cavity passes of one heavy atom's subtree (reference steps A-D of
-// platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).
+// Build + cavity passes of one forest = the subtrees of up to kMaxRoots heavy atoms (reference steps A-D of
+// platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).  Work slot s holds the
+// roots order[forest_start[s] .. forest_start[s+1]); the packing comes from the previous evaluation's subtree sizes
+// (k_outputs' bookkeeping workgroup); slots beyond *nforests have nothing to do.
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
 __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
+  const int nforests = A.nforests[0];
+  if (blockIdx.x == 0 && tid == 0) A.cur_nforests[0] = nforests;
 
-#ifdef AGBNP_DIAG_SKIP  // timing experiment only: leave the largest subtrees out (results are incomplete)
-  for (int slot = blockIdx.x + AGBNP_DIAG_SKIP; slot < A.nh; slot += gridDim.x) {
-#else
-  for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
-#endif
-    const int hi = A.order[slot];  // longest-processing-time-first: big subtrees start early, small ones fill the tail
+  for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
+    const int f0 = A.forest_start[slot];
+    const int m = A.forest_start[slot + 1] - f0;  // 1..kMaxRoots roots, largest forests first
+    const int* roots = A.order + f0;
     for (int la = tid; la < ACAP; la += BS) {
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
@@ -76,56 +78,51 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     __syncthreads();
     CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
-    const int rc = build_subtree<NCAP, ACAP, BS>(S, A, tid, hi, &nnodes, &natoms);
+    int rc = build_forest<NCAP, ACAP, BS>(S, A, tid, roots, m, &nnodes, &natoms);
     CSTAMP(0);
-    if (rc != kBuildOk) {
-      if (tid == 0) {
-        atomicAdd(&A.status[rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow], 1);
-        A.hdr[slot].nnodes = 0;
-        A.hdr[slot].natoms = 0;
-        A.sizes[hi] = make_int2(0, 0);
-      }
-      __syncthreads();
-      continue;
-    }
-
-    CSTAMP(1);
-    // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
-    // The node slots still hold the Gaussians of the build, so only the atom paths are laid down before the
-    // gather.  Its gradient stays in the local accumulators and leaves together with that of pass 2.
-    double e_sum, w_sum;
+    double e_sum = 0.0;
     int npairs = 0;
     // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
     // LDS variants: one atom per lane)
-    const int hj_mine = tid < natoms ? S.at_gidx[tid] : hi;
+    const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : roots[0];
     const double a_vdw_mine = A.a_vdw[hj_mine], v_vdw_mine = A.v_vdw[hj_mine];
-    {
-      const bool want_sv1 = A.sv_large != nullptr;
-      if (!volume_pass<NCAP, ACAP, BS, true, true>(S, tid, nnodes, natoms, want_sv1, &e_sum, &w_sum, &npairs)) {
-        if (tid == 0) {  // the membership list does not fit: same protocol as a node overflow
-          atomicAdd(&A.status[kStatNodeOverflow], 1);
-          A.hdr[slot].nnodes = 0;
-          A.hdr[slot].natoms = 0;
-          A.sizes[hi] = make_int2(0, 0);
-        }
-        __syncthreads();
-        continue;
+    const bool want_sv1 = A.sv_large != nullptr;
+    // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
+    // The node slots still hold the Gaussians of the build, so only the atom paths and the membership list are
+    // laid down before the gather.  Its gradient stays in the local accumulators and leaves with that of pass 2.
+    if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs))
+      rc = kBuildNodeOverflow;  // the membership list does not fit: same protocol as a node overflow
+    if (rc != kBuildOk) {
+      if (tid == 0) {
+        // a forest that does not fit is a packing misprediction (repeat unpacked); a single subtree that does not fit
+        // needs the next capacity variant
+        atomicAdd(&A.status[m > 1 ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
+        A.hdr[slot].nnodes = 0;
+        A.hdr[slot].natoms = 0;
       }
-      // level-1 node: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
-      if (tid == 0) A.epart[2 * hi] = e_sum + S.at[5][0] * S.at[4][0];
-      if (want_sv1) {  // diagnostics: enlarged-radius self volumes
-        for (int la = tid; la < natoms; la += BS) {
-          glb_add(&A.sv_large[S.at_gidx[la]], la == 0 ? w_sum + S.at[4][0] : S.at[9][la]);
-          S.at[9][la] = 0.0;
-        }
+      if (tid < m) A.sizes[roots[tid]] = make_int2(0, 0);
+      __syncthreads();
+      continue;
+    }
+    CSTAMP(1);
+    if (tid == 0) {
+      // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
+      double e1 = e_sum;
+      for (int q = 0; q < m; q++) e1 += S.at[5][q] * S.at[4][q];
+      A.epart[2 * slot] = e1;
+    }
+    if (want_sv1) {  // diagnostics: enlarged-radius self volumes
+      for (int la = tid; la < natoms; la += BS) {
+        glb_add(&A.sv_large[S.at_gidx[la]], la < m ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+        S.at[9][la] = 0.0;
       }
     }
-    // ---- topology out for the pseudo-volume pass: the atom paths (8 B/node) and the local atom list are all a
-    // replay needs; fixed stride per subtree, no allocation traffic
+    // ---- topology out for the pseudo-volume pass: the atom paths (8 B/node), the membership list and the local
+    // atom list are all a replay needs; fixed stride per work slot, no allocation traffic
     {
       const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
       const unsigned long long* path = reinterpret_cast<const unsigned long long*>(S.nd[6]);
-      for (int n = 1 + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
+      for (int n = m + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
       for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
       if (TreeStore<NCAP, ACAP>::kPairGather) {
         const size_t pair_off = (size_t)slot * TreeStore<NCAP, ACAP>::PCAP;
@@ -135,13 +132,13 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         SubtreeHeader h;
         h.nnodes = nnodes;
         h.natoms = natoms;
-        h.root = hi;
+        h.nroots = m;
         h.npairs = npairs;
-        h.lvl[0] = 0;
-        for (int L = 1; L <= 9; L++) h.lvl[L] = S.lvl[L];
+        for (int q = 0; q < kMaxRoots; q++) h.partners[q] = q < m ? S.rt[kRtCount + q] : 0;
         A.hdr[slot] = h;
-        A.sizes[hi] = make_int2(nnodes, natoms);
       }
+      // per-subtree shape for the next evaluation's packing and the statistics
+      if (tid < m) A.sizes[roots[tid]] = make_int2(1 + S.rt[kRtNodes + tid], 1 + S.rt[kRtCount + tid]);
     }
     CSTAMP(2);
     // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
@@ -163,29 +160,31 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     CSTAMP(3);
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
-    volume_pass<NCAP, ACAP, BS, true>(S, tid, nnodes, natoms, true, &e_sum, &w_sum, &npairs);
+    volume_pass<NCAP, ACAP, BS, true>(S, tid, m, nnodes, natoms, true, &e_sum, &npairs);
     CSTAMP(4);
-    const double e2 = e_sum + S.at[5][0] * S.at[4][0];
-    const double sv2_root = w_sum + S.at[4][0];
-    root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
+    root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     CSTAMP(5);
 
-    // ---- flush per-atom sums
+    // ---- flush per-atom sums (a root's self volume: its own sphere + every node of its tree)
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
       glb_add(&A.gx[hj], S.at[6][la]);
       glb_add(&A.gy[hj], S.at[7][la]);
       glb_add(&A.gz[hj], S.at[8][la]);
-      glb_add(&A.sv_vdw[hj], la == 0 ? sv2_root : S.at[9][la]);
+      glb_add(&A.sv_vdw[hj], la < m ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
     }
-    if (tid == 0) A.epart[2 * hi + 1] = e2;
+    if (tid == 0) {
+      double e2 = e_sum;
+      for (int q = 0; q < m; q++) e2 += S.at[5][q] * S.at[4][q];
+      A.epart[2 * slot + 1] = e2;
+    }
     __syncthreads();
     CSTAMP(6);
     CSTAMP_FLUSH();
   }
 }
 
-// Replay of a stored subtree topology with vdW radii: reference steps K+L (ReferenceAGBNPKernels.cpp:718-747),
+// Replay of a stored forest with vdW radii: reference steps K+L (ReferenceAGBNPKernels.cpp:718-747),
 // nu_i = (W_i+U_i)/V_i formed on the fly from the chain-rule sums, gradient only.  The reference does two passes
 // (W then U); the pass is linear in nu, so one pass with the sum gives the same gradient.
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
@@ -194,11 +193,12 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   TreeStore<NCAP, ACAP> S;
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
-  for (int slot = blockIdx.x; slot < A.nh; slot += gridDim.x) {
+  const int nforests = A.cur_nforests[0];
+  for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
     PSTAMP_BEGIN();
-    // One round trip to the stored topology: the paths and the local atom list are requested together with the
-    // header (capacity-strided slots: reading past the subtree's own entries is harmless, the values are masked
-    // below), a second one to the per-atom parameters.
+    // One round trip to the stored topology: the paths, the membership list and the local atom list are requested
+    // together with the header (capacity-strided slots: reading past the forest's own entries is harmless, the
+    // values are masked below), a second one to the per-atom parameters.
     const SubtreeHeader* H = &A.hdr[slot];  // written by k_tree_cavity's workgroup of the same slot
     const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
     static_assert(GLOBAL || (NCAP <= 8 * BS && ACAP <= BS), "prefetch registers");
@@ -215,17 +215,26 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       for (int k = 0; k < (NCAP + BS - 1) / BS; k++) pw[k] = tid + k * BS < NCAP ? A.node_pool[pool_off + tid + k * BS] : 0ull;
       hj_pre = tid < ACAP ? A.atom_pool[atom_off + tid] : 0;
     }
-    const int nnodes = H->nnodes, natoms = H->natoms;
+    const int nnodes = H->nnodes, natoms = H->natoms, m = H->nroots;
     int npairs = H->npairs;
-    if (nnodes <= 1) continue;  // not built (capacity overflow: the host repeats the evaluation) or a lone atom
+    if (nnodes <= m) continue;  // not built (capacity overflow: the host repeats the evaluation) or lone atoms only
+    if (tid == 0) {
+      int run = m;
+      for (int q = 0; q < m; q++) {
+        const int c = H->partners[q];
+        S.rt[kRtCount + q] = c;
+        S.rt[kRtBase + q] = run;
+        run += c;
+      }
+    }
     {
       unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
       if (GLOBAL) {
-        for (int n = 1 + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
+        for (int n = m + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
       } else {
 #pragma unroll
         for (int k = 0; k < (NCAP + BS - 1) / BS; k++)
-          if (tid + k * BS >= 1 && tid + k * BS < nnodes) path[tid + k * BS] = pw[k];
+          if (tid + k * BS >= m && tid + k * BS < nnodes) path[tid + k * BS] = pw[k];
       }
     }
     for (int la = tid; la < natoms; la += BS) {
@@ -244,10 +253,10 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     }
     __syncthreads();
     PSTAMP(0);
-    double e_sum = 0.0, w_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, false>(S, tid, nnodes, natoms, false, &e_sum, &w_sum, &npairs, kPairs ? &pair_word : nullptr);
+    double e_sum = 0.0;
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, kPairs ? &pair_word : nullptr);
     PSTAMP(1);
-    root_gradient_from_invariance<NCAP, ACAP, BS>(S, tid, natoms);
+    root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
       glb_add(&A.gx[hj], S.at[6][la]);

@@ -31,7 +31,8 @@ mx = (C.c_ulonglong * 16)()
 lib.agbnp_debug_stamps_max(mx, 1)
 mx = np.array(list(mx), dtype=np.float64)
 tot = v[:7].sum()
-print(f"{name}: cycles per evaluation summed over {s.nheavy} workgroups (lane 0), total {tot:.3e}")
+nfor = max(int(ctx.kernel.scalar('forests')), 1)
+print(f"{name}: cycles per evaluation summed over the workgroups (lane 0), total {tot:.3e}; forests {int(ctx.kernel.scalar('forests'))}")
 for k, n in names.items():
-    print(f"  {n:34s} {v[k]:12.3e}  {100*v[k]/tot:5.1f}%   per subtree {v[k]/s.nheavy:9.0f} cyc   slowest per phase {mx[k]:9.0f}")
-print(f"slowest workgroup: total {mx[15]:.0f} cyc (mean {tot/s.nheavy:.0f}); build {mx[0]:.0f}, pass1 {mx[2]:.0f}, pass2 {mx[4]:.0f}")
+    print(f"  {n:34s} {v[k]:12.3e}  {100*v[k]/tot:5.1f}%   per subtree {v[k]/nfor:9.0f} cyc   slowest per phase {mx[k]:9.0f}")
+print(f"slowest workgroup: total {mx[15]:.0f} cyc (mean {tot/nfor:.0f}); build {mx[0]:.0f}, pass1 {mx[2]:.0f}, pass2 {mx[4]:.0f}")
