@@ -546,24 +546,63 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
     if (lb >= le) break;
     for (int nb = lb; nb < le;) {
-      // phase 0 (wave 0): up to 64 nodes, one per lane -> number of younger siblings = tasks, their prefix sum,
-      // the task -> node byte map.  A node's ncs still holds the end of its sibling list at this point.
-      if (tid < 64) {
+      // phase 0: one node per lane -> number of younger siblings = tasks, their prefix sum, the task -> node byte
+      // map.  A node's ncs still holds the end of its sibling list at this point.  Up to 64 nodes are handled by
+      // wave 0 alone; wider levels (forests, big subtrees) take all waves and one more barrier for up to BS nodes.
+      const bool wide = BS > 64 && le - nb > 64;
+      if (!wide) {
+        if (tid < 64) {
+          const int k = nb + tid;
+          const bool has = k < le;
+          const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
+          const int incl = wave_inclusive_scan(cnt);
+          const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
+          const int nin = __popcll(__ballot(inb));
+          const int T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
+          if (inb) {
+            const int excl = incl - cnt;
+            S.tstart[tid] = (unsigned short)excl;
+            for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
+          }
+          if (tid == 0) {
+            S.tstart[nin] = (unsigned short)T;
+            S.ctl[1] = nin;
+            S.ctl[2] = T;
+          }
+        }
+      } else {
+        const int wv = tid >> 6, ln = tid & 63;
         const int k = nb + tid;
         const bool has = k < le;
         const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
-        const int incl = wave_inclusive_scan(cnt);
-        const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
-        const int nin = __popcll(__ballot(inb));
-        const int T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
+        const int local = wave_inclusive_scan(cnt);
+        if (ln == 63) S.ctl[4 + wv] = local;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; w++) woff += S.ctl[4 + w];
+        const int incl = local + woff;
+        const bool inb = has && (incl <= TCAP);  // prefix property over the whole workgroup
+        const unsigned long long bm = __ballot(inb);
+        const int nw = __popcll(bm);
+        const int tw = nw > 0 ? __builtin_amdgcn_readlane(incl, nw > 0 ? nw - 1 : 0) : 0;
         if (inb) {
           const int excl = incl - cnt;
           S.tstart[tid] = (unsigned short)excl;
           for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
         }
+        if (ln == 0) {
+          S.ctl[8 + wv] = nw;
+          S.rt[kRtNum + 1 + wv] = tw;
+        }
+        __syncthreads();
         if (tid == 0) {
-          S.tstart[nin] = (unsigned short)T;
-          S.ctl[1] = nin;
+          int n = 0, T = 0;
+          for (int w = 0; w < BS / 64; w++) {
+            n += S.ctl[8 + w];
+            T = S.ctl[8 + w] > 0 ? S.rt[kRtNum + 1 + w] : T;  // the last wave that holds batch nodes knows the total
+          }
+          S.tstart[n] = (unsigned short)T;
+          S.ctl[1] = n;
           S.ctl[2] = T;
         }
       }
@@ -588,18 +627,42 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       __syncthreads();
       AGBNP_BUILD_STAMP(11);
 
-      // phase 2 (wave 0): children per node, their base slots
-      if (tid < 64) {
-        int c = 0;
-        if (tid < nin) {
-          // a node has up to ACAP - 2 younger siblings: 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
-          const int ts = S.tstart[tid], te = S.tstart[tid + 1];
-          c = __popcll(kept_bits(S.kmask, ts, ACAP <= 64 || te - ts <= 63 ? te : ts + 63));
-          if (ACAP > 64)
-            for (int s0 = ts + 63; s0 < te; s0 += 63) c += __popcll(kept_bits(S.kmask, s0, s0 + 63 < te ? s0 + 63 : te));
+      // phase 2: children per node, their base slots (wave 0, or all waves for a wide batch)
+      auto kept_children = [&](int j) {
+        // a node has up to ACAP - 2 younger siblings: 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
+        const int ts = S.tstart[j], te = S.tstart[j + 1];
+        int c = __popcll(kept_bits(S.kmask, ts, ACAP <= 64 || te - ts <= 63 ? te : ts + 63));
+        if (ACAP > 64)
+          for (int s0 = ts + 63; s0 < te; s0 += 63) c += __popcll(kept_bits(S.kmask, s0, s0 + 63 < te ? s0 + 63 : te));
+        return c;
+      };
+      if (!wide) {
+        if (tid < 64) {
+          const int c = tid < nin ? kept_children(tid) : 0;
+          const int cincl = wave_inclusive_scan(c);
+          const int cb = tail + cincl - c;
+          if (tid < nin) {
+            S.cbase[tid] = (unsigned short)cb;
+            if (c > 0) {
+              S.ncs[nb + tid] = (unsigned short)cb;  // from here on: first child
+              S.ncc[nb + tid] = (unsigned short)c;
+            }
+          }
+          if (tid == 63) S.ctl[3] = cincl;
         }
-        const int cincl = wave_inclusive_scan(c);
-        const int cb = tail + cincl - c;
+      } else {
+        const int wv = tid >> 6, ln = tid & 63;
+        const int c = tid < nin ? kept_children(tid) : 0;
+        const int local = wave_inclusive_scan(c);
+        if (ln == 63) S.ctl[4 + wv] = local;
+        __syncthreads();
+        int woff = 0, all = 0;
+        for (int w = 0; w < BS / 64; w++) {
+          const int v = S.ctl[4 + w];
+          woff += w < wv ? v : 0;
+          all += v;
+        }
+        const int cb = tail + woff + local - c;
         if (tid < nin) {
           S.cbase[tid] = (unsigned short)cb;
           if (c > 0) {
@@ -607,7 +670,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
             S.ncc[nb + tid] = (unsigned short)c;
           }
         }
-        if (tid == 63) S.ctl[3] = cincl;
+        if (tid == 0) S.ctl[3] = all;
       }
       __syncthreads();
       const int created = S.ctl[3];
