@@ -410,6 +410,35 @@ def test_every_capacity_variant_is_exact(gpu_required, n, spacing, seed, variant
     assert int(ctx.kernel.scalar("total_nodes")) == nheavy + sum(o.tree_stats()["level_counts"][2:])
 
 
+def test_forest_packing_and_its_overflow_protocol(gpu_required, systems):
+    """From the second evaluation on, the tree kernels build several subtrees per workgroup, packed from the previous
+    evaluation's subtree shapes.  Steady state must stay exact; a geometry that makes the trees grow far beyond the
+    prediction (here: the same atoms 20 % closer together) overflows the packed forests and must be repeated
+    unpacked -- silently for execute_host -- with the packing tightened afterwards."""
+    s = systems("1dwc")  # 2084 subtrees > 1024 resident workgroups: packing pays (a small system keeps one subtree per slot)
+    ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    nheavy = int(np.sum(s.ishydrogen == 0))
+    for step in range(3):  # steady state on slightly different geometries
+        pos = s.jittered(step)
+        ctx.setPositions(pos)
+        e, f = ctx.getState()
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+        if step > 0:
+            assert int(ctx.kernel.scalar("forests")) < nheavy  # packed: fewer work slots than subtrees
+    centre = s.pos.mean(axis=0)
+    squeezed = centre + 0.85 * (s.pos - centre)
+    ctx.setPositions(squeezed)
+    e, f = ctx.getState()
+    eo, fo = oracle.execute(squeezed)
+    assert_close(e, f, eo, fo, tol=1e-6)
+    ctx.setPositions(s.pos)  # and back again
+    e, f = ctx.getState()
+    eo, fo = oracle.execute(s.pos)
+    assert_close(e, f, eo, fo)
+
+
 def test_many_radius_types_spill_the_default_lds_allowance(gpu_required):
     """15 distinct heavy radii + the hydrogen radius: 16 x 15 type pairs x 16 knots x 16 B = 61 KB of spline tables,
     beyond the default dynamic-LDS allowance of a workgroup (the launchers must raise it) but inside the budget."""
