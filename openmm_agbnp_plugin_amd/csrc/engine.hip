@@ -30,8 +30,8 @@ size_t tree_variant_lds_bytes(int variant);
 size_t tree_variant_scratch_bytes(int variant);
 int tree_variant_node_cap(int variant);
 int tree_variant_atom_cap(int variant);
-hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
-hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st);
+hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
+hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
 
 using namespace agbnp;
@@ -106,6 +106,7 @@ struct agbnp_hip_context {
   long kernel_launches[kKernelCount] = {0};
   int last_status[kStatWords] = {0};
   int tree_slots[4] = {1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
+  int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
   bool have_results = false;
   bool diagnostics = false;
@@ -178,9 +179,9 @@ int upload_parameters(agbnp_hip_context* c) {
 
 int ensure_scratch(agbnp_hip_context* c) {
   // topology store: fixed stride per subtree, sized for the current variant
-  const size_t nhp = std::max(c->nh, 1);
-  const size_t need_nodes = nhp * (size_t)tree_variant_node_cap(c->variant);
-  const size_t need_atoms = nhp * (size_t)tree_variant_atom_cap(c->variant);
+  const size_t nslots = (size_t)c->slot_cap;
+  const size_t need_nodes = nslots * (size_t)tree_variant_node_cap(c->variant);
+  const size_t need_atoms = nslots * (size_t)tree_variant_atom_cap(c->variant);
   if (c->d_node_pool.count < need_nodes) {
     HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
     c->T.node_pool = c->d_node_pool.p;
@@ -283,11 +284,12 @@ void wire_args(agbnp_hip_context* c) {
   P.order = c->d_order.p;
   T.order = c->d_order.p;
   {
-    const size_t nhp1 = std::max(c->nh, 1);
+    const size_t nhp1 = (size_t)c->slot_cap;
     P.forest_start = c->d_forest.p;
     P.nforests = c->d_forest.p + nhp1 + 1;
     P.cur_nforests = c->d_forest.p + nhp1 + 2;
     P.pack_state = c->d_forest.p + nhp1 + 3;
+    P.tree_slot_cap = c->slot_cap;
     P.tree_node_cap = tree_variant_node_cap(c->variant);
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
     static const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
@@ -349,8 +351,10 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_sv_vdw.alloc(nhp));
   HIP_TRY(c, c->d_sv_large.alloc(nhp));
   HIP_TRY(c, c->d_gam.alloc(nhp));
-  HIP_TRY(c, c->d_epart.alloc(2 * nhp));
-  HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nhp));
+  c->slot_cap = std::max(2 * std::max(nh, 1), c->tree_slots[0]);
+  const size_t nslots = (size_t)c->slot_cap;
+  HIP_TRY(c, c->d_epart.alloc(2 * nslots));
+  HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nslots));
   HIP_TRY(c, c->d_aposq.alloc(n));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
@@ -365,21 +369,21 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
   {
-    std::vector<int> ident(nhp);
+    std::vector<int> ident(4 * nhp + 8, 0);  // work items: up to four per subtree
     for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
     HIP_TRY(c, c->d_order.upload(ident));
     // packing of the first evaluation: one subtree per work slot (nothing is known about the tree yet)
     // layout: [0, nh] forest_start, [nh+1] number of forests, [nh+2] the count the running evaluation took
     // [nh+3] how often a packed forest has overflowed so far
-    std::vector<int> forest(nhp + 4);
-    for (size_t k = 0; k <= nhp; k++) forest[k] = (int)k;
-    forest[nhp + 1] = nh;
-    forest[nhp + 2] = nh;
-    forest[nhp + 3] = 0;
+    std::vector<int> forest(nslots + 4);
+    for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
+    forest[nslots + 1] = nh;
+    forest[nslots + 2] = nh;
+    forest[nslots + 3] = 0;
     HIP_TRY(c, c->d_forest.upload(forest));
   }
-  HIP_TRY(c, c->d_hdr.alloc(nhp));
-  HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nhp));
+  HIP_TRY(c, c->d_hdr.alloc(nslots));
+  HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nslots));
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
@@ -397,11 +401,11 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   HIP_TRY(c, launch_prep(c->P, st, tl));
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
-  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->T, st));
+  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->slot_cap, c->T, st));
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
-    HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->T, st));
+    HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->slot_cap, c->T, st));
   }
   HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
   return AGBNP_HIP_OK;

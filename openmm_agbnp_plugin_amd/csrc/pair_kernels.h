@@ -34,14 +34,15 @@ struct PairArgs {
   double *sv_vdw, *sv_large;  // [nh]
   double* gam;             // [nh] nu of the current tree pass
   double* epart;           // [2nh]
-  const int2* sizes;       // [nh] {nodes, local atoms} per subtree, written by the tree kernel
-  int* order;              // [nh] subtree order for the NEXT evaluation (descending node count)
+  int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
+  int* order;              // [4 nh] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation, by forest
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
   int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
+  int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
   int* status;
   // ---- pair-stage intermediates
   double* born_part;       // [n] sum_j s_j Q (atomic sums of the tiles)

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P) {
     P.sv_vdw[h] = 0.0;
     P.sv_large[h] = 0.0;
     P.gam[h] = P.gam_cav[h];
+    P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
   }
 }
 
@@ -191,6 +192,240 @@ __device__ __forceinline__ double rsqrt_pos(double u) {
   return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
 
+constexpr size_t kRoleScratchBytes = 4352;  // LDS the two roles borrow from their host kernel's dynamic area
+// ---- two single-workgroup roles, off the critical path:
+//   energy:      fixed-order sum of every energy partial, ADDED to the caller's scalar; needs the GB stage's partials:
+//                first workgroup of the chain-rule launch
+//   bookkeeping: tree statistics, subtree order and forest packing of the NEXT evaluation; needs the tree's shapes
+//                only: first workgroup of the GB launch
+// (version 0 has no pair stages: both ride in the output launch)
+__device__ __forceinline__ double block_sum_256(double v, double* red4) {
+  v = wave_sum(v);
+  const int t = threadIdx.x;
+  if ((t & 63) == 0) red4[t >> 6] = v;
+  __syncthreads();
+  const double r = (red4[0] + red4[1]) + (red4[2] + red4[3]);  // fixed order -> reproducible
+  __syncthreads();
+  return r;
+}
+
+__device__ void energy_role(const PairArgs& P, int version, double* __restrict__ energy_out, double* __restrict__ components,
+                            char* scratch) {  // scratch: kRoleScratchBytes of LDS
+  const int t = threadIdx.x;
+    double* red4 = reinterpret_cast<double*>(scratch);
+      // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
+      // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
+      auto strided_sum = [&](const double* __restrict__ a, int count, int stride, int offset) {
+        double acc = 0.0;
+        for (int base = 0; base < count; base += 256 * 8) {
+          double v[8];
+  #pragma unroll
+          for (int b = 0; b < 8; b++) {
+            const int k = base + b * 256 + t;
+            v[b] = k < count ? a[(size_t)k * stride + offset] : 0.0;
+          }
+  #pragma unroll
+          for (int b = 0; b < 8; b++) acc += v[b];
+        }
+        return acc;
+      };
+      const int nslots = P.cur_nforests[0];  // cavity energies are per work slot
+    const double ecav1 = strided_sum(P.epart, nslots, 2, 0), ecav2 = strided_sum(P.epart, nslots, 2, 1);
+      double eatom = 0, egb = 0;
+      if (version == 1) {
+        eatom = strided_sum(P.e_atom, P.n, 1, 0);
+        egb = strided_sum(P.egb_part, P.egb_parts, 1, 0);
+      }
+      const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
+      const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
+      if (t == 0) {
+        components[0] = o0;
+        components[1] = o1;
+        components[2] = o2;
+        components[3] = o3;
+        energy_out[0] += o0 + o1 + o2 + o3;
+      }
+}
+
+// Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes
+// predict the next step's work): tree statistics, the subtrees sorted by weight (largest first), and their packing
+// into forests = work slots of the tree kernels.
+//   weight w = max(nodes / Tn, local atoms / Ta, 1/8) in units of 1/1024, with Tn, Ta = 90 % of the store's capacity.
+//   A subtree with w > 1/2 is a forest of its own.  The others (sorted, descending) are dealt over Fs forests in
+//   serpentine order (0, 1, .., Fs-1, Fs-1, .., 0, 0, 1, ..), which balances the forests to within one item.  Fs is the
+//   smallest count that keeps the mean fill at or below 85 % and the roots per forest at or below 8 -- raised, if need
+//   be, so that the total number of forests just fills a whole number of rounds of resident workgroups: the
+//   kernels are bound by latency per workgroup, so F workgroups of n nodes cost about ceil(F / resident) * (a + b n),
+//   and a round that is only partly filled costs as much as a full one.
+// A forest that overflows anyway (kStatPackOverflow) makes the host repeat the evaluation on the one-subtree-per-slot
+// packing written here, and every such event lowers the capacities assumed here by 15 % for good (pack_state);
+// after six of them packing stays off.
+__device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
+  const int t = threadIdx.x;
+  constexpr int kBins = 512, kBatch = 8;
+  constexpr unsigned kUnit = 1024;
+  unsigned long long* comb = reinterpret_cast<unsigned long long*>(scratch);  // [kBins] count << 32 | weight
+  unsigned long long* part = comb + kBins;                                       // [4]
+  int* imax = reinterpret_cast<int*>(part + 4);                                  // [24]
+  static_assert(sizeof(unsigned long long) * (kBins + 4) + sizeof(int) * 24 <= kRoleScratchBytes, "role scratch");
+  for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
+  const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
+  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0);
+  const bool pack = P.pack_enabled && !overflow && level < 6;
+  float share = 0.9f;
+  for (int k = 0; k < level; k++) share *= 0.85f;
+  const float inv_tn = (float)kUnit / (share * (float)P.tree_node_cap), inv_ta = (float)kUnit / (share * (float)P.tree_atom_cap);
+  // A big subtree can be shared by several work items (each expands a residue class of its level-2 nodes).  That
+  // pays when the device holds every workgroup at once with room to spare (few subtrees: the kernel lasts as long
+  // as its slowest workgroup, and idle slots are free); with more subtrees than resident workgroups the extra items
+  // crowd the forests of the others and the kernel gets slower (measured on 1dwc: 57 -> 59 us), so they stay whole.
+  const bool roomy = 2 * P.nh <= P.tree_slots;
+  const int max_parts = (pack && roomy) ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : 1;
+  const int split_nodes = 48;
+  auto parts_of = [&](int2 sz) { return min(max_parts, 1 + sz.x / split_nodes); };
+  auto weight = [&](int2 sz, int parts) -> unsigned {  // of one work item of the subtree, 128..2047
+    const int l2 = max(sz.y - 1, 0);
+    const float nodes = (float)(1 + l2) + (float)(max(sz.x - 1 - l2, 0) + parts - 1) / (float)parts;
+    const float w = fmaxf(fmaxf(nodes * inv_tn, (float)sz.y * inv_ta), (float)(kUnit / 8));
+    return (unsigned)fminf(w, 2047.0f);
+  };
+  __syncthreads();
+  int tot = 0, mx = 0, ma = 0;
+  for (int base = 0; base < P.nh; base += 256 * kBatch) {
+    int2 sz[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {  // independent loads first, then the (slow) LDS atomics
+      const int h = base + b * 256 + t;
+      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      if (sz[b].x >= 0) {
+        tot += sz[b].x;
+        mx = sz[b].x > mx ? sz[b].x : mx;
+        ma = sz[b].y > ma ? sz[b].y : ma;
+        const int parts = parts_of(sz[b]);
+        const unsigned w = weight(sz[b], parts);
+        atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    tot += __shfl_xor(tot, off, 64);
+    mx = max(mx, __shfl_xor(mx, off, 64));
+    ma = max(ma, __shfl_xor(ma, off, 64));
+  }
+  if ((t & 63) == 0) {
+    imax[t >> 6] = mx;
+    imax[4 + (t >> 6)] = ma;
+    imax[8 + (t >> 6)] = tot;
+  }
+  __syncthreads();
+  if (t == 0) {
+    P.status[kStatTotalNodes] = (imax[8] + imax[9]) + (imax[10] + imax[11]);
+    P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
+    P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
+    P.pack_state[0] = level;
+  }
+  // exclusive scan of the (count, weight) histogram (bins are in descending weight order): thread t owns bins 2t, 2t+1
+  const unsigned long long h0 = comb[2 * t], h1 = comb[2 * t + 1];
+  unsigned long long incl = h0 + h1;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
+  }
+  __syncthreads();
+  if ((t & 63) == 63) part[t >> 6] = incl;
+  __syncthreads();
+  unsigned long long before = 0ull;
+  for (int w = 0; w < (t >> 6); w++) before += part[w];
+  const unsigned long long excl = before + incl - (h0 + h1);
+  comb[2 * t] = excl;
+  comb[2 * t + 1] = excl + h0;
+  // class boundaries in the sorted order (whole bins): A = weight > 3/4 (alone), B = (1/2, 3/4] (takes one partner
+  // of weight <= 1/4 from the light end of the order, as long as there are any), the rest is dealt over Fs forests
+  auto at_bin = [&](int bin, int slot) {
+    if (2 * t == bin || 2 * t + 1 == bin) {
+      const unsigned long long e = (2 * t == bin) ? excl : excl + h0;
+      imax[slot] = (int)(e >> 32);
+      imax[slot + 1] = (int)(unsigned)(e & 0xffffffffull);
+    }
+  };
+  at_bin(kBins - 1 - 192, 12);  // items / weight above 3/4
+  at_bin(kBins - 1 - 128, 14);  // above 1/2
+  at_bin(kBins - 1 - 64, 16);   // above 1/4
+  if (t == 255) {
+    imax[18] = (int)((excl + h0 + h1) >> 32);                       // work items
+    imax[19] = (int)(unsigned)((excl + h0 + h1) & 0xffffffffull);  // total weight
+  }
+  __syncthreads();
+  const int nitems = imax[18];
+  const int na = pack ? imax[12] : nitems;      // forests of one heavy item
+  const int nab = pack ? imax[14] : nitems;     // ... plus the forests led by a class-B item
+  const int nb = nab - na;
+  const int npair = pack ? min(nb, nitems - imax[16]) : 0;  // class-B items that get a light partner
+  const int nc = nitems - nab - npair;          // items dealt over the remaining forests
+  int fs = 0;
+  if (nc > 0) {
+    const unsigned wc = (unsigned)imax[19] - (unsigned)imax[15];               // (the partners' weight is left in: safe side)
+    const int fmin = max((int)((wc + 869u) / 870u), (nc + 7) / 8);            // mean fill <= 85 %, at most 8 roots
+    const int round = max(1, (P.tree_slots * 31) / 32);                        // a round of resident workgroups, 3 % spare
+    const int rounds = (nab + fmin + round - 1) / round;                       // whole rounds that hold fmin
+    fs = min(nc, max(fmin, rounds * round - nab));
+  }
+  const int nf = nab + fs;
+  const int full = fs > 0 ? nc / fs : 0, rem = fs > 0 ? nc % fs : 0;  // full serpentine rounds, items of the last one
+  auto small_start = [&](int f) {  // first position (among the dealt items) of forest f of the last class
+    return f * full + ((full & 1) ? max(0, f - (fs - rem)) : min(f, rem));
+  };
+  auto forest_first = [&](int f) {  // first work item of forest f
+    if (f < na) return f;
+    if (f < nab) {
+      const int j = f - na;
+      return na + 2 * min(j, npair) + max(0, j - npair);
+    }
+    return f < nf ? nab + npair + small_start(f - nab) : nitems;
+  };
+  for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
+  if (t == 0) {
+    P.nforests[0] = nf;
+    P.status[kStatForests] = nf;
+  }
+  // sorted order -> place inside the forests
+  for (int base = 0; base < P.nh; base += 256 * kBatch) {
+    int2 sz[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      const int h = base + b * 256 + t;
+      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; b++) {
+      if (sz[b].x >= 0) {
+        const int parts = parts_of(sz[b]);
+        const unsigned w = weight(sz[b], parts);
+        const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+        for (int part = 0; part < parts; part++) {
+          const int pos = (int)(v >> 32) + part;  // position in descending weight order
+          int dst;
+          if (pos < na) {
+            dst = pos;
+          } else if (pos < nab) {
+            dst = forest_first(pos);  // leads its forest
+          } else if (pos >= nitems - npair) {
+            dst = forest_first(na + (nitems - 1 - pos)) + 1;  // the lightest item joins the heaviest class-B item
+          } else {
+            const int k = pos - nab, r = k / fs, idx = k - r * fs;
+            const int f = (r & 1) ? fs - 1 - idx : idx;
+            dst = nab + npair + small_start(f) + r;
+          }
+          P.order[dst] = (base + b * 256 + t) | (part << 24) | ((parts - 1) << 26);
+        }
+      }
+    }
+  }
+}
+
 // Epilogue shared by the two tile kernels: the four waves of a tile hold partial sums for the same 64 i atoms
 // (lane = atom) and, rotated, for the same 64 j atoms.  They meet in LDS and leave as ONE set of FP64 HBM
 // atomics per tile (8 rows of 64), added in a fixed order within the tile.  Float atomics execute at the memory
@@ -213,9 +448,13 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
                                                   const double* __restrict__ alpha, double* __restrict__ born,
                                                   double* __restrict__ born_fp, double* __restrict__ brw,
                                                   double* __restrict__ e_atom, double* __restrict__ gb_rows,
-                                                  double* __restrict__ egb_part) {
+                                                  double* __restrict__ egb_part, PairArgs P) {
   // one LDS area, two lives: the atom records during the walk, the sums of the four waves after it
   __shared__ __align__(16) char s_area[sizeof(TileSums)];
+  static_assert(sizeof(TileSums) >= kRoleScratchBytes, "the bookkeeping workgroup borrows the tile area");
+  // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): ~20 us of mostly
+  // serial work that hides underneath this launch, the longest of the pair stages
+  if (blockIdx.x == 0) return bookkeeping_role(P, s_area);
   static_assert(sizeof(TileSums) >= sizeof(double2) * (3 * 128 + 3 * 64), "records fit the area of the sums");
   double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over: entry m and m + 64 are atom 64 J + m
   double2* const s_zq = s_xy + 128;
@@ -225,7 +464,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   double2* const s_ibc = s_izq + 64;
   __shared__ double s_e[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = items[blockIdx.x];
+  const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
   // Born radii from the finished descreening sums (every tile recomputes them for its 128 atoms: a few dozen
@@ -316,7 +555,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int i = 64 * I + lane, j = 64 * J + lane;
   if (i < n) hbm_add(&row[i], tile_sums_fold(s_sums, wave, lane));
   if (j < n) hbm_add(&row[j], tile_sums_fold(s_sums, 4 + wave, lane));
-  if (threadIdx.x == 0) egb_part[blockIdx.x] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
+  if (threadIdx.x == 0) egb_part[blockIdx.x - 1] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
 // ---- descreening sums of the inverse Born radii, 64x64 tiles in "pair order" with range culling -------------
@@ -412,197 +651,6 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   }
 }
 
-constexpr size_t kRoleScratchBytes = 4352;  // LDS the two roles borrow from their host kernel's dynamic area
-// ---- two single-workgroup roles that only need what the GB stage has left behind; they ride as the first two
-// workgroups of the chain-rule launch (version 1) or of the output launch (version 0), off the critical path.
-//   energy:      fixed-order sum of every energy partial, ADDED to the caller's scalar
-//   bookkeeping: tree statistics and the largest-first subtree order of the NEXT evaluation
-__device__ __forceinline__ double block_sum_256(double v, double* red4) {
-  v = wave_sum(v);
-  const int t = threadIdx.x;
-  if ((t & 63) == 0) red4[t >> 6] = v;
-  __syncthreads();
-  const double r = (red4[0] + red4[1]) + (red4[2] + red4[3]);  // fixed order -> reproducible
-  __syncthreads();
-  return r;
-}
-
-__device__ void energy_role(const PairArgs& P, int version, double* __restrict__ energy_out, double* __restrict__ components,
-                            char* scratch) {  // scratch: kRoleScratchBytes of LDS
-  const int t = threadIdx.x;
-    double* red4 = reinterpret_cast<double*>(scratch);
-      // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
-      // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
-      auto strided_sum = [&](const double* __restrict__ a, int count, int stride, int offset) {
-        double acc = 0.0;
-        for (int base = 0; base < count; base += 256 * 8) {
-          double v[8];
-  #pragma unroll
-          for (int b = 0; b < 8; b++) {
-            const int k = base + b * 256 + t;
-            v[b] = k < count ? a[(size_t)k * stride + offset] : 0.0;
-          }
-  #pragma unroll
-          for (int b = 0; b < 8; b++) acc += v[b];
-        }
-        return acc;
-      };
-      const int nslots = P.cur_nforests[0];  // cavity energies are per work slot
-    const double ecav1 = strided_sum(P.epart, nslots, 2, 0), ecav2 = strided_sum(P.epart, nslots, 2, 1);
-      double eatom = 0, egb = 0;
-      if (version == 1) {
-        eatom = strided_sum(P.e_atom, P.n, 1, 0);
-        egb = strided_sum(P.egb_part, P.egb_parts, 1, 0);
-      }
-      const double o0 = block_sum_256(ecav1, red4), o1 = block_sum_256(ecav2, red4);
-      const double o2 = block_sum_256(eatom, red4), o3 = block_sum_256(egb, red4);
-      if (t == 0) {
-        components[0] = o0;
-        components[1] = o1;
-        components[2] = o2;
-        components[3] = o3;
-        energy_out[0] += o0 + o1 + o2 + o3;
-      }
-}
-
-// Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes
-// predict the next step's work): tree statistics, the subtrees sorted by weight (largest first), and their packing
-// into forests = work slots of the tree kernels.
-//   weight w = max(nodes / Tn, local atoms / Ta, 1/8) in units of 1/1024, with Tn, Ta = 90 % of the store's capacity.
-//   A subtree with w > 1/2 is a forest of its own.  The others (sorted, descending) are dealt over Fs forests in
-//   serpentine order (0, 1, .., Fs-1, Fs-1, .., 0, 0, 1, ..), which balances the forests to within one item.  Fs is the
-//   smallest count that keeps the mean fill at or below 85 % and the roots per forest at or below 8 -- raised, if need
-//   be, so that the total number of forests just fills a whole number of rounds of resident workgroups: the
-//   kernels are bound by latency per workgroup, so F workgroups of n nodes cost about ceil(F / resident) * (a + b n),
-//   and a round that is only partly filled costs as much as a full one.
-// A forest that overflows anyway (kStatPackOverflow) makes the host repeat the evaluation on the one-subtree-per-slot
-// packing written here, and every such event lowers the capacities assumed here by 15 % for good (pack_state);
-// after six of them packing stays off.
-__device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
-  const int t = threadIdx.x;
-  constexpr int kBins = 512, kBatch = 8;
-  constexpr unsigned kUnit = 1024, kLone = 512;  // kLone is a multiple of 4: lone subtrees are whole bins
-  unsigned long long* comb = reinterpret_cast<unsigned long long*>(scratch);  // [kBins] count << 32 | weight
-  unsigned long long* part = comb + kBins;                                       // [4]
-  int* imax = reinterpret_cast<int*>(part + 4);                                  // [16]
-  static_assert(sizeof(unsigned long long) * (kBins + 4) + sizeof(int) * 16 <= kRoleScratchBytes, "role scratch");
-  for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
-  const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
-  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0);
-  const bool pack = P.pack_enabled && !overflow && level < 6;
-  float share = 0.9f;
-  for (int k = 0; k < level; k++) share *= 0.85f;
-  const float inv_tn = (float)kUnit / (share * (float)P.tree_node_cap), inv_ta = (float)kUnit / (share * (float)P.tree_atom_cap);
-  auto weight = [&](int2 sz) -> unsigned {  // 128..2047
-    const float w = fmaxf(fmaxf((float)sz.x * inv_tn, (float)sz.y * inv_ta), (float)(kUnit / 8));
-    return (unsigned)fminf(w, 2047.0f);
-  };
-  __syncthreads();
-  int tot = 0, mx = 0, ma = 0;
-  for (int base = 0; base < P.nh; base += 256 * kBatch) {
-    int2 sz[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {  // independent loads first, then the (slow) LDS atomics
-      const int h = base + b * 256 + t;
-      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
-    }
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      if (sz[b].x >= 0) {
-        tot += sz[b].x;
-        mx = sz[b].x > mx ? sz[b].x : mx;
-        ma = sz[b].y > ma ? sz[b].y : ma;
-        const unsigned w = weight(sz[b]);
-        atomicAdd(&comb[kBins - 1 - (w >> 2)], (1ull << 32) | w);
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    tot += __shfl_xor(tot, off, 64);
-    mx = max(mx, __shfl_xor(mx, off, 64));
-    ma = max(ma, __shfl_xor(ma, off, 64));
-  }
-  if ((t & 63) == 0) {
-    imax[t >> 6] = mx;
-    imax[4 + (t >> 6)] = ma;
-    imax[8 + (t >> 6)] = tot;
-  }
-  __syncthreads();
-  if (t == 0) {
-    P.status[kStatTotalNodes] = (imax[8] + imax[9]) + (imax[10] + imax[11]);
-    P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
-    P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
-    P.pack_state[0] = level;
-  }
-  // exclusive scan of the (count, weight) histogram (bins are in descending weight order): thread t owns bins 2t, 2t+1
-  const unsigned long long h0 = comb[2 * t], h1 = comb[2 * t + 1];
-  unsigned long long incl = h0 + h1;
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned long long v = __shfl_up(incl, off, 64);
-    if ((t & 63) >= off) incl += v;
-  }
-  __syncthreads();
-  if ((t & 63) == 63) part[t >> 6] = incl;
-  __syncthreads();
-  unsigned long long before = 0ull;
-  for (int w = 0; w < (t >> 6); w++) before += part[w];
-  const unsigned long long excl = before + incl - (h0 + h1);
-  comb[2 * t] = excl;
-  comb[2 * t + 1] = excl + h0;
-  // the first bin of the packable subtrees (weight <= kLone): everything sorted before it is a forest of its own
-  constexpr int kFirstSmallBin = kBins - 1 - (int)(kLone >> 2);
-  if (2 * t == kFirstSmallBin || 2 * t + 1 == kFirstSmallBin) {
-    const unsigned long long e = (2 * t == kFirstSmallBin) ? excl : excl + h0;
-    imax[12] = (int)(e >> 32);                      // lone subtrees
-    imax[13] = (int)(unsigned)(e & 0xffffffffull);  // their weight
-  }
-  if (t == 255) imax[14] = (int)(unsigned)((excl + h0 + h1) & 0xffffffffull);  // total weight
-  __syncthreads();
-  const int nlone = pack ? imax[12] : P.nh;
-  const int nsmall = P.nh - nlone;
-  int fs = 0;  // forests of the packable subtrees
-  if (nsmall > 0) {
-    const unsigned wsmall = (unsigned)imax[14] - (unsigned)imax[13];
-    const int fmin = max((int)((wsmall + 869u) / 870u), (nsmall + 7) / 8);  // mean fill <= 85 %, at most 8 roots
-    const int round = max(1, (P.tree_slots * 31) / 32);                       // a round of resident workgroups, 3 % spare
-    const int rounds = (nlone + fmin + round - 1) / round;                    // whole rounds that hold fmin
-    fs = min(nsmall, max(fmin, rounds * round - nlone));
-  }
-  const int nf = nlone + fs;
-  const int full = fs > 0 ? nsmall / fs : 0, rem = fs > 0 ? nsmall % fs : 0;  // full serpentine rounds, items of the last one
-  auto small_start = [&](int f) {  // first position (among the packable subtrees) of small forest f
-    return f * full + ((full & 1) ? max(0, f - (fs - rem)) : min(f, rem));
-  };
-  for (int f = t; f <= nf; f += 256) P.forest_start[f] = f < nlone ? f : (f < nf ? nlone + small_start(f - nlone) : P.nh);
-  if (t == 0) {
-    P.nforests[0] = nf;
-    P.status[kStatForests] = nf;
-  }
-  // sorted order; a packable subtree goes to its place inside its forest
-  for (int base = 0; base < P.nh; base += 256 * kBatch) {
-    int2 sz[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      const int h = base + b * 256 + t;
-      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
-    }
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      if (sz[b].x >= 0) {
-        const unsigned w = weight(sz[b]);
-        const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], (1ull << 32) | w);
-        int pos = (int)(v >> 32);  // position in descending weight order
-        if (pos >= nlone) {
-          const int k = pos - nlone, r = k / fs, idx = k - r * fs;
-          const int f = (r & 1) ? fs - 1 - idx : idx;
-          pos = nlone + small_start(f) + r;
-        }
-        P.order[pos] = base + b * 256 + t;
-      }
-    }
-  }
-}
-
 // ---- Born-radius chain rule, 64x64 tiles in "pair order" with range culling ------------------------------
 // Reference loop (ReferenceAGBNPKernels.cpp:555-586) over ordered (i, heavy j != i, d < 2 nm):
 //   W_j += brw_i Q,  U_j += bru_i Q,  F_i += D (brw_i + bru_i) s_j Q'/d,  F_j -= same      (D = r_j - r_i)
@@ -667,16 +715,15 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
                                                     int nh, const double2* __restrict__ lut, double* __restrict__ db_rows,
                                                     PairArgs P, double* __restrict__ energy_out,
                                                     double* __restrict__ components) {
-  // the first two workgroups carry the energy sum and the bookkeeping of the next evaluation (see above)
+  // the first workgroup carries the energy sum (see above)
   extern __shared__ double2 s_lut[];
   if (blockIdx.x == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_lut));
-  if (blockIdx.x == 1) return bookkeeping_role(P, reinterpret_cast<char*>(s_lut));
   // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
   __shared__ double2 s_rec[3][128];
   // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
   // and the spline tables
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = items[blockIdx.x - 2];
+  const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
   const bool both = J < nhb;  // heavy x heavy
@@ -815,12 +862,12 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
                        (const double*)P.pbox, P.pos, P.ameta, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
-  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part);
+  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
-  // (+ 2: the energy and bookkeeping workgroups; with no heavy atom there is no tile but the roles still run)
-  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 2), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
+  // (+ 1: the energy workgroup; with no heavy atom there is no tile but the role still runs)
+  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 1), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
                      (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components);
   AGBNP_CHECK_LAUNCH();

@@ -72,8 +72,22 @@ constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of 
 // by level.  Every phase of the expansion and of the volume passes is bound by latency, not by work, so a forest of a
 // few hundred nodes costs little more than one subtree of a hundred.
 constexpr int kMaxRoots = 8;
-constexpr int kRootWords = 4 * kMaxRoots + 8;
-enum RootWord { kRtHeavy = 0, kRtCount = kMaxRoots, kRtBase = 2 * kMaxRoots, kRtNodes = 3 * kMaxRoots, kRtNum = 4 * kMaxRoots };
+constexpr int kRootWords = 5 * kMaxRoots + 8;
+enum RootWord {
+  kRtHeavy = 0,              // heavy index of the root
+  kRtCount = kMaxRoots,      // level-2 partners
+  kRtBase = 2 * kMaxRoots,   // first partner slot
+  kRtNodes = 3 * kMaxRoots,  // nodes below the root that this workgroup owns
+  kRtPart = 4 * kMaxRoots,   // part | parts << 8: a big subtree is shared by `parts` work items; item `part` expands the
+                             // level-2 nodes whose rank is congruent to it (branches under different level-2 nodes are
+                             // independent) and treats the other level-2 nodes as siblings only
+  kRtNum = 5 * kMaxRoots
+};
+// work item = heavy index | part << 24 | (parts - 1) << 26
+__host__ __device__ inline int work_item_root(int e) { return e & 0xffffff; }
+__host__ __device__ inline int work_item_part(int e) { return (e >> 24) & 3; }
+__host__ __device__ inline int work_item_parts(int e) { return ((e >> 26) & 3) + 1; }
+
 
 // ---- LDS / scratch carve-out -----------------------------------------------------------------
 template <int NCAP, int ACAP>
@@ -263,6 +277,21 @@ __device__ __forceinline__ void dev_merge(double x1, double y1, double z1, doubl
 }
 
 // ---- wave / workgroup helpers -------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global store and atomic the
+// wave has in flight (vmcnt(0)); after the topology has been written out or the per-atom sums flushed nothing in
+// the workgroup depends on those, and under load they take microseconds to retire.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// The barrier of the tree kernels: their working set is in LDS for every variant but the HBM-scratch one.
+template <int NCAP>
+__device__ __forceinline__ void tree_barrier() {
+  if (NCAP > 2048)
+    __syncthreads();
+  else
+    lds_barrier();
+}
+
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
@@ -374,7 +403,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
   AGBNP_BUILD_STAMP_BEGIN();
   if (tid < m) {
-    const int hi = roots[tid];
+    const int item = roots[tid];
+    const int hi = work_item_root(item);
     const double rx = A.hx[hi], ry = A.hy[hi], rz = A.hz[hi];
     const double ra = A.a_large[hi], rv = A.v_large[hi], rg = A.gam[hi];
     S.at[0][tid] = rx;
@@ -395,12 +425,13 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.rt[kRtHeavy + tid] = hi;
     S.rt[kRtCount + tid] = 0;
     S.rt[kRtNodes + tid] = 0;
+    S.rt[kRtPart + tid] = work_item_part(item) | (work_item_parts(item) << 8);
   }
   if (tid == 0) {
     S.ctl[0] = 0;  // level-2 candidate counter of the whole forest
     S.rt[kRtNum] = m;
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
 
   // ---- level 2: for every root, all heavy atoms with a larger index whose overlap with the root survives the
   // switch.  The candidate ranges of the roots are laid end to end and walked two per lane and trip, every field
@@ -455,7 +486,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     consider(q0, h0, v0, x0, y0, z0, a0, w0, g0);
     consider(q1, h1, v1, x1, y1, z1, a1, w1, g1);
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
   AGBNP_BUILD_STAMP(8);
   const int ncand = S.ctl[0];
   if (m + ncand > ACAP) return kBuildAtomOverflow;
@@ -534,7 +565,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.lvl[2] = m;
     S.lvl[3] = m + ncand;
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
 
   AGBNP_BUILD_STAMP(9);
   // ---- levels 3..8: level-synchronous expansion in batches of <= BS nodes / <= TCAP tasks
@@ -545,6 +576,12 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   for (; L < kMaxOrder; L++) {
     const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
     if (lb >= le) break;
+    // a level-2 node is expanded by the work item that owns its rank (see kRtPart); deeper nodes by whoever created them
+    auto owned_level2 = [&](int k) {
+      if (L != 2) return true;
+      const int q = S.npar[k], pp = S.rt[kRtPart + q];
+      return ((k - S.rt[kRtBase + q]) % (pp >> 8)) == (pp & 0xff);
+    };
     for (int nb = lb; nb < le;) {
       // phase 0: one node per lane -> number of younger siblings = tasks, their prefix sum, the task -> node byte
       // map.  A node's ncs still holds the end of its sibling list at this point.  Up to 64 nodes are handled by
@@ -554,7 +591,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         if (tid < 64) {
           const int k = nb + tid;
           const bool has = k < le;
-          const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
+          const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
           const int incl = wave_inclusive_scan(cnt);
           const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
           const int nin = __popcll(__ballot(inb));
@@ -574,10 +611,10 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         const int wv = tid >> 6, ln = tid & 63;
         const int k = nb + tid;
         const bool has = k < le;
-        const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
+        const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
         const int local = wave_inclusive_scan(cnt);
         if (ln == 63) S.ctl[4 + wv] = local;
-        __syncthreads();
+        tree_barrier<NCAP>();
         int woff = 0;
         for (int w = 0; w < wv; w++) woff += S.ctl[4 + w];
         const int incl = local + woff;
@@ -594,7 +631,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           S.ctl[8 + wv] = nw;
           S.rt[kRtNum + 1 + wv] = tw;
         }
-        __syncthreads();
+        tree_barrier<NCAP>();
         if (tid == 0) {
           int n = 0, T = 0;
           for (int w = 0; w < BS / 64; w++) {
@@ -606,7 +643,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           S.ctl[2] = T;
         }
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       const int nin = S.ctl[1];
       const int T = S.ctl[2];
       AGBNP_BUILD_STAMP(10);
@@ -624,7 +661,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         const unsigned long long km = __ballot(kept);  // tasks t0..t0+63 of this wave trip: t0 = t - lane
         if ((tid & 63) == 0) S.kmask[t >> 6] = km;
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       AGBNP_BUILD_STAMP(11);
 
       // phase 2: children per node, their base slots (wave 0, or all waves for a wide batch)
@@ -655,7 +692,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         const int c = tid < nin ? kept_children(tid) : 0;
         const int local = wave_inclusive_scan(c);
         if (ln == 63) S.ctl[4 + wv] = local;
-        __syncthreads();
+        tree_barrier<NCAP>();
         int woff = 0, all = 0;
         for (int w = 0; w < BS / 64; w++) {
           const int v = S.ctl[4 + w];
@@ -672,7 +709,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         }
         if (tid == 0) S.ctl[3] = all;
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       const int created = S.ctl[3];
       if (tail + created > NCAP) return kBuildNodeOverflow;
       AGBNP_BUILD_STAMP(12);
@@ -712,7 +749,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           S.ncc[slot] = 0;
         }
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       AGBNP_BUILD_STAMP(13);
       tail += created;
       nb += nin;
@@ -723,7 +760,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     // lvl[L+1] already equals tail (set when level L-1 was expanded); deeper levels are empty
     for (int M = L + 2; M <= 9; M++) S.lvl[M] = tail;
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
   *nnodes_out = tail;
   *natoms_out = m + ncand;
   return kBuildOk;
@@ -745,15 +782,13 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
 //                (same atom order as the reference's path; one sqrt and one exp per node instead of one per level),
 //                so the six level barriers of a top-down rescan disappear and a replay needs nothing but the paths.
 __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
-  const double t[8] = {1.0,
-                       kPi,
-                       kPi * kPi,
-                       kPi * kPi * kPi,
-                       kPi * kPi * kPi * kPi,
-                       kPi * kPi * kPi * kPi * kPi,
-                       kPi * kPi * kPi * kPi * kPi * kPi,
-                       kPi * kPi * kPi * kPi * kPi * kPi * kPi};
-  return t[k];
+  // selects, not a table: a table lives in memory, and a vector load issued here would have to wait (vmcnt is
+  // in order) for every store and atomic of the topology write-out still in flight
+  const double p2 = kPi * kPi, p4 = p2 * p2;
+  double r = (k & 1) ? kPi : 1.0;
+  r = (k & 2) ? r * p2 : r;
+  r = (k & 4) ? r * p4 : r;
+  return r;
 }
 
 // *npairs: length of the (atom, node) pair list; written by a FRESH_BUILD pass (which builds the list), read by the
@@ -769,17 +804,33 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
   AGBNP_BUILD_STAMP_BEGIN();
   if (FRESH_BUILD && kPairs) {
     for (int la = tid; la < ACAP; la += BS) S.pcnt[la] = 0;
-    __syncthreads();
+    tree_barrier<NCAP>();
   }
   // (1+2) node-parallel: centre slots <- c_n, exponent slot <- coef_n = -2 c_n gamma_n sfp_n G_n,
   //       gamma slot <- w_n = c_n s(G_n) G_n   (c_n = +-1/level)
   // A node's path word: bytes 0..6 = the local atoms added at levels 2..8, byte 7 = its root (local atom < m).
   constexpr unsigned long long kPartners = 0x00ffffffffffffffull;
   double e_part = 0.0;
-  for (int n = m + tid; n < nnodes; n += BS) {
-    int level, rootq;
-    double g, gam;
+  for (int nbase = m; nbase < nnodes; nbase += BS) {  // whole waves stay together: per-root sums are folded wave by wave
+    const int n = nbase + tid;
+    int level = 0, rootq = -1;  // rootq < 0: no node on this lane, or an inert one
+    double g = 0.0, gam = 0.0, w = 0.0;
+    do {
+      if (n >= nnodes) break;
     if (FRESH_BUILD) {
+      {
+        // a level-2 node that another work item owns is a sibling only: empty path = inert in every pass
+        const int par = S.npar[n];
+        if (par < m) {
+          const int pp = S.rt[kRtPart + par];
+          if (((n - S.rt[kRtBase + par]) % (pp >> 8)) != (pp & 0xff)) {
+            path[n] = (unsigned long long)par << 56;
+            S.nd[3][n] = 0.0;
+            S.nd[5][n] = 0.0;
+            break;
+          }
+        }
+      }
       unsigned long long pw = 0ull;
       level = 1;
       int p = n;
@@ -791,11 +842,15 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       }
       rootq = p;
       path[n] = pw | ((unsigned long long)rootq << 56);
-      atomicAdd(&S.rt[kRtNodes + rootq], 1);
       g = S.nd[4][n];
       gam = S.nd[5][n];
     } else {
       const unsigned long long pwr = path[n];
+      if ((pwr & kPartners) == 0ull) {  // inert (a level-2 node owned by another work item)
+        S.nd[3][n] = 0.0;
+        S.nd[5][n] = 0.0;
+        break;
+      }
       rootq = (int)(pwr >> 56);
       double A = S.at[3][rootq], cx = S.at[0][rootq], cy = S.at[1][rootq], cz = S.at[2][rootq];
       double pv = S.at[4][rootq], pa = A, E = 0.0;
@@ -826,17 +881,32 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
     const double cp = ((level & 1) ? 1.0 : -1.0) / (double)level;
     double sp;
     const double sw = dev_switch(g, sp);
-    const double w = cp * sw * g;
+    w = cp * sw * g;
     S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
     S.nd[5][n] = w;
     e_part += gam * w;
-    if (with_selfvol) lds_add(&S.at[9][rootq], w);  // the root is in every node of its tree
+    } while (false);
+    // The root is in every node of its tree: its self volume is the tree's sum of w (and its node count the count).
+    // The lanes of a wave mostly share one root (levels are contiguous runs per tree): fold per root inside the wave
+    // and add once -- same-address LDS atomics from all lanes serialize.
+    if (with_selfvol || FRESH_BUILD) {
+      for (unsigned long long todo = __ballot(rootq >= 0); todo;) {
+        const int q = __builtin_amdgcn_readlane(rootq, __builtin_ctzll(todo));
+        const unsigned long long mine = __ballot(rootq == q);
+        if (with_selfvol) {
+          const double sq = wave_sum_f64(rootq == q ? w : 0.0);
+          if ((tid & 63) == 0) lds_add(&S.at[9][q], sq);
+        }
+        if (FRESH_BUILD && (tid & 63) == 0) atomicAdd(&S.rt[kRtNodes + q], (int)__popcll(mine));
+        todo &= ~mine;
+      }
+    }
   }
   if (WITH_ENERGY) {
     e_part = wave_sum_f64(e_part);
     if ((tid & 63) == 0) S.misc[tid >> 6] = e_part;
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
   if (WITH_ENERGY) {
     double es = 0.0;
     for (int w = 0; w < BS / 64; w++) es += S.misc[w];  // fixed order
@@ -856,7 +926,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         if (a1 < ACAP) S.pcnt[a1] = incl - c1;
         if (tid == 63) S.ctl[4] = incl;
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       const int total = S.ctl[4];
       *npairs = total;
       if (total > PCAP) return false;
@@ -865,11 +935,11 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
           const int la = (int)(pw & 0xffull);
           S.pairs[atomicAdd(&S.pcnt[la], 1)] = (unsigned short)((la << 9) | n);
         }
-      __syncthreads();
+      tree_barrier<NCAP>();
     }
     if (pair_word) {  // replay: the pair list arrives in registers and takes the place of the atom paths
       if (tid < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid] = *pair_word;
-      __syncthreads();
+      tree_barrier<NCAP>();
     }
     // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom), sums
     // the terms of a run of the same atom in registers and adds the run to the atom's accumulators with LDS FP64
@@ -904,7 +974,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       sv += wn;
     }
     if (cur >= 0) flush();
-    __syncthreads();
+    tree_barrier<NCAP>();
     AGBNP_BUILD_STAMP(14);
     return true;
   }
@@ -949,7 +1019,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       double* ex1 = kSingleRound ? S.nd[1] : S.nd[4] + BS;
       double* ex2 = kSingleRound ? S.nd[2] : S.nd[4] + 2 * BS;
       double* ex3 = kSingleRound ? S.nd[3] : S.nd[4] + 3 * BS;
-      __syncthreads();  // every wave is done reading the node records
+      tree_barrier<NCAP>();  // every wave is done reading the node records
       const int wave = tid >> 6, lane = tid & 63;
       if (lane < A) {
         ex0[wave * 64 + lane] = gx;
@@ -957,7 +1027,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         ex2[wave * 64 + lane] = gz;
         ex3[wave * 64 + lane] = sv;
       }
-      __syncthreads();
+      tree_barrier<NCAP>();
       if (tid < A && live) {  // wave 0 lanes own the atoms; fixed summation order
         double tx = 0.0, ty = 0.0, tz = 0.0, tv = 0.0;
         for (int w = 0; w < BS / 64; w++) {
@@ -973,7 +1043,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       }
     }
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
   AGBNP_BUILD_STAMP(14);
   return true;
 }
@@ -999,7 +1069,7 @@ __device__ void root_gradients_from_invariance(const TreeStore<NCAP, ACAP>& S, i
       S.at[8][q] = -sz;
     }
   }
-  __syncthreads();
+  tree_barrier<NCAP>();
 }
 
 }  // namespace agbnp

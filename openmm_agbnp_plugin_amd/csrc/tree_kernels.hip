@@ -8,6 +8,7 @@ namespace agbnp {
 #ifdef AGBNP_STAMPS
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase; [15] = slowest workgroup in total
+__device__ unsigned long long g_stamps_slowest[24];  // the slowest workgroup's own phases [0..15] + slot, roots, nodes, atoms
 // per-workgroup sums live in the store (S.stamps); flushed once at the end (no contention inside phases)
 #define STAMP_BEGIN()                                   \
   if (tid < 16) S.stamps[tid] = 0;                      \
@@ -15,7 +16,7 @@ __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase;
   unsigned long long t_prev__ = __builtin_readcyclecounter()
 #define STAMP(i)                                                   \
   do {                                                             \
-    __syncthreads();                                               \
+    lds_barrier();                                                 \
     if (tid == 0) {                                                \
       const unsigned long long t_now__ = __builtin_readcyclecounter(); \
       S.stamps[i] += t_now__ - t_prev__;                           \
@@ -27,7 +28,13 @@ __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase;
     __syncthreads();                                               \
     if (tid < 16) atomicAdd(&g_stamps[tid], S.stamps[tid]);        \
     if (tid < 16) atomicMax(&g_stamps_max[tid], S.stamps[tid]);    \
-    if (tid == 0) atomicMax(&g_stamps_max[15], S.stamps[0] + S.stamps[1] + S.stamps[2] + S.stamps[3] + S.stamps[4] + S.stamps[5] + S.stamps[6]); \
+    if (tid == 0) {                                                \
+      const unsigned long long tot__ = S.stamps[0] + S.stamps[1] + S.stamps[2] + S.stamps[3] + S.stamps[4] + S.stamps[5] + S.stamps[6]; \
+      if (tot__ > atomicMax(&g_stamps_max[15], tot__)) {          \
+        for (int i__ = 0; i__ < 16; i__++) g_stamps_slowest[i__] = S.stamps[i__]; \
+        g_stamps_slowest[16] = slot; g_stamps_slowest[17] = m; g_stamps_slowest[18] = nnodes; g_stamps_slowest[19] = natoms; \
+      }                                                            \
+    }                                                              \
     __syncthreads();                                               \
   } while (0)
 #else
@@ -62,7 +69,11 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
-  const int nforests = A.nforests[0];
+  int nforests = A.nforests[0];
+  if (!GLOBAL && nforests > (int)gridDim.x) {  // more work slots planned than launched: report it, the host repeats unpacked
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&A.status[kStatPackOverflow], 1);
+    nforests = gridDim.x;
+  }
   if (blockIdx.x == 0 && tid == 0) A.cur_nforests[0] = nforests;
 
   for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       S.at[8][la] = 0.0;
       S.at[9][la] = 0.0;
     }
-    __syncthreads();
+    tree_barrier<NCAP>();
     CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
     int rc = build_forest<NCAP, ACAP, BS>(S, A, tid, roots, m, &nnodes, &natoms);
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     int npairs = 0;
     // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
     // LDS variants: one atom per lane)
-    const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : roots[0];
+    const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : work_item_root(roots[0]);
     const double a_vdw_mine = A.a_vdw[hj_mine], v_vdw_mine = A.v_vdw[hj_mine];
     const bool want_sv1 = A.sv_large != nullptr;
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
@@ -100,20 +111,22 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         A.hdr[slot].nnodes = 0;
         A.hdr[slot].natoms = 0;
       }
-      if (tid < m) A.sizes[roots[tid]] = make_int2(0, 0);
-      __syncthreads();
+      tree_barrier<NCAP>();
       continue;
     }
     CSTAMP(1);
+    // Take delivery of the prefetched vdW parameters HERE, while nothing else is in flight: the memory counter is in
+    // order, so a wait placed after the topology stores below would also wait for every one of them.
+    asm volatile("" ::"v"(a_vdw_mine), "v"(v_vdw_mine));
     if (tid == 0) {
-      // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141)
+      // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141); once per subtree (its part 0)
       double e1 = e_sum;
-      for (int q = 0; q < m; q++) e1 += S.at[5][q] * S.at[4][q];
+      for (int q = 0; q < m; q++) e1 += (S.rt[kRtPart + q] & 0xff) == 0 ? S.at[5][q] * S.at[4][q] : 0.0;
       A.epart[2 * slot] = e1;
     }
     if (want_sv1) {  // diagnostics: enlarged-radius self volumes
       for (int la = tid; la < natoms; la += BS) {
-        glb_add(&A.sv_large[S.at_gidx[la]], la < m ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+        glb_add(&A.sv_large[S.at_gidx[la]], (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
         S.at[9][la] = 0.0;
       }
     }
@@ -137,8 +150,14 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         for (int q = 0; q < kMaxRoots; q++) h.partners[q] = q < m ? S.rt[kRtCount + q] : 0;
         A.hdr[slot] = h;
       }
-      // per-subtree shape for the next evaluation's packing and the statistics
-      if (tid < m) A.sizes[roots[tid]] = make_int2(1 + S.rt[kRtNodes + tid], 1 + S.rt[kRtCount + tid]);
+      // per-subtree shape for the next evaluation's packing and the statistics (zeroed by k_prep; the work items
+      // of a shared subtree add their own nodes, part 0 the root and the partner count)
+      if (tid < m) {
+        const bool first = (S.rt[kRtPart + tid] & 0xff) == 0;
+        int* sz = reinterpret_cast<int*>(&A.sizes[S.rt[kRtHeavy + tid]]);  // (no global load behind the stores above)
+        atomicAdd(&sz[0], S.rt[kRtNodes + tid] + (first ? 1 : 0));
+        if (first) sz[1] = 1 + S.rt[kRtCount + tid];
+      }
     }
     CSTAMP(2);
     // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         S.at[5][la] = -S.at[5][la];
       }
     }
-    __syncthreads();
+    tree_barrier<NCAP>();  // the topology stores above keep draining underneath pass 2
     CSTAMP(3);
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
@@ -171,14 +190,14 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
       glb_add(&A.gx[hj], S.at[6][la]);
       glb_add(&A.gy[hj], S.at[7][la]);
       glb_add(&A.gz[hj], S.at[8][la]);
-      glb_add(&A.sv_vdw[hj], la < m ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+      glb_add(&A.sv_vdw[hj], (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
     }
     if (tid == 0) {
       double e2 = e_sum;
-      for (int q = 0; q < m; q++) e2 += S.at[5][q] * S.at[4][q];
+      for (int q = 0; q < m; q++) e2 += (S.rt[kRtPart + q] & 0xff) == 0 ? S.at[5][q] * S.at[4][q] : 0.0;
       A.epart[2 * slot + 1] = e2;
     }
-    __syncthreads();
+    tree_barrier<NCAP>();
     CSTAMP(6);
     CSTAMP_FLUSH();
   }
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       S.at[8][la] = 0.0;
       S.at[9][la] = 0.0;
     }
-    __syncthreads();
+    tree_barrier<NCAP>();
     PSTAMP(0);
     double e_sum = 0.0;
     volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, kPairs ? &pair_word : nullptr);
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
       glb_add(&A.gy[hj], S.at[7][la]);
       glb_add(&A.gz[hj], S.at[8][la]);
     }
-    __syncthreads();
+    tree_barrier<NCAP>();
     PSTAMP(2);
     PSTAMP_FLUSH();
   }
@@ -276,6 +295,9 @@ extern "C" void agbnp_debug_stamps(unsigned long long* out, int reset) {
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
   }
+}
+extern "C" void agbnp_debug_stamps_slowest(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_slowest), sizeof(unsigned long long) * 24);
 }
 extern "C" void agbnp_debug_stamps_max(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_max), sizeof(unsigned long long) * 16);
@@ -324,27 +346,27 @@ static hipError_t launch_tree(K kernel, int grid, size_t lds, const TreeArgs& A,
   return hipGetLastError();
 }
 
-hipError_t launch_tree_cavity(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
+hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
 #ifdef AGBNP_STAMPS  // diagnostic build only: time the largest subtrees alone (results are incomplete)
   if (const char* env = getenv("AGBNP_DIAG_TREE_GRID"))
     return launch_tree(k_tree_cavity<512, 64, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<512, 64>::kBytes, A, st);
 #endif
   switch (variant) {
-    case 0: return launch_tree(k_tree_cavity<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kBytes, A, st);
-    case 1: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kBytes, A, st);
-    case 2: return launch_tree(k_tree_cavity<2048, 256, kBS, false>, A.nh, TreeStore<2048, 256>::kBytes, A, st);
+    case 0: return launch_tree(k_tree_cavity<512, 64, kBS, false>, slots, TreeStore<512, 64>::kBytes, A, st);
+    case 1: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kBytes, A, st);
+    case 2: return launch_tree(k_tree_cavity<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kBytes, A, st);
     default:
       return launch_tree(k_tree_cavity<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
 }
 
-hipError_t launch_tree_pseudo(int variant, int global_grid, const TreeArgs& A, hipStream_t st) {
+hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, A.nh, TreeStore<512, 64>::kReplayBytes, A, st);
-    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, A.nh, TreeStore<1024, 128>::kReplayBytes, A, st);
-    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, A.nh, TreeStore<2048, 256>::kReplayBytes, A, st);
+    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, slots, TreeStore<512, 64>::kReplayBytes, A, st);
+    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kReplayBytes, A, st);
+    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kReplayBytes, A, st);
     default:
       return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
