@@ -294,6 +294,8 @@ void wire_args(agbnp_hip_context* c) {
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
     static const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
     P.pack_enabled = no_pack ? 0 : 1;
+    static const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
+    P.round_permille = std::max(100, round_permille);
     T.forest_start = c->d_forest.p;
     T.nforests = c->d_forest.p + nhp1 + 1;
     T.cur_nforests = c->d_forest.p + nhp1 + 2;

@@ -369,7 +369,7 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   if (nc > 0) {
     const unsigned wc = (unsigned)imax[19] - (unsigned)imax[15];               // (the partners' weight is left in: safe side)
     const int fmin = max((int)((wc + 869u) / 870u), (nc + 7) / 8);            // mean fill <= 85 %, at most 8 roots
-    const int round = max(1, (P.tree_slots * 31) / 32);                        // a round of resident workgroups, 3 % spare
+    const int round = max(1, (int)(((long long)P.tree_slots * P.round_permille) / 1000));  // a round of resident workgroups, a few % spare
     const int rounds = (nab + fmin + round - 1) / round;                       // whole rounds that hold fmin
     fs = min(nc, max(fmin, rounds * round - nab));
   }
