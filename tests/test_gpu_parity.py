@@ -439,6 +439,30 @@ def test_forest_packing_and_its_overflow_protocol(gpu_required, systems):
     assert_close(e, f, eo, fo)
 
 
+def test_shared_subtrees_on_a_roomy_device(gpu_required, systems):
+    """A small system leaves most of the device idle, so from the second evaluation on its big subtrees are shared by
+    several workgroups (each expands a residue class of the level-2 nodes): more work slots than subtrees, same
+    numbers, same tree statistics."""
+    for name in ("trpcage", "fixture264"):
+        s = systems(name)
+        nheavy = int(np.sum(s.ishydrogen == 0))
+        for version in (0, 1):
+            ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=version))
+            oracle = Oracle(*s.params(), version=version)
+            totals = []
+            for step in range(4):
+                pos = s.jittered(step) if step < 3 else s.pos
+                ctx.setPositions(pos)
+                e, f = ctx.getState()
+                eo, fo = oracle.execute(pos)
+                assert_close(e, f, eo, fo)
+                totals.append(int(ctx.kernel.scalar("total_nodes")))
+                nodes = ctx.kernel.vector("subtree_nodes")
+                assert int(nodes.sum()) == totals[-1]
+                assert totals[-1] == nheavy + sum(oracle.tree_stats()["level_counts"][2:])
+            assert int(ctx.kernel.scalar("forests")) > nheavy
+
+
 def test_many_radius_types_spill_the_default_lds_allowance(gpu_required):
     """15 distinct heavy radii + the hydrogen radius: 16 x 15 type pairs x 16 knots x 16 B = 61 KB of spline tables,
     beyond the default dynamic-LDS allowance of a workgroup (the launchers must raise it) but inside the budget."""
