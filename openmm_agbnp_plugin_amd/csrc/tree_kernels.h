@@ -1,9 +1,10 @@
 // GaussVol overlap-tree kernels for gfx950 (MI355X).
 //
-// One workgroup (BS = 64..256 lanes) owns the complete overlap subtree rooted at one heavy atom and keeps
-// it in LDS for its whole life: build (large radii) -> bottom-up volume pass -> top-down rescan with vdW
-// radii -> second bottom-up pass, all inside one launch.  Only per-atom sums (gradients, self
-// volumes), one energy pair per subtree and the 8-byte/node topology leave the CU.
+// One workgroup (BS = 256 lanes) owns a FOREST -- the complete overlap subtrees rooted at up to eight heavy atoms
+// (or one residue class of the level-2 branches of a big subtree) -- and keeps it in LDS for its whole life: build
+// (large radii) -> volume pass 1 on the build's Gaussians -> topology out -> vdW radii -> volume pass 2, all inside
+// one launch.  Only per-atom sums (gradients, self volumes), one energy pair per forest and the stored topology
+// (8-byte atom path per node + 2-byte (atom, node) memberships) leave the CU.
 //
 // What is computed (reference restated in oracle/agbnp_oracle.cpp):
 //   build      : gaussvol/gaussvol.cpp:197-250 (child scan over YOUNGER siblings), :154-192 (children sorted
@@ -14,7 +15,7 @@
 //   rescan     : gaussvol/gaussvol.cpp:254-327 (volumes) and :330-372 (gammas only)
 //
 // Design differences from the reference (same numbers, different machine):
-//   * breadth-first node order inside a subtree (levels contiguous) so that expansion and both sweeps are
+//   * breadth-first node order inside a forest (levels contiguous over all its trees) so that the expansion is
 //     lane-parallel over a level; the reference is depth-first recursive.
 //   * level-synchronous expansion: every (node, younger sibling) pair of a level is one task = one lane;
 //     tasks -> switched volumes in LDS -> per-node child counts (prefix sum) -> per-task rank inside its
@@ -24,12 +25,11 @@
 //     product of Gaussians, so dG_n/dr_m = -2 a_m (r_m - c_n) G_n for every atom m of the node, and
 //       dE/dr_m   = sum_{n contains m} c_n gamma_n sfp_n * (-2 a_m)(r_m - c_n) G_n
 //       selfvol_m = sum_{n contains m} c_n s(G_n) G_n                 (c_n = +-1/level)
-//     A pass is therefore: (1) top-down rescan (Gaussians, gammas, one 8-byte "atom path" per node),
-//     (2) one node-parallel step turning (G_n, gamma_n, level) into the two scalars coef_n, w_n,
-//     (3) an atom-owned gather: every local atom is owned by one lane group, walks the node list and adds the
-//     terms of the nodes whose path contains it -- no atomics (64-bit LDS atomics cost ~160 cycles per
-//     wave instruction on gfx950), no level ordering, bit-reproducible inside a subtree.
-//     The subtree root's gradient follows from translation invariance (the gradients of a subtree sum to 0).
+//   * no top-down rescan: every node carries its atom list (path word), so a pass evaluates every node directly from
+//     its atoms (telescoped chain of pairwise merges, see volume_pass) -- no level ordering, no barriers between
+//     levels -- then turns (G_n, gamma_n, level) into the two scalars coef_n, w_n and gathers them over a list of
+//     (atom, node) memberships sorted by atom (equal pieces per lane, one LDS FP64 add per run of an atom).
+//     A root's gradient follows from translation invariance (the gradients of a tree sum to 0).
 #pragma once
 #include <hip/hip_runtime.h>
 
