@@ -296,6 +296,10 @@ void wire_args(agbnp_hip_context* c) {
     P.pack_enabled = no_pack ? 0 : 1;
     static const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
     P.round_permille = std::max(100, round_permille);
+    static const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 1;
+    static const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 720;
+    P.split_big = std::min(4, std::max(1, split_big));
+    P.split_permille = std::max(50, split_permille);
     T.forest_start = c->d_forest.p;
     T.nforests = c->d_forest.p + nhp1 + 1;
     T.cur_nforests = c->d_forest.p + nhp1 + 2;

@@ -42,6 +42,7 @@ struct PairArgs {
   int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
+  int split_big, split_permille;  // tuning knobs: parts and node threshold (share of the capacity) for sharing on a full device
   int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 969)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
   int* status;

@@ -280,8 +280,8 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   // as its slowest workgroup, and idle slots are free); with more subtrees than resident workgroups the extra items
   // crowd the forests of the others and the kernel gets slower (measured on 1dwc: 57 -> 59 us), so they stay whole.
   const bool roomy = 2 * P.nh <= P.tree_slots;
-  const int max_parts = (pack && roomy) ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : 1;
-  const int split_nodes = 48;
+  const int max_parts = !pack ? 1 : (roomy ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : P.split_big);
+  const int split_nodes = roomy ? 48 : (int)((float)P.split_permille * 0.001f * share * (float)P.tree_node_cap);
   auto parts_of = [&](int2 sz) { return min(max_parts, 1 + sz.x / split_nodes); };
   auto weight = [&](int2 sz, int parts) -> unsigned {  // of one work item of the subtree, 128..2047
     const int l2 = max(sz.y - 1, 0);
