@@ -36,6 +36,13 @@ struct SubtreeHeader {
   int partners[8];  // level-2 partners of every root
 };
 
+// Level-2 candidates of every heavy atom (younger heavy atoms inside the conservative overlap cutoff), found by
+// the tile workgroups of the k_prep launch: up to kCandCap records of 8 doubles {x, y, z, exponent, volume, gamma,
+// heavy index (as an integer in the bits of a double), unused}.  A root with more candidates than that (dense
+// synthetic systems) is searched the long way by its tree workgroup.
+constexpr int kCandCap = 128;
+constexpr int kCandRecDoubles = 8;
+
 // status/overflow word indices (device int array)
 enum StatusWord {
   kStatNodeOverflow = 0,   // a subtree needed more than NCAP nodes

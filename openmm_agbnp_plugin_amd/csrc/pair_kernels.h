@@ -20,6 +20,12 @@ struct PairArgs {
   const double* inv_rvdw;  // [n] 1/R_i
   const double* inv_vol_h;  // [nh] 1/(4 pi R^3/3), vdW radius
   const double* gam_cav;   // [nh] gamma/roffset
+  const double *a_large, *v_large;  // [nh] Gaussian exponent / volume with the enlarged radii
+  double rcut2;            // conservative squared cutoff of the 2-body overlap search
+  const int* cand_items;   // [cand_items_count] heavy-block tiles I | J << 12 (I <= J) of the level-2 candidate search
+  int cand_items_count;
+  int* cand_count;         // [nh] level-2 candidates found for every heavy atom (zero at the start of an evaluation)
+  double* cand_rec;        // [nh][kCandCap][kCandRecDoubles]
   const int2* ameta;       // [n] {screened type, screener type or -1}
   const double2* lut;      // [nti*ntj*16] {y, y2*dr^2/6}
   int nti, ntj, lut_entries;

@@ -41,6 +41,8 @@ struct TreeArgs {
   int nh;  // heavy atoms
   const int* order;            // [nh] subtrees sorted by the previous evaluation's node count, descending
   const int* forest_start;     // [nh+1] work slot s builds the subtrees order[forest_start[s] .. forest_start[s+1])
+  const int* cand_count;       // [nh] level-2 candidates listed by the k_prep launch (see kCandCap)
+  const double* cand_rec;      // [nh][kCandCap][kCandRecDoubles]
   const int* nforests;         // [1] work slots in use (rewritten for the NEXT evaluation while this one's pair stages run)
   int* cur_nforests;           // [1] copy taken by k_tree_cavity: the count the later kernels of THIS evaluation use
   const double *hx, *hy, *hz;  // heavy-atom positions (SoA, heavy index)
@@ -72,7 +74,7 @@ constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of 
 // by level.  Every phase of the expansion and of the volume passes is bound by latency, not by work, so a forest of a
 // few hundred nodes costs little more than one subtree of a hundred.
 constexpr int kMaxRoots = 8;
-constexpr int kRootWords = 5 * kMaxRoots + 8;
+constexpr int kRootWords = 6 * kMaxRoots + 8;
 enum RootWord {
   kRtHeavy = 0,              // heavy index of the root
   kRtCount = kMaxRoots,      // level-2 partners
@@ -81,7 +83,8 @@ enum RootWord {
   kRtPart = 4 * kMaxRoots,   // part | parts << 8: a big subtree is shared by `parts` work items; item `part` expands the
                              // level-2 nodes whose rank is congruent to it (branches under different level-2 nodes are
                              // independent) and treats the other level-2 nodes as siblings only
-  kRtNum = 5 * kMaxRoots
+  kRtCand = 5 * kMaxRoots,   // listed level-2 candidates of the root (-1: too many for the list, sweep all younger atoms)
+  kRtNum = 6 * kMaxRoots
 };
 // work item = heavy index | part << 24 | (parts - 1) << 26
 __host__ __device__ inline int work_item_root(int e) { return e & 0xffffff; }
@@ -426,6 +429,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.rt[kRtCount + tid] = 0;
     S.rt[kRtNodes + tid] = 0;
     S.rt[kRtPart + tid] = work_item_part(item) | (work_item_parts(item) << 8);
+    const int listed = A.cand_count ? A.cand_count[hi] : kCandCap + 1;  // no lists (small systems): sweep
+    S.rt[kRtCand + tid] = listed <= kCandCap ? listed : -1;
   }
   if (tid == 0) {
     S.ctl[0] = 0;  // level-2 candidate counter of the whole forest
@@ -434,25 +439,11 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   tree_barrier<NCAP>();
 
   // ---- level 2: for every root, all heavy atoms with a larger index whose overlap with the root survives the
-  // switch.  The candidate ranges of the roots are laid end to end and walked two per lane and trip, every field
-  // requested up front (one L2 round trip per 2*BS candidates); a hit takes a slot with an LDS counter and parks
-  // its atom record in the (still unused) upper node slots so that ranking never goes back to HBM.
-  int off[kMaxRoots + 1];  // candidate offsets of the roots in the concatenated range (registers, m <= kMaxRoots)
-  off[0] = 0;
-#pragma unroll
-  for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? A.nh - 1 - S.rt[kRtHeavy + q] : 0);
-  const int ncandidates = off[kMaxRoots];
-  auto locate = [&](int c, int& q, int& hj) {  // concatenated index -> (root, heavy atom)
-    q = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
-    int o = off[0];
-#pragma unroll
-    for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
-    hj = S.rt[kRtHeavy + q] + 1 + (c - o);
-  };
-  auto consider = [&](int q, int hj, bool valid, double xj, double yj, double zj, double aj, double vj, double gj) {
-    if (!valid) return;
+  // switch.  The k_prep launch has listed, per heavy atom, the records of the younger atoms inside the conservative
+  // cutoff; the lists of the roots are laid end to end and fetched two records per lane and trip (one round trip for
+  // ~60 records), each takes the exact test, and a hit takes a slot with an LDS counter and parks its atom record
+  // in the (still unused) upper node slots so that ranking never goes back to HBM.
+  auto consider = [&](int q, int hj, double xj, double yj, double zj, double aj, double vj, double gj) {
     const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
     const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
     const double d2 = dx * dx + dy * dy + dz * dz;
@@ -473,18 +464,68 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[5][st] = gj;
     }
   };
-  for (int base = 0; base < ncandidates; base += 2 * BS) {
-    const int c0 = base + tid, c1 = base + BS + tid;
-    const bool v0 = c0 < ncandidates, v1 = c1 < ncandidates;
-    int q0, h0, q1, h1;
-    locate(v0 ? c0 : 0, q0, h0);
-    locate(v1 ? c1 : 0, q1, h1);
-    if (!v0) h0 = S.rt[kRtHeavy];  // any valid address
-    if (!v1) h1 = S.rt[kRtHeavy];
-    const double x0 = A.hx[h0], y0 = A.hy[h0], z0 = A.hz[h0], a0 = A.a_large[h0], w0 = A.v_large[h0], g0 = A.gam[h0];
-    const double x1 = A.hx[h1], y1 = A.hy[h1], z1 = A.hz[h1], a1 = A.a_large[h1], w1 = A.v_large[h1], g1 = A.gam[h1];
-    consider(q0, h0, v0, x0, y0, z0, a0, w0, g0);
-    consider(q1, h1, v1, x1, y1, z1, a1, w1, g1);
+  {
+    int off[kMaxRoots + 1];  // offsets of the roots' lists in the concatenated range (m <= kMaxRoots)
+    off[0] = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? max(S.rt[kRtCand + q], 0) : 0);
+    const int nlisted = off[kMaxRoots];
+    auto fetch = [&](int c, int& q, int& hj, double2& r0, double2& r1, double2& r2) {
+      q = 0;
+#pragma unroll
+      for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
+      int o = off[0];
+#pragma unroll
+      for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
+      const double2* rec = reinterpret_cast<const double2*>(A.cand_rec + ((size_t)S.rt[kRtHeavy + q] * kCandCap + (c - o)) * kCandRecDoubles);
+      r0 = rec[0];
+      r1 = rec[1];
+      r2 = rec[2];
+      hj = __double2loint(rec[3].x);
+    };
+    for (int base = 0; base < nlisted; base += 2 * BS) {
+      const int c0 = base + tid, c1 = base + BS + tid;
+      const bool v0 = c0 < nlisted, v1 = c1 < nlisted;
+      int q0, h0, q1, h1;
+      double2 a0, b0, g0, a1, b1, g1;
+      fetch(v0 ? c0 : 0, q0, h0, a0, b0, g0);
+      fetch(v1 ? c1 : 0, q1, h1, a1, b1, g1);
+      if (v0) consider(q0, h0, a0.x, a0.y, b0.x, b0.y, g0.x, g0.y);
+      if (v1) consider(q1, h1, a1.x, a1.y, b1.x, b1.y, g1.x, g1.y);
+    }
+  }
+  // Roots without a list sweep all their younger atoms: the ranges of those roots are laid end to end and walked two
+  // per lane and trip, every field requested up front (one L2 round trip per 2*BS candidates).  This is the only
+  // search of a system too small for the lists to pay (the tile search costs ~4 us in the k_prep launch and saves
+  // one round trip per 512 candidates here), and the fallback of a root whose list overflowed (dense systems).
+  {
+    int off[kMaxRoots + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + ((q < m && S.rt[kRtCand + q] < 0) ? A.nh - 1 - S.rt[kRtHeavy + q] : 0);
+    const int nswept = off[kMaxRoots];
+    auto locate = [&](int c, int& q, int& hj) {  // concatenated index -> (root, heavy atom)
+      q = 0;
+#pragma unroll
+      for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
+      int o = off[0];
+#pragma unroll
+      for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
+      hj = S.rt[kRtHeavy + q] + 1 + (c - o);
+    };
+    for (int base = 0; base < nswept; base += 2 * BS) {
+      const int c0 = base + tid, c1 = base + BS + tid;
+      const bool v0 = c0 < nswept, v1 = c1 < nswept;
+      int q0, h0, q1, h1;
+      locate(v0 ? c0 : 0, q0, h0);
+      locate(v1 ? c1 : 0, q1, h1);
+      if (!v0) h0 = S.rt[kRtHeavy];  // any valid address
+      if (!v1) h1 = S.rt[kRtHeavy];
+      const double x0 = A.hx[h0], y0 = A.hy[h0], z0 = A.hz[h0], a0 = A.a_large[h0], w0 = A.v_large[h0], g0 = A.gam[h0];
+      const double x1 = A.hx[h1], y1 = A.hy[h1], z1 = A.hz[h1], a1 = A.a_large[h1], w1 = A.v_large[h1], g1 = A.gam[h1];
+      if (v0) consider(q0, h0, x0, y0, z0, a0, w0, g0);
+      if (v1) consider(q1, h1, x1, y1, z1, a1, w1, g1);
+    }
   }
   tree_barrier<NCAP>();
   AGBNP_BUILD_STAMP(8);
