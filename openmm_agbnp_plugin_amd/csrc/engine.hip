@@ -433,11 +433,15 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   HIP_TRY(c, launch_prep(c->P, st, tl));
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
-  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, c->slot_cap, c->T, st));
+  // work slots to launch: the packing rarely needs more than the subtree count (a shared subtree on a roomy device
+  // aside); if it ever plans more than were launched the tree kernel reports a packing overflow and the host repeats
+  static const int grid_permille = getenv("AGBNP_HIP_GRID_PERMILLE") ? atoi(getenv("AGBNP_HIP_GRID_PERMILLE")) : 1250;
+  const int tree_grid = std::min(c->slot_cap, std::max(c->tree_slots[0], (int)((long long)c->nh * grid_permille / 1000)));
+  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
-    HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, c->slot_cap, c->T, st));
+    HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, tree_grid, c->T, st));
   }
   HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
   return AGBNP_HIP_OK;
