@@ -434,6 +434,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   }
   if (tid == 0) {
     S.ctl[0] = 0;  // level-2 candidate counter of the whole forest
+    S.ctl[5] = 0;  // near-candidate counter (stage 1 of the search)
+    S.ctl[6] = 0;  // set when the near list overflowed
     S.rt[kRtNum] = m;
   }
   tree_barrier<NCAP>();
@@ -443,25 +445,45 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   // cutoff; the lists of the roots are laid end to end and fetched two records per lane and trip (one round trip for
   // ~60 records), each takes the exact test, and a hit takes a slot with an LDS counter and parks its atom record
   // in the (still unused) upper node slots so that ranking never goes back to HBM.
-  auto consider = [&](int q, int hj, double xj, double yj, double zj, double aj, double vj, double gj) {
-    const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
-    const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 >= A.rcut2) return;
-    const double sv = dev_merge_volume(rx, ry, rz, S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj);
-    if (!(sv > kMinGvol)) return;
+  // Two stages, because the exact test (a Gaussian merge: exp, sqrt, reciprocal) is two hundred instructions that a
+  // wave executes in full as soon as ONE of its lanes is inside the cutoff -- and with ~30 of ~1000 candidates inside,
+  // nearly every wave has one.  Stage 1 (here, per candidate) only appends the near ones to a staging list; stage 2
+  // (below, after the sweep) takes the exact test densely, one near candidate per lane.
+  constexpr int kNearCap = NCAP - ACAP;  // staging slots NCAP-1-p, p < kNearCap: clear of the roots and level-2 nodes (< ACAP)
+  auto accept = [&](int q, int hj, double sv, double xj, double yj, double zj, double aj, double vj, double gj) {
     const int p = atomicAdd(&S.ctl[0], 1);
     atomicAdd(&S.rt[kRtCount + q], 1);
     if (p < ACAP - m) {
       S.cand_vol[p] = sv;
       S.cand_idx[p] = hj | (q << 24);
-      const int st = NCAP - 1 - p;  // staging slot (roots and level-2 nodes land below ACAP <= NCAP - ACAP)
+      const int st = NCAP - 1 - p;  // staging slot of the accepted candidates (level-2 nodes land below ACAP)
       S.nd[0][st] = xj;
       S.nd[1][st] = yj;
       S.nd[2][st] = zj;
       S.nd[3][st] = aj;
       S.nd[4][st] = vj;
       S.nd[5][st] = gj;
+    }
+  };
+  auto consider = [&](int q, int hj, double xj, double yj, double zj, double aj, double vj, double gj) {
+    const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
+    const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 >= A.rcut2) return;
+    const int p = atomicAdd(&S.ctl[5], 1);
+    if (p < kNearCap) {
+      const int st = NCAP - 1 - p;
+      S.nd[0][st] = xj;
+      S.nd[1][st] = yj;
+      S.nd[2][st] = zj;
+      S.nd[3][st] = aj;
+      S.nd[4][st] = vj;
+      S.nd[5][st] = gj;
+      S.nd[6][st] = __hiloint2double(0, hj | (q << 24));
+    } else {
+      // the staging list is full (dense synthetic systems): take the exact test on the spot.  Accepted candidates
+      // then share the staging slots with the near list: park them after stage 2 instead
+      S.ctl[6] = 1;
     }
   };
   {
@@ -525,6 +547,25 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       const double x1 = A.hx[h1], y1 = A.hy[h1], z1 = A.hz[h1], a1 = A.a_large[h1], w1 = A.v_large[h1], g1 = A.gam[h1];
       if (v0) consider(q0, h0, x0, y0, z0, a0, w0, g0);
       if (v1) consider(q1, h1, x1, y1, z1, a1, w1, g1);
+    }
+  }
+  tree_barrier<NCAP>();
+  if (S.ctl[6]) return kBuildAtomOverflow;  // more near candidates than staging slots: next capacity variant
+  {
+    // stage 2: exact test, one near candidate per lane.  An accepted candidate moves to the staging slot of its
+    // running number, which is never above the near slots already read (numbers are handed out as trips complete).
+    const int nnear = S.ctl[5];
+    for (int base = 0; base < nnear; base += BS) {
+      const bool mine = base + tid < nnear;
+      const int st = NCAP - 1 - (mine ? base + tid : 0);
+      const double xj = S.nd[0][st], yj = S.nd[1][st], zj = S.nd[2][st], aj = S.nd[3][st], vj = S.nd[4][st], gj = S.nd[5][st];
+      const int packed = __double2loint(S.nd[6][st]);
+      const int q = mine ? packed >> 24 : 0;
+      double sv = 0.0;
+      if (mine) sv = dev_merge_volume(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj);
+      tree_barrier<NCAP>();  // the near records of this trip are in registers: accepted ones may take staging slots
+      if (mine && sv > kMinGvol) accept(q, packed & 0xffffff, sv, xj, yj, zj, aj, vj, gj);
+      tree_barrier<NCAP>();
     }
   }
   tree_barrier<NCAP>();
