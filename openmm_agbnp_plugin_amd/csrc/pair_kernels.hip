@@ -37,12 +37,13 @@ struct SplineCubic {
   double c0, c1, c2, c3, t;
 };
 __device__ __forceinline__ SplineCubic spline_cubic(const double2* __restrict__ tab, int base, double d) {
+  // callers only ask inside the table (d < kI4MaxA), so the knot index needs no clamp and the position inside the
+  // interval is the hardware fraction: one conversion instead of two (conversions issue at quarter rate)
   const double u = d * ((kI4Nodes - 1) / kI4MaxA);
-  int k = (int)u;
-  k = k > kI4Nodes - 2 ? kI4Nodes - 2 : k;
+  const int k = (int)u;
   const double2 lo = tab[base + k], hi = tab[base + k + 1];
   SplineCubic c;
-  c.t = u - (double)k;
+  c.t = __builtin_amdgcn_fract(u);
   c.c0 = lo.x;
   c.c1 = (hi.x - lo.x) - fma(2.0, lo.y, hi.y);
   c.c2 = 3.0 * lo.y;
