@@ -252,6 +252,32 @@ __device__ __forceinline__ double dev_merge_volume(double x1, double y1, double 
   return dev_switch(gvol, sp) * gvol;
 }
 
+// the same, also returning the unswitched overlap volume (kept for the node record: the merge itself is then only the
+// weighted centre, see dev_merge_known)
+__device__ __forceinline__ double dev_merge_volume2(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
+                                                    double z2, double a2, double v2, double& gvol_out) {
+  const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+  const double d2 = dx * dx + dy * dy + dz * dz;
+  const double df = a1 * a2 * fast_rcp(a1 + a2);
+  const double q = df * (1.0 / kPi);
+  const double gvol = v1 * (v2 * (q * sqrt(q)) * exp(-df * d2));  // same association as dev_merge
+  gvol_out = gvol;
+  double sp;
+  return dev_switch(gvol, sp) * gvol;
+}
+
+// node record of an overlap whose unswitched volume is already known: exponent sum and weighted centre, no exp / sqrt
+__device__ __forceinline__ void dev_merge_known(double x1, double y1, double z1, double a1, double x2, double y2, double z2,
+                                                double a2, double gvol, double& x, double& y, double& z, double& a) {
+  const double a12 = a1 + a2;
+  const double deltai = fast_rcp(a12);
+  x = (x1 * a1 + x2 * a2) * deltai;
+  y = (y1 * a1 + y2 * a2) * deltai;
+  z = (z1 * a1 + z2 * a2) * deltai;
+  a = a12;
+  (void)gvol;
+}
+
 __device__ __forceinline__ void dev_merge(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
                                           double z2, double a2, double v2, Merged& m) {
   const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
@@ -450,7 +476,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   // nearly every wave has one.  Stage 1 (here, per candidate) only appends the near ones to a staging list; stage 2
   // (below, after the sweep) takes the exact test densely, one near candidate per lane.
   constexpr int kNearCap = NCAP - ACAP;  // staging slots NCAP-1-p, p < kNearCap: clear of the roots and level-2 nodes (< ACAP)
-  auto accept = [&](int q, int hj, double sv, double xj, double yj, double zj, double aj, double vj, double gj) {
+  auto accept = [&](int q, int hj, double sv, double gvol, double xj, double yj, double zj, double aj, double vj, double gj) {
     const int p = atomicAdd(&S.ctl[0], 1);
     atomicAdd(&S.rt[kRtCount + q], 1);
     if (p < ACAP - m) {
@@ -463,6 +489,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[3][st] = aj;
       S.nd[4][st] = vj;
       S.nd[5][st] = gj;
+      S.nd[6][st] = gvol;  // unswitched overlap with the root: the level-2 node's volume
     }
   };
   auto consider = [&](int q, int hj, double xj, double yj, double zj, double aj, double vj, double gj) {
@@ -561,10 +588,10 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       const double xj = S.nd[0][st], yj = S.nd[1][st], zj = S.nd[2][st], aj = S.nd[3][st], vj = S.nd[4][st], gj = S.nd[5][st];
       const int packed = __double2loint(S.nd[6][st]);
       const int q = mine ? packed >> 24 : 0;
-      double sv = 0.0;
-      if (mine) sv = dev_merge_volume(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj);
+      double sv = 0.0, gvol = 0.0;
+      if (mine) sv = dev_merge_volume2(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj, gvol);
       tree_barrier<NCAP>();  // the near records of this trip are in registers: accepted ones may take staging slots
-      if (mine && sv > kMinGvol) accept(q, packed & 0xffffff, sv, xj, yj, zj, aj, vj, gj);
+      if (mine && sv > kMinGvol) accept(q, packed & 0xffffff, sv, gvol, xj, yj, zj, aj, vj, gj);
       tree_barrier<NCAP>();
     }
   }
@@ -629,13 +656,14 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.at[4][slot] = v2;
     S.at[5][slot] = g2;
     S.at_gidx[slot] = hj;
-    Merged mg;
-    dev_merge(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], x2, y2, z2, a2, v2, mg);
-    S.nd[0][slot] = mg.x;
-    S.nd[1][slot] = mg.y;
-    S.nd[2][slot] = mg.z;
-    S.nd[3][slot] = mg.a;
-    S.nd[4][slot] = mg.v;
+    const double gv2 = S.nd[6][st];  // unswitched overlap with the root, from the exact test of the search
+    double cmx, cmy, cmz, cma;
+    dev_merge_known(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], x2, y2, z2, a2, gv2, cmx, cmy, cmz, cma);
+    S.nd[0][slot] = cmx;
+    S.nd[1][slot] = cmy;
+    S.nd[2][slot] = cmz;
+    S.nd[3][slot] = cma;
+    S.nd[4][slot] = gv2;
     S.nd[5][slot] = S.at[5][q] + g2;
     S.nla[slot] = (unsigned short)slot;
     S.npar[slot] = (unsigned short)q;
@@ -736,10 +764,13 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         const int kk = nb + j;
         const int s = kk + 1 + (t - (int)S.tstart[j]);
         const int la = S.nla[s];
-        const double v = dev_merge_volume(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
-                                          S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la]);
+        double gv;
+        const double v = dev_merge_volume2(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
+                                           S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la], gv);
         const bool kept = v > kMinGvol;
-        tvol[t] = kept ? v : 0.0;
+        // the UNSWITCHED volume is kept: it is the child's node volume, and the switched volume s(V) V that the
+        // reference sorts by is strictly increasing in V wherever a child survives, so the order is the same
+        tvol[t] = kept ? gv : 0.0;
         const unsigned long long km = __ballot(kept);  // tasks t0..t0+63 of this wave trip: t0 = t - lane
         if ((tid & 63) == 0) S.kmask[t >> 6] = km;
       }
@@ -816,14 +847,14 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           const int cb = S.cbase[j];
           const int slot = cb + rank;
           const int la = S.nla[kk + 1 + (t - ts)];
-          Merged m;
-          dev_merge(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la], S.at[1][la], S.at[2][la],
-                    S.at[3][la], S.at[4][la], m);
-          S.nd[0][slot] = m.x;
-          S.nd[1][slot] = m.y;
-          S.nd[2][slot] = m.z;
-          S.nd[3][slot] = m.a;
-          S.nd[4][slot] = m.v;
+          double mx, my, mz, ma;
+          dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
+                          mx, my, mz, ma);
+          S.nd[0][slot] = mx;
+          S.nd[1][slot] = my;
+          S.nd[2][slot] = mz;
+          S.nd[3][slot] = ma;
+          S.nd[4][slot] = v;
           S.nd[5][slot] = S.nd[5][kk] + S.at[5][la];
           S.nla[slot] = (unsigned short)la;
           S.npar[slot] = (unsigned short)kk;
