@@ -81,7 +81,7 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot, d_cand_items, d_cand_count;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot, d_cand_count;
   DevBuf<double> d_cand_rec;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
   DevBuf<int2> d_ameta;
@@ -287,11 +287,11 @@ void wire_args(agbnp_hip_context* c) {
   P.a_large = c->d_a_large.p;
   P.v_large = c->d_v_large.p;
   P.rcut2 = c->T.rcut2;
-  P.cand_items = c->d_cand_items.p;
   // the level-2 candidate lists pay from a few thousand heavy atoms on (see build_forest); AGBNP_HIP_CAND_LISTS=0/1 forces
   static const char* cand_env = getenv("AGBNP_HIP_CAND_LISTS");
   const bool lists = c->nh > 0 && (cand_env ? atoi(cand_env) != 0 : c->nh >= 3000);
-  P.cand_items_count = lists ? (int)c->d_cand_items.count : 0;
+  const int nhb_c = (c->nh + 63) / 64;
+  P.cand_items_count = lists ? nhb_c * (nhb_c + 1) / 2 : 0;
   P.cand_count = c->d_cand_count.p;
   P.cand_rec = c->d_cand_rec.p;
   T.cand_count = lists ? c->d_cand_count.p : nullptr;
@@ -374,11 +374,6 @@ int allocate_work(agbnp_hip_context* c) {
     // level-2 candidate search: tiles of 64x64 heavy atoms (I <= J), per-atom record lists
     const int nhb = (nh + 63) / 64;
     if (nhb > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 heavy atoms are not supported by the tile index encoding");
-    std::vector<int> tiles;
-    for (int I = 0; I < nhb; I++)
-      for (int J = I; J < nhb; J++) tiles.push_back(I | (J << 12));
-    if (tiles.empty()) tiles.push_back(0);
-    HIP_TRY(c, c->d_cand_items.upload(tiles));
     HIP_TRY(c, c->d_cand_count.alloc(nhp));
     HIP_TRY(c, hipMemset(c->d_cand_count.p, 0, sizeof(int) * nhp));
     HIP_TRY(c, c->d_cand_rec.alloc(nhp * (size_t)kCandCap * kCandRecDoubles));

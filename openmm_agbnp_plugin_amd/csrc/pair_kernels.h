@@ -22,8 +22,7 @@ struct PairArgs {
   const double* gam_cav;   // [nh] gamma/roffset
   const double *a_large, *v_large;  // [nh] Gaussian exponent / volume with the enlarged radii
   double rcut2;            // conservative squared cutoff of the 2-body overlap search
-  const int* cand_items;   // [cand_items_count] heavy-block tiles I | J << 12 (I <= J) of the level-2 candidate search
-  int cand_items_count;
+  int cand_items_count;    // tiles of 64x64 heavy atoms (I <= J) of the level-2 candidate search; 0 = no lists
   int* cand_count;         // [nh] level-2 candidates found for every heavy atom (zero at the start of an evaluation)
   double* cand_rec;        // [nh][kCandCap][kCandRecDoubles]
   const int2* ameta;       // [n] {screened type, screener type or -1}

@@ -204,14 +204,6 @@ struct TreeStore {
 };
 
 // ---- Gaussian merge ----------------------------------------------------------------------------
-struct Merged {
-  double x, y, z, a, v;  // overlap Gaussian (v = UNswitched volume)
-  double vol;            // switched volume s*v
-  double sfp;            // s' * v + s
-  double dvx, dvy, dvz;  // dv1 = (c2-c1) * (-dVdr)
-  double dvv1;           // dV/dV1 (unswitched)
-};
-
 // 1/x to ~1 ulp: hardware seed + two Newton steps (an IEEE divide costs ~4x as many instructions)
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -240,20 +232,9 @@ __device__ __forceinline__ double dev_switch(double gvol, double& sp) {
   return s;
 }
 
-// switched overlap volume only (the keep test and the sort key of the expansion)
-__device__ __forceinline__ double dev_merge_volume(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
-                                                   double z2, double a2, double v2) {
-  const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
-  const double d2 = dx * dx + dy * dy + dz * dz;
-  const double df = a1 * a2 * fast_rcp(a1 + a2);
-  const double q = df * (1.0 / kPi);
-  const double gvol = v1 * (v2 * (q * sqrt(q)) * exp(-df * d2));  // same association as dev_merge
-  double sp;
-  return dev_switch(gvol, sp) * gvol;
-}
-
-// the same, also returning the unswitched overlap volume (kept for the node record: the merge itself is then only the
-// weighted centre, see dev_merge_known)
+// Overlap of two Gaussians (gaussvol/gaussvol.cpp:60-93): returns the switched volume s(V) V (the keep test of the
+// expansion) and hands back the unswitched V, which is the node record's volume -- the rest of the record is only
+// the weighted centre, see dev_merge_known
 __device__ __forceinline__ double dev_merge_volume2(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
                                                     double z2, double a2, double v2, double& gvol_out) {
   const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
@@ -276,33 +257,6 @@ __device__ __forceinline__ void dev_merge_known(double x1, double y1, double z1,
   z = (z1 * a1 + z2 * a2) * deltai;
   a = a12;
   (void)gvol;
-}
-
-__device__ __forceinline__ void dev_merge(double x1, double y1, double z1, double a1, double v1, double x2, double y2,
-                                          double z2, double a2, double v2, Merged& m) {
-  const double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
-  const double d2 = dx * dx + dy * dy + dz * dz;
-  const double a12 = a1 + a2;
-  const double deltai = fast_rcp(a12);
-  const double df = a1 * a2 * deltai;
-  const double ef = exp(-df * d2);
-  const double q = df * (1.0 / kPi);
-  const double per_v1 = v2 * (q * sqrt(q)) * ef;  // dV12/dV1 (unswitched); the reference forms gvol/v1
-  const double gvol = v1 * per_v1;
-  const double mdVdr = 2.0 * df * gvol;  // -(dV/dr)/r
-  m.x = (x1 * a1 + x2 * a2) * deltai;
-  m.y = (y1 * a1 + y2 * a2) * deltai;
-  m.z = (z1 * a1 + z2 * a2) * deltai;
-  m.a = a12;
-  m.v = gvol;
-  double sp;
-  const double s = dev_switch(gvol, sp);
-  m.vol = s * gvol;
-  m.sfp = sp * gvol + s;
-  m.dvx = dx * mdVdr;
-  m.dvy = dy * mdVdr;
-  m.dvz = dz * mdVdr;
-  m.dvv1 = v1 > 0 ? per_v1 : 0.0;
 }
 
 // ---- wave / workgroup helpers -------------------------------------------------------------------
@@ -364,34 +318,6 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 63);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// inclusive scan of one int per thread over the workgroup; *total = sum over all threads.
-// `part` = BS/64 ints of LDS.  Contains two barriers.
-template <int BS>
-__device__ __forceinline__ int block_inclusive_scan(int v, int tid, int* part, int* total) {
-  const int lane = tid & 63;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
-  if (BS == 64) {
-    *total = __shfl(v, 63, 64);
-    return v;
-  }
-  const int w = tid >> 6;
-  if (lane == 63) part[w] = v;
-  __syncthreads();
-  int add = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < BS / 64; i++) {
-    const int s = part[i];
-    if (i < w) add += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return v + add;
 }
 
 #ifdef AGBNP_STAMPS
