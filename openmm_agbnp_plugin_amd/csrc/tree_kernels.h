@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include "agbnp_common.h"
+#include "device_math.h"
 
 namespace agbnp {
 
@@ -241,7 +242,7 @@ __device__ __forceinline__ double dev_merge_volume2(double x1, double y1, double
   const double d2 = dx * dx + dy * dy + dz * dz;
   const double df = a1 * a2 * fast_rcp(a1 + a2);
   const double q = df * (1.0 / kPi);
-  const double gvol = v1 * (v2 * (q * sqrt(q)) * exp(-df * d2));  // same association as dev_merge
+  const double gvol = v1 * (v2 * pow_three_halves(q) * exp_nonpositive(-df * d2));
   gvol_out = gvol;
   double sp;
   return dev_switch(gvol, sp) * gvol;
@@ -912,7 +913,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         level++;
       }
       const double q = pa * fast_rcp(A * pi_power(level - 1));
-      g = pv * (q * sqrt(q)) * exp(-E);
+      g = pv * pow_three_halves(q) * exp_nonpositive(-E);
       S.nd[0][n] = cx;
       S.nd[1][n] = cy;
       S.nd[2][n] = cz;
