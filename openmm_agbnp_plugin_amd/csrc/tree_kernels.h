@@ -419,7 +419,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[6][st] = gvol;  // unswitched overlap with the root: the level-2 node's volume
     }
   };
-  auto consider = [&](int q, int hj, double xj, double yj, double zj, double aj, double vj, double gj) {
+  auto consider = [&](int q, int hj, double xj, double yj, double zj) {
     const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
     const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
     const double d2 = dx * dx + dy * dy + dz * dz;
@@ -430,14 +430,9 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[0][st] = xj;
       S.nd[1][st] = yj;
       S.nd[2][st] = zj;
-      S.nd[3][st] = aj;
-      S.nd[4][st] = vj;
-      S.nd[5][st] = gj;
       S.nd[6][st] = __hiloint2double(0, hj | (q << 24));
     } else {
-      // the staging list is full (dense synthetic systems): take the exact test on the spot.  Accepted candidates
-      // then share the staging slots with the near list: park them after stage 2 instead
-      S.ctl[6] = 1;
+      S.ctl[6] = 1;  // more near candidates than staging slots (dense synthetic systems): next capacity variant
     }
   };
   {
@@ -466,8 +461,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       double2 a0, b0, g0, a1, b1, g1;
       fetch(v0 ? c0 : 0, q0, h0, a0, b0, g0);
       fetch(v1 ? c1 : 0, q1, h1, a1, b1, g1);
-      if (v0) consider(q0, h0, a0.x, a0.y, b0.x, b0.y, g0.x, g0.y);
-      if (v1) consider(q1, h1, a1.x, a1.y, b1.x, b1.y, g1.x, g1.y);
+      if (v0) consider(q0, h0, a0.x, a0.y, b0.x);
+      if (v1) consider(q1, h1, a1.x, a1.y, b1.x);
     }
   }
   // Roots without a list sweep all their younger atoms: the ranges of those roots are laid end to end and walked two
@@ -489,18 +484,27 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
       hj = S.rt[kRtHeavy + q] + 1 + (c - o);
     };
-    for (int base = 0; base < nswept; base += 2 * BS) {
-      const int c0 = base + tid, c1 = base + BS + tid;
-      const bool v0 = c0 < nswept, v1 = c1 < nswept;
-      int q0, h0, q1, h1;
-      locate(v0 ? c0 : 0, q0, h0);
-      locate(v1 ? c1 : 0, q1, h1);
-      if (!v0) h0 = S.rt[kRtHeavy];  // any valid address
-      if (!v1) h1 = S.rt[kRtHeavy];
-      const double x0 = A.hx[h0], y0 = A.hy[h0], z0 = A.hz[h0], a0 = A.a_large[h0], w0 = A.v_large[h0], g0 = A.gam[h0];
-      const double x1 = A.hx[h1], y1 = A.hy[h1], z1 = A.hz[h1], a1 = A.a_large[h1], w1 = A.v_large[h1], g1 = A.gam[h1];
-      if (v0) consider(q0, h0, x0, y0, z0, a0, w0, g0);
-      if (v1) consider(q1, h1, x1, y1, z1, a1, w1, g1);
+    // positions only (the Gaussian parameters are fetched for the few near candidates in stage 2): every workgroup of the
+    // launch sweeps at the same time, and this traffic is what the L2 has to carry
+    constexpr int kSweep = 4;  // candidates per lane and trip
+    for (int base = 0; base < nswept; base += kSweep * BS) {
+      int qs[kSweep], hs[kSweep];
+      double xs[kSweep], ys[kSweep], zs[kSweep];
+#pragma unroll
+      for (int k = 0; k < kSweep; k++) {
+        const int c = base + k * BS + tid;
+        locate(c < nswept ? c : 0, qs[k], hs[k]);
+        if (c >= nswept) {
+          hs[k] = S.rt[kRtHeavy];  // any valid address
+          qs[k] = -1;
+        }
+        xs[k] = A.hx[hs[k]];
+        ys[k] = A.hy[hs[k]];
+        zs[k] = A.hz[hs[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < kSweep; k++)
+        if (qs[k] >= 0) consider(qs[k], hs[k], xs[k], ys[k], zs[k]);
     }
   }
   tree_barrier<NCAP>();
@@ -512,9 +516,11 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     for (int base = 0; base < nnear; base += BS) {
       const bool mine = base + tid < nnear;
       const int st = NCAP - 1 - (mine ? base + tid : 0);
-      const double xj = S.nd[0][st], yj = S.nd[1][st], zj = S.nd[2][st], aj = S.nd[3][st], vj = S.nd[4][st], gj = S.nd[5][st];
+      const double xj = S.nd[0][st], yj = S.nd[1][st], zj = S.nd[2][st];
       const int packed = __double2loint(S.nd[6][st]);
       const int q = mine ? packed >> 24 : 0;
+      const int hjn = mine ? packed & 0xffffff : 0;
+      const double aj = A.a_large[hjn], vj = A.v_large[hjn], gj = A.gam[hjn];
       double sv = 0.0, gvol = 0.0;
       if (mine) sv = dev_merge_volume2(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj, gvol);
       tree_barrier<NCAP>();  // the near records of this trip are in registers: accepted ones may take staging slots
