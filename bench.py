@@ -165,7 +165,9 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
-        if not kernel.finish(stream):  # True = a capacity overflow invalidated the run: time it again
+        # finish() reads the device's sticky overflow log: EVERY one of the K timed evaluations is accounted for, not
+        # just the last.  Non-zero = some were withheld (capacity negotiation still under way): time the run again.
+        if not kernel.finish(stream):
             elapsed = t1 - t0
             break
     if elapsed is None:
@@ -199,7 +201,8 @@ def main():
     if rank == 0:
         kernel.set_profiling(True)
         run_steps(W, K)
-        kernel.finish(stream)
+        if kernel.finish(stream):
+            raise SystemExit("bench: an evaluation of the profiling pass overflowed after the timed pass had settled")
         times = kernel.kernel_times()
         kernel.set_profiling(False)
         raw_us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in times.items() if v[1] > 0}

@@ -68,11 +68,18 @@ with torch.cuda.stream(side):  # warm-up outside the capture (allocations, capac
     forces()
     for _ in range(5):
         md_step()
-    assert kernel.finish(side.cuda_stream) is False
+    assert kernel.finish(side.cuda_stream) == 0
 torch.cuda.synchronize()
-graph = torch.cuda.CUDAGraph()
-with torch.cuda.graph(graph):
-    md_step()
+
+
+def capture():
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        md_step()
+    return g, kernel.generation()
+
+
+graph, generation = capture()
 
 print(f"{system.name}: {system.n} atoms, AGBNP1 + tethers, Langevin 300 K, 1 fs, engine on {torch.cuda.get_device_name(0)}")
 print('#"Step","AGBNP Energy (kJ/mole)","Temperature (K)"')
@@ -80,8 +87,14 @@ start = time.perf_counter()
 for step in range(1, nsteps + 1):
     graph.replay()
     if step % 1000 == 0:
-        if kernel.finish(torch.cuda.current_stream().cuda_stream):  # a step asked for a repeat (tree capacity)
-            print("  (capacity raised at step", step, "- that step's AGBNP contribution was incomplete)")
+        # the device logs every replayed step whose trees outgrew their store: such a step got NO AGBNP force (its
+        # outputs are withheld, never partial).  A production driver would roll back to its last checkpoint here.
+        missed = kernel.finish(torch.cuda.current_stream().cuda_stream)
+        if missed:
+            first = step - 1000 + kernel.withheld()[0] + 1
+            print(f"  ({missed} step(s) from step {first} on ran without the AGBNP term: tree capacity exceeded)")
+        if kernel.generation() != generation:  # the capacity variant was raised: the captured kernels are stale
+            graph, generation = capture()
         ke = 0.5 * float((mass * v * v).sum())
         print(f"{step},{float(ene):.4f},{2.0 * ke / (3 * system.n * kB):.2f}")
 torch.cuda.synchronize()

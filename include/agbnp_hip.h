@@ -46,7 +46,8 @@ int agbnp_hip_create(agbnp_hip_context** out, int num_particles, const double* r
 
 /* Replaces ReferenceCalcAGBNPForceKernel::copyParametersToContext (ReferenceAGBNPKernels.cpp:1796-1815):
  * gamma, alpha and charge may change; a changed particle count, radius (squared difference > 1e-6) or
- * heavy->hydrogen flip fails with AGBNP_HIP_ERR_PARAMETERS and the reference's message. */
+ * heavy->hydrogen flip fails with AGBNP_HIP_ERR_PARAMETERS and the reference's message.
+ * Synchronises the device (nothing of this context may be in flight) and rewrites the device copies in place. */
 int agbnp_hip_update_parameters(agbnp_hip_context* ctx, int num_particles, const double* radius, const double* gamma,
                                 const double* vdw_alpha, const double* charge, const int* ishydrogen);
 
@@ -60,16 +61,37 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556: forces and energy are ADDED to device
  * buffers, nothing is returned).  d_positions[3N], d_forces[3N], d_energy[1] are FP64 device
  * pointers on the context's device; `stream` is a hipStream_t (NULL = the context's own stream).
- * Asynchronous.  Call agbnp_hip_finish() before trusting the results. */
+ * Asynchronous: seven kernel launches, no host synchronisation, no allocation once the context has run on its
+ * current capacity variant -- any number of evaluations may be queued, or captured into a HIP graph and replayed,
+ * before agbnp_hip_finish().
+ *
+ * Overflow contract.  The overlap-tree stage works in fixed-capacity LDS stores; an evaluation whose trees
+ * outgrow them (or whose forest packing mispredicted) is INCOMPLETE.  Such an evaluation adds NOTHING to
+ * d_forces / d_energy -- the outputs are gated on the device -- and is entered in a log on the device that only
+ * agbnp_hip_finish() reads and clears.  So after any number of queued evaluations the caller's buffers hold
+ * exactly the sum of the complete ones, and finish() says which ones are missing (the analogue of the reference
+ * OpenCL platform's PanicButton protocol, OpenCLAGBNPKernels.cpp:3599-3634: forces invalidated, step retried). */
 int agbnp_hip_execute_device(agbnp_hip_context* ctx, const double* d_positions, double* d_forces, double* d_energy,
                              void* stream);
 
-/* Waits for `stream`, then checks the overflow words of the last evaluation.  Returns AGBNP_HIP_OK if the
- * results are valid.  If a capacity overflow happened, the context has switched to a larger
- * variant, *must_repeat is set to 1 and AGBNP_HIP_OK is returned: the caller must discard the
- * forces/energy of that evaluation and run it again (the analogue of the reference OpenCL
- * platform's PanicButton protocol, OpenCLAGBNPKernels.cpp:3599-3634). */
+/* Waits for `stream`, then reads and clears the overflow log.  *must_repeat = the number of evaluations enqueued
+ * since the previous agbnp_hip_finish() whose outputs were withheld (0: every one is complete and in the caller's
+ * buffers).  If it is not 0 the context has already prepared the repeat (one subtree per workgroup, and the next
+ * larger capacity variant if a single subtree did not fit): the caller runs those evaluations again -- their
+ * positions in enqueue order come from agbnp_hip_withheld_evaluations() -- and calls finish() again.
+ * Returns AGBNP_HIP_ERR_CAPACITY if a subtree exceeds the largest variant. */
 int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
+
+/* Which evaluations the LAST agbnp_hip_finish() found withheld: writes up to `capacity` indices (0 = the first
+ * evaluation enqueued after the finish before it; the log holds indices below 2048, later ones are only counted)
+ * and returns their total number (-1: null context). */
+int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, int capacity);
+
+/* Changes whenever kernel arguments that a captured HIP graph of agbnp_hip_execute_device has frozen go stale:
+ * after a finish() that raised the capacity variant or grew the scratch pools.  A caller that replays a graph
+ * compares the value at capture time with the current one after every finish() and re-captures on a difference.
+ * agbnp_hip_update_parameters() does NOT change it: parameters are rewritten in place at unchanged addresses. */
+unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
 
 /* Diagnostics of the LAST completed evaluation (test support; mirrors the quantities the reference
  * prints at verbose_level > 0, ReferenceAGBNPKernels.cpp:333-352,459-462,519).
@@ -103,7 +125,8 @@ int agbnp_hip_get_kernel_times(agbnp_hip_context* ctx, double* total_ms, long* l
 int agbnp_hip_num_particles(const agbnp_hip_context* ctx);
 int agbnp_hip_version(const agbnp_hip_context* ctx);
 
-/* Message of the last error on this context; with ctx == NULL, of the last failed agbnp_hip_create(). */
+/* Message of the last error on this context; with ctx == NULL, of the last failed agbnp_hip_create() on the
+ * calling thread (thread-local). */
 const char* agbnp_hip_last_error(const agbnp_hip_context* ctx);
 
 void agbnp_hip_destroy(agbnp_hip_context* ctx);

@@ -167,13 +167,30 @@ class HipCalcAGBNPForceKernel:
             raise OpenMMException(_lib.last_error(self._h))
 
     def finish(self, stream=None):
-        """Synchronise and validate the last device evaluation; returns True if it must be repeated."""
+        """Synchronise and read the device's overflow log: returns the number of evaluations enqueued since the
+        previous finish() whose forces and energy were WITHHELD on the device (0 = all complete).  Those must be
+        run again (see withheld()); the context has already switched to the packing / capacity variant they need."""
         self._need()
         rep = C.c_int(0)
         rc = _lib.load().agbnp_hip_finish(self._h, C.c_void_p(stream or 0), C.byref(rep))
         if rc != _lib.OK:
             raise OpenMMException(_lib.last_error(self._h))
-        return bool(rep.value)
+        return int(rep.value)
+
+    def withheld(self):
+        """Indices (enqueue order since the finish() before the last one) of the evaluations the last finish()
+        reported as withheld."""
+        self._need()
+        lib = _lib.load()
+        n = lib.agbnp_hip_withheld_evaluations(self._h, None, 0)
+        idx = np.zeros(max(n, 1), dtype=np.int32)
+        lib.agbnp_hip_withheld_evaluations(self._h, _ip(idx), n)
+        return [int(k) for k in idx[:min(n, 2048)]]
+
+    def generation(self):
+        """Changes when a captured HIP graph of execute_device has gone stale (capacity variant raised)."""
+        self._need()
+        return int(_lib.load().agbnp_hip_generation(self._h))
 
     def copyParametersToContext(self, force):
         self._need()

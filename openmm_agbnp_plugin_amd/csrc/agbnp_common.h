@@ -43,7 +43,10 @@ struct SubtreeHeader {
 constexpr int kCandCap = 128;
 constexpr int kCandRecDoubles = 8;
 
-// status/overflow word indices (device int array)
+// status/overflow word indices (device int array of kStatTotalWords).
+// Words [0, kStatEvalWords) belong to ONE evaluation: k_prep clears them.  The words from kStatEvalSeq on are STICKY:
+// they survive from one evaluation to the next, so that a caller who queues many evaluations (or replays a graph)
+// before agbnp_hip_finish still learns about every one that overflowed; only agbnp_hip_finish resets them.
 enum StatusWord {
   kStatNodeOverflow = 0,   // a subtree needed more than NCAP nodes
   kStatAtomOverflow = 1,   // a node had more than ACAP children / level-2 partners
@@ -55,7 +58,16 @@ enum StatusWord {
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
-  kStatWords = 16
+  kStatEvalWords = 10,     // ---- everything below is sticky
+  kStatEvalSeq = 10,       // evaluations enqueued since the last agbnp_hip_finish
+  kStatBadCount = 11,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
+  kStatStickyNode = 12,    // OR of the per-evaluation overflow words over those evaluations
+  kStatStickyAtom = 13,
+  kStatStickyPack = 14,
+  kStatWords = 16,
+  kStatBadBitmap = 16,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatBadBits = 2048,
+  kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };
 
 // kernel ids of one evaluation, in launch order (bench/profiling support)

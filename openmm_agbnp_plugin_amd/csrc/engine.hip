@@ -38,7 +38,7 @@ using namespace agbnp;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // message of the last failed agbnp_hip_create / host_tables on THIS thread
 
 template <class T>
 struct DevBuf {
@@ -50,9 +50,14 @@ struct DevBuf {
     if (n == 0) return hipSuccess;
     return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
   }
+  // Same size as before: the data is replaced IN PLACE and the device address stays what it was -- kernel
+  // arguments frozen into a captured HIP graph keep pointing at live memory across agbnp_hip_update_parameters.
   hipError_t upload(const std::vector<T>& v) {
-    hipError_t e = alloc(v.size());
-    if (e != hipSuccess || v.empty()) return e;
+    if (p == nullptr || count != v.size()) {
+      hipError_t e = alloc(v.size());
+      if (e != hipSuccess) return e;
+    }
+    if (v.empty()) return hipSuccess;
     return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
   }
   void release() {
@@ -105,7 +110,10 @@ struct agbnp_hip_context {
   Timeline timeline;
   double kernel_ms[kKernelCount] = {0};
   long kernel_launches[kKernelCount] = {0};
-  int last_status[kStatWords] = {0};
+  int last_status[kStatTotalWords] = {0};
+  std::vector<int> withheld;   // evaluations (numbered from the previous finish) that the last finish found withheld
+  int withheld_count = 0;
+  unsigned generation = 1;     // bumped whenever kernel arguments a captured graph has frozen go stale
   int tree_slots[4] = {1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
@@ -186,20 +194,26 @@ int ensure_scratch(agbnp_hip_context* c) {
   if (c->d_node_pool.count < need_nodes) {
     HIP_TRY(c, c->d_node_pool.alloc(need_nodes));
     c->T.node_pool = c->d_node_pool.p;
+    c->generation++;
   }
   const size_t need_pairs = c->variant == 0 ? 4 * need_nodes : 0;  // membership pairs of the 512-node variant
   if (c->d_pair_pool.count < need_pairs) {
     HIP_TRY(c, c->d_pair_pool.alloc(need_pairs));
     c->T.pair_pool = c->d_pair_pool.p;
+    c->generation++;
   }
   if (c->d_atom_pool.count < need_atoms) {
     HIP_TRY(c, c->d_atom_pool.alloc(need_atoms));
     c->T.atom_pool = c->d_atom_pool.p;
+    c->generation++;
   }
   if (c->variant != kGlobalVariant) return AGBNP_HIP_OK;
   const size_t stride = tree_variant_scratch_bytes(kGlobalVariant);
   const size_t need = stride * (size_t)std::min(kGlobalGrid, std::max(c->nh, 1));
-  if (c->d_scratch.count < need) HIP_TRY(c, c->d_scratch.alloc(need));
+  if (c->d_scratch.count < need) {
+    HIP_TRY(c, c->d_scratch.alloc(need));
+    c->generation++;
+  }
   c->T.scratch = c->d_scratch.p;
   c->T.scratch_stride = stride;
   return AGBNP_HIP_OK;
@@ -311,7 +325,10 @@ void wire_args(agbnp_hip_context* c) {
     P.round_permille = std::max(100, round_permille);
     static const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 1;
     static const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 720;
-    P.split_big = std::min(4, std::max(1, split_big));
+    // a full device has slot_cap = 2 x subtrees work slots: more parts per subtree than that could plan more work items
+    // than forest_start / order / the topology pools hold
+    P.split_big = std::min(std::min(4, c->slot_cap / std::max(c->nh, 1)), std::max(1, split_big));
+    P.split_big = std::max(1, P.split_big);
     P.split_permille = std::max(50, split_permille);
     T.forest_start = c->d_forest.p;
     T.nforests = c->d_forest.p + nhp1 + 1;
@@ -321,6 +338,8 @@ void wire_args(agbnp_hip_context* c) {
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
 }
+
+int upload_identity_packing(agbnp_hip_context* c);
 
 int allocate_work(agbnp_hip_context* c) {
   const int n = c->n, nh = c->nh;
@@ -359,8 +378,8 @@ int allocate_work(agbnp_hip_context* c) {
     if (nh == 0) c->d_db_items.count = 0;
   }
 
-  HIP_TRY(c, c->d_status.alloc(kStatWords));
-  HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatWords));
+  HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
+  HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
   HIP_TRY(c, c->d_hx.alloc(nhp));
   HIP_TRY(c, c->d_hy.alloc(nhp));
   HIP_TRY(c, c->d_hz.alloc(nhp));
@@ -396,18 +415,8 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
   {
-    std::vector<int> ident(4 * nhp + 8, 0);  // work items: up to four per subtree
-    for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
-    HIP_TRY(c, c->d_order.upload(ident));
-    // packing of the first evaluation: one subtree per work slot (nothing is known about the tree yet)
-    // layout: [0, nh] forest_start, [nh+1] number of forests, [nh+2] the count the running evaluation took
-    // [nh+3] how often a packed forest has overflowed so far
-    std::vector<int> forest(nslots + 4);
-    for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
-    forest[nslots + 1] = nh;
-    forest[nslots + 2] = nh;
-    forest[nslots + 3] = 0;
-    HIP_TRY(c, c->d_forest.upload(forest));
+    int rc = upload_identity_packing(c);  // the first evaluation: nothing is known about the tree yet
+    if (rc != AGBNP_HIP_OK) return rc;
   }
   HIP_TRY(c, c->d_hdr.alloc(nslots));
   HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nslots));
@@ -442,7 +451,28 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   return AGBNP_HIP_OK;
 }
 
-// after the stream is idle: read status + components; react to overflow.  *repeat = 1 if the caller must re-run.
+// one subtree per work slot (what a context starts with, and what an overflowed evaluation is repeated on)
+int upload_identity_packing(agbnp_hip_context* c) {
+  const size_t nhp = std::max(c->nh, 1), nslots = (size_t)c->slot_cap;
+  std::vector<int> ident(4 * nhp + 8, 0);  // work items: up to four per subtree
+  for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
+  HIP_TRY(c, c->d_order.upload(ident));
+  // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
+  // [slots+3] how often a packed forest has overflowed so far (kept)
+  std::vector<int> forest(nslots + 3);
+  for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
+  forest[nslots + 1] = c->nh;
+  forest[nslots + 2] = c->nh;
+  if (c->d_forest.p == nullptr) {
+    forest.push_back(0);
+    return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
+  }
+  HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
+  return AGBNP_HIP_OK;
+}
+
+// after the stream is idle: read status + components; react to overflow.  *repeat = number of evaluations since the
+// previous harvest whose forces and energy were withheld on the device (the caller must run those again).
 int harvest(agbnp_hip_context* c, int* repeat) {
   *repeat = 0;
   // per-kernel durations of everything enqueued since the last harvest
@@ -456,23 +486,31 @@ int harvest(agbnp_hip_context* c, int* repeat) {
     c->kernel_launches[id]++;
   }
   tl.used = 0;
-  HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatWords, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
-  if (s[kStatPackOverflow] && !s[kStatNodeOverflow] && !s[kStatAtomOverflow]) {
-    // a packed forest outgrew its store: the device has already fallen back to one subtree per slot and tightened
-    // its packing thresholds; same capacity variant, run the evaluation again
-    *repeat = 1;
-    return AGBNP_HIP_OK;
-  }
-  if (s[kStatNodeOverflow] || s[kStatAtomOverflow]) {
+  c->withheld.clear();
+  c->withheld_count = s[kStatBadCount];
+  // the last evaluation's own words say whether the diagnostics on the device are those of a complete evaluation
+  c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow]) : c->have_results;
+  if (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0)  // start a new log
+    HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
+  if (c->withheld_count == 0) return AGBNP_HIP_OK;
+  for (int k = 0; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
+    if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k);
+  *repeat = c->withheld_count;
+  // A repeat must not overflow for the same reason again: it runs one subtree per work slot (the packing of the
+  // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last) ...
+  int rc = upload_identity_packing(c);
+  if (rc != AGBNP_HIP_OK) return rc;
+  if (s[kStatStickyNode] || s[kStatStickyAtom]) {
+    // ... and, if a single subtree outgrew the store, on the next larger capacity variant
     if (c->variant >= kGlobalVariant)
       return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 255 partners per heavy atom)");
     c->variant++;
-    *repeat = 1;
-    return AGBNP_HIP_OK;
+    c->generation++;  // other kernels, other scratch: a captured graph of this context is stale
   }
-  c->have_results = true;
+  // (a packed forest that outgrew its store: the device has already tightened its packing thresholds)
   return AGBNP_HIP_OK;
 }
 
@@ -598,7 +636,9 @@ int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radiu
     c->charge[i] = charge[i];
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // the parameter arrays are rewritten in place (their addresses stay valid for captured graphs), so nothing of this
+  // context may be in flight on ANY stream: this is the platform's synchronisation point, as in the reference
+  HIP_TRY(c, hipDeviceSynchronize());
   int rc = upload_parameters(c);
   if (rc != AGBNP_HIP_OK) return rc;
   wire_args(c);
@@ -776,6 +816,14 @@ int agbnp_hip_host_tables(int n, const double* radius, const int* ishydrogen, in
   memcpy(type_screener, t.type_screener.data(), sizeof(int) * n);
   return AGBNP_HIP_OK;
 }
+
+int agbnp_hip_withheld_evaluations(const agbnp_hip_context* c, int* indices, int capacity) {
+  if (!c) return -1;
+  for (int k = 0; indices && k < capacity && k < (int)c->withheld.size(); k++) indices[k] = c->withheld[k];
+  return c->withheld_count;
+}
+
+unsigned agbnp_hip_generation(const agbnp_hip_context* c) { return c ? c->generation : 0u; }
 
 int agbnp_hip_num_particles(const agbnp_hip_context* c) { return c ? c->n : -1; }
 int agbnp_hip_version(const agbnp_hip_context* c) { return c ? c->version : -1; }

@@ -139,7 +139,10 @@ __device__ void candidate_tile(const PairArgs& P, int tile) {
 __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   if ((int)blockIdx.x >= prep_blocks) return candidate_tile(P, blockIdx.x - prep_blocks);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kStatWords && blockIdx.x == 0) P.status[i] = 0;
+  // the status words of ONE evaluation start from zero; the sticky ones (overflow log since the last
+  // agbnp_hip_finish) are left alone, and the evaluation takes its running number
+  if (i < kStatEvalWords && blockIdx.x == 0) P.status[i] = 0;
+  if (i == 0) P.status[kStatEvalSeq] += 1;
   if (i < P.nslots) {
     // bounding box of every block of 64 slots in pair order (one wave each) for the tile culling of the
     // chain-rule stage; padding slots are neutral
@@ -277,8 +280,27 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         components[1] = o1;
         components[2] = o2;
         components[3] = o3;
-        energy_out[0] += o0 + o1 + o2 + o3;
+        // An evaluation whose tree stage overflowed (capacity or forest packing: the words are final once
+        // k_tree_cavity has ended) is incomplete: NOTHING of it reaches the caller's buffers -- here the energy,
+        // in k_outputs the forces -- and it is entered in the sticky log that agbnp_hip_finish reports, so that
+        // queued or graph-replayed evaluations cannot lose an overflow to the next evaluation's k_prep.  This
+        // role runs exactly once per evaluation, after the tree stage.
+        const int node = P.status[kStatNodeOverflow], atom = P.status[kStatAtomOverflow], pack = P.status[kStatPackOverflow];
+        if ((node | atom | pack) == 0) {
+          energy_out[0] += o0 + o1 + o2 + o3;
+        } else {
+          const int seq = P.status[kStatEvalSeq] - 1;  // k_prep counted this evaluation in
+          P.status[kStatBadCount] += 1;
+          P.status[kStatStickyNode] |= node;
+          P.status[kStatStickyAtom] |= atom;
+          P.status[kStatStickyPack] |= pack;
+          if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
+        }
       }
+}
+
+__device__ __forceinline__ bool evaluation_overflowed(const int* __restrict__ status) {
+  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow]) != 0;
 }
 
 // Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes
@@ -856,6 +878,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     fy += P.gb_fy[i] + P.db_fy[i];
     fz += P.gb_fz[i] + P.db_fz[i];
   }
+  if (evaluation_overflowed(P.status)) return;  // incomplete evaluation: withheld (see energy_role), the caller repeats it
   force_out[3 * i] += fx;
   force_out[3 * i + 1] += fy;
   force_out[3 * i + 2] += fz;
@@ -878,7 +901,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_MARK(kKPrep);
-  const int n = std::max(std::max(P.n, P.nslots), (int)kStatWords);
+  const int n = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
   const int prep_blocks = (n + 255) / 256;
   hipLaunchKernelGGL(k_prep, dim3(prep_blocks + P.cand_items_count), dim3(256), 0, st, P, prep_blocks);
   return hipGetLastError();

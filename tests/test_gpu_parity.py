@@ -149,7 +149,7 @@ def test_device_resident_entry_point(gpu_required, systems):
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
-    assert k.finish(stream) is False
+    assert k.finish(stream) == 0
     eo, fo = Oracle(*s.params(), version=1).execute(s.pos)
     assert abs((ene.item() - 10.0) / 3 - eo) < TIGHT
     assert np.abs((frc.cpu().numpy() - 1.5) / 3 - fo).max() < TIGHT
@@ -169,7 +169,7 @@ def test_evaluation_is_graph_capturable(gpu_required, systems):
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):  # warm-up outside the capture: scratch allocation, capacity negotiation
         k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), side.cuda_stream)
-        assert k.finish(side.cuda_stream) is False
+        assert k.finish(side.cuda_stream) == 0
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         frc.zero_()
@@ -184,6 +184,121 @@ def test_evaluation_is_graph_capturable(gpu_required, systems):
         eo, fo = oracle.execute(geometry)
         assert abs(ene.item() - eo) < TIGHT
         assert np.abs(frc.cpu().numpy() - fo).max() < TIGHT
+
+
+@pytest.mark.parametrize("squeeze", [0.97, 0.85])
+def test_queued_evaluations_withhold_an_overflowed_one(gpu_required, systems, squeeze):
+    """Several evaluations are queued on a stream before agbnp_hip_finish; the middle one overflows -- squeeze 0.97:
+    the trees grow by a quarter, so the packed forests do not fit (every subtree still fits the (512, 64) store);
+    squeeze 0.85: a subtree reaches 1977 nodes, two capacity variants up.  The overflowed evaluation must add
+    NOTHING to the caller's buffers, finish() must name it although later evaluations have long reset the
+    per-evaluation status words, and repeating it afterwards must complete the sums."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    geoms = [s.jittered(0), s.jittered(1), centre + squeeze * (s.pos - centre), s.jittered(2), s.jittered(3)]
+    oracle = Oracle(*s.params(), version=1)
+    want = [oracle.execute(g) for g in geoms]
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    run = lambda i: k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    for i in (0, 1):  # settle: the second evaluation already runs on packed forests
+        run(i)
+    assert k.finish(stream) == 0
+    frc.zero_()
+    ene.zero_()
+    for i in range(5):
+        run(i)
+    assert k.finish(stream) == 1
+    assert k.withheld() == [2]
+    clean = [0, 1, 3, 4]
+    assert abs(ene.item() - sum(want[i][0] for i in clean)) < 4 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(want[i][1] for i in clean)).max() < 4 * TIGHT
+    gen = k.generation()
+    for attempt in range(3):  # one repeat per capacity variant the squeezed trees have to climb
+        run(2)
+        if k.finish(stream) == 0:
+            break
+        assert k.withheld() == [0]
+    else:
+        raise AssertionError("the repeat did not converge")
+    assert (k.generation() != gen) == (squeeze < 0.9)  # a captured graph would be stale only after a variant change
+    assert abs(ene.item() - sum(w[0] for w in want)) < 5 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 5 * TIGHT
+    assert k.finish(stream) == 0  # an empty log stays empty
+
+
+def test_graph_replay_survives_parameter_updates_and_reports_staleness(gpu_required, systems):
+    """A captured evaluation keeps working after updateParametersInContext (device copies are rewritten in place) and
+    the generation counter tells the caller when a re-capture is due (capacity variant raised by an overflow that a
+    replayed step reported through the sticky log)."""
+    torch = pytest.importorskip("torch")
+    s = systems("fixture264")
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(force)
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(s.pos, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    side = torch.cuda.Stream()
+
+    def capture():
+        with torch.cuda.stream(side):
+            k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), side.cuda_stream)
+            assert k.finish(side.cuda_stream) == 0
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            frc.zero_()
+            ene.zero_()
+            k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return g, k.generation()
+
+    def replay_and_compare(graph, oracle, geometry):
+        pos.copy_(torch.tensor(geometry, dtype=torch.float64))
+        graph.replay()
+        torch.cuda.synchronize()
+        eo, fo = oracle.execute(geometry)
+        assert abs(ene.item() - eo) < TIGHT and np.abs(frc.cpu().numpy() - fo).max() < TIGHT
+
+    graph, gen = capture()
+    replay_and_compare(graph, Oracle(*s.params(), version=1), s.jittered(0))
+    # new charges and alphas: same graph, new numbers
+    for i in range(s.n):
+        r, g, a, q, h = force.getParticleParameters(i)
+        force.setParticleParameters(i, r, g, a * 0.7, q * 1.1, h)
+    k.copyParametersToContext(force)
+    assert k.generation() == gen
+    oracle2 = Oracle(s.radius, s.gamma, s.alpha * 0.7, s.charge * 1.1, s.ishydrogen, version=1)
+    replay_and_compare(graph, oracle2, s.jittered(1))
+    # a replayed step on a geometry that outgrows the store (5527-node subtree): withheld, logged, variant raised
+    centre = s.pos.mean(axis=0)
+    squeezed = centre + 0.8 * (s.pos - centre)
+    pos.copy_(torch.tensor(squeezed, dtype=torch.float64))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert ene.item() == 0.0 and not frc.cpu().numpy().any()  # zeroed inside the graph, nothing added
+    pos.copy_(torch.tensor(s.pos, dtype=torch.float64))
+    graph.replay()
+    assert k.finish(torch.cuda.current_stream().cuda_stream) == 1 and k.withheld() == [0]
+    assert k.generation() != gen
+    for _ in range(4):  # climb to the variant that holds the squeezed trees, re-capturing as the counter asks
+        graph, gen = None, None
+        pos.copy_(torch.tensor(squeezed, dtype=torch.float64))
+        with torch.cuda.stream(side):
+            k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), side.cuda_stream)
+            if k.finish(side.cuda_stream) == 0:
+                break
+    graph, gen = capture()
+    replay_and_compare(graph, oracle2, squeezed)
+    replay_and_compare(graph, oracle2, s.pos)
 
 
 def test_update_parameters_in_context(gpu_required, systems):
