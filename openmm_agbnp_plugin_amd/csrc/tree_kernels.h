@@ -442,12 +442,16 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? max(S.rt[kRtCand + q], 0) : 0);
     const int nlisted = off[kMaxRoots];
     auto fetch = [&](int c, int& q, int& hj, double2& r0, double2& r1, double2& r2) {
+      // root of candidate c and the start of that root's range: one fused pass over the (non-decreasing) offsets.
+      // (Looking off[q] up after the count makes the compiler index the array dynamically, i.e. put it in scratch.)
       q = 0;
+      int o = 0;
 #pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
-      int o = off[0];
-#pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
+      for (int k = 1; k < kMaxRoots; k++) {
+        const bool past = k < m && c >= off[k];
+        q += past ? 1 : 0;
+        o = past ? off[k] : o;
+      }
       const double2* rec = reinterpret_cast<const double2*>(A.cand_rec + ((size_t)S.rt[kRtHeavy + q] * kCandCap + (c - o)) * kCandRecDoubles);
       r0 = rec[0];
       r1 = rec[1];
@@ -477,11 +481,13 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     const int nswept = off[kMaxRoots];
     auto locate = [&](int c, int& q, int& hj) {  // concatenated index -> (root, heavy atom)
       q = 0;
+      int o = 0;
 #pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) q += (k < m && c >= off[k]) ? 1 : 0;
-      int o = off[0];
-#pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) o = (k <= q) ? off[k] : o;
+      for (int k = 1; k < kMaxRoots; k++) {  // fused: see fetch
+        const bool past = k < m && c >= off[k];
+        q += past ? 1 : 0;
+        o = past ? off[k] : o;
+      }
       hj = S.rt[kRtHeavy + q] + 1 + (c - o);
     };
     // positions only (the Gaussian parameters are fetched for the few near candidates in stage 2): every workgroup of the
