@@ -88,11 +88,14 @@ struct agbnp_hip_context {
   // static device data
   DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot, d_cand_count;
   DevBuf<double> d_cand_rec;
-  DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_h, d_gam_cav, d_a_large, d_v_large, d_a_vdw, d_v_vdw;
+  DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
+  DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
+  size_t hstride = 64;
+  double* hrow(int r) const { return d_heavy.p + (size_t)r * hstride; }
   DevBuf<int2> d_ameta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
-  DevBuf<double> d_pbox, d_hx, d_hy, d_hz, d_gx, d_gy, d_gz, d_sv_vdw, d_sv_large, d_gam, d_epart;
+  DevBuf<double> d_pbox, d_epart;
   DevBuf<double4> d_aposq;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -176,12 +179,20 @@ int upload_parameters(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_charge.upload(c->charge));
   HIP_TRY(c, c->d_alpha.upload(c->alpha));
   HIP_TRY(c, c->d_inv_rvdw.upload(inv_rvdw));
-  HIP_TRY(c, c->d_inv_vol_h.upload(inv_vol_h));
-  HIP_TRY(c, c->d_gam_cav.upload(gam_cav));
-  HIP_TRY(c, c->d_a_large.upload(a_large));
-  HIP_TRY(c, c->d_v_large.upload(v_large));
-  HIP_TRY(c, c->d_a_vdw.upload(a_vdw));
-  HIP_TRY(c, c->d_v_vdw.upload(v_vdw));
+  if (c->d_heavy.p == nullptr) {
+    c->hstride = ((size_t)std::max(nh, 1) + 63) / 64 * 64;
+    HIP_TRY(c, c->d_heavy.alloc((size_t)kHvRows * c->hstride));
+    HIP_TRY(c, hipMemset(c->d_heavy.p, 0, sizeof(double) * kHvRows * c->hstride));
+  }
+  auto put = [&](int row, const std::vector<double>& v) {  // in place: the addresses stay valid for captured graphs
+    return v.empty() ? hipSuccess : hipMemcpy(c->hrow(row), v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice);
+  };
+  HIP_TRY(c, put(kHvInvVol, inv_vol_h));
+  HIP_TRY(c, put(kHvGam, gam_cav));
+  HIP_TRY(c, put(kHvALarge, a_large));
+  HIP_TRY(c, put(kHvVLarge, v_large));
+  HIP_TRY(c, put(kHvAVdw, a_vdw));
+  HIP_TRY(c, put(kHvVVdw, v_vdw));
   c->T.rcut2 = overlap_search_cutoff2(a_large, v_large);
   return AGBNP_HIP_OK;
 }
@@ -228,16 +239,16 @@ void wire_args(agbnp_hip_context* c) {
   P.charge = c->d_charge.p;
   P.alpha = c->d_alpha.p;
   P.inv_rvdw = c->d_inv_rvdw.p;
-  P.inv_vol_h = c->d_inv_vol_h.p;
-  P.gam_cav = c->d_gam_cav.p;
+  P.inv_vol_h = c->hrow(kHvInvVol);
+  P.gam_cav = c->hrow(kHvGam);
   P.ameta = c->d_ameta.p;
   P.lut = c->d_lut.p;
   P.nti = c->lut.nscreened;
   P.ntj = c->lut.nscreener;
   P.lut_entries = c->lut.nscreened * c->lut.nscreener * kI4Nodes;
-  P.hx = c->d_hx.p;
-  P.hy = c->d_hy.p;
-  P.hz = c->d_hz.p;
+  P.hx = c->hrow(kHvX);
+  P.hy = c->hrow(kHvY);
+  P.hz = c->hrow(kHvZ);
   P.aposq = c->d_aposq.p;
   P.pbox = c->d_pbox.p;
   P.pslot = c->d_pslot.p;
@@ -245,12 +256,11 @@ void wire_args(agbnp_hip_context* c) {
   P.nhb = (c->nh + 63) / 64;
   P.db_items = c->d_db_items.p;
   P.db_items_count = (int)c->d_db_items.count;
-  P.gx = c->d_gx.p;
-  P.gy = c->d_gy.p;
-  P.gz = c->d_gz.p;
-  P.sv_vdw = c->d_sv_vdw.p;
-  P.sv_large = c->d_sv_large.p;
-  P.gam = c->d_gam.p;
+  P.gx = c->hrow(kHvGx);
+  P.gy = c->hrow(kHvGy);
+  P.gz = c->hrow(kHvGz);
+  P.sv_vdw = c->hrow(kHvSvVdw);
+  P.sv_large = c->hrow(kHvSvLarge);
   P.epart = c->d_epart.p;
   P.status = c->d_status.p;
   P.born_part = c->d_born_part.p;
@@ -273,22 +283,10 @@ void wire_args(agbnp_hip_context* c) {
 
   TreeArgs& T = c->T;
   T.nh = c->nh;
-  T.hx = c->d_hx.p;
-  T.hy = c->d_hy.p;
-  T.hz = c->d_hz.p;
-  T.a_large = c->d_a_large.p;
-  T.v_large = c->d_v_large.p;
-  T.a_vdw = c->d_a_vdw.p;
-  T.v_vdw = c->d_v_vdw.p;
-  T.gam = c->d_gam.p;
+  T.hv = c->d_heavy.p;
+  T.hstride = (unsigned)c->hstride;
   T.db_wu = c->d_dbf.p + 3 * (size_t)c->n;
-  T.inv_vol_h = c->d_inv_vol_h.p;
-  T.h2a = c->d_h2a.p;
-  T.gx = c->d_gx.p;
-  T.gy = c->d_gy.p;
-  T.gz = c->d_gz.p;
-  T.sv_large = c->diagnostics ? c->d_sv_large.p : nullptr;  // pass-1 self volumes cost extra HBM atomics: opt-in
-  T.sv_vdw = c->d_sv_vdw.p;
+  T.want_sv_large = c->diagnostics ? 1 : 0;  // pass-1 self volumes cost extra HBM atomics: opt-in
   T.epart = c->d_epart.p;
   T.hdr = c->d_hdr.p;
   T.node_pool = c->d_node_pool.p;
@@ -298,8 +296,8 @@ void wire_args(agbnp_hip_context* c) {
   T.sizes = c->d_sizes.p;
   P.order = c->d_order.p;
   T.order = c->d_order.p;
-  P.a_large = c->d_a_large.p;
-  P.v_large = c->d_v_large.p;
+  P.a_large = c->hrow(kHvALarge);
+  P.v_large = c->hrow(kHvVLarge);
   P.rcut2 = c->T.rcut2;
   // the level-2 candidate lists pay from a few thousand heavy atoms on (see build_forest); AGBNP_HIP_CAND_LISTS=0/1 forces
   static const char* cand_env = getenv("AGBNP_HIP_CAND_LISTS");
@@ -330,9 +328,8 @@ void wire_args(agbnp_hip_context* c) {
     P.split_big = std::min(std::min(4, c->slot_cap / std::max(c->nh, 1)), std::max(1, split_big));
     P.split_big = std::max(1, P.split_big);
     P.split_permille = std::max(50, split_permille);
-    T.forest_start = c->d_forest.p;
-    T.nforests = c->d_forest.p + nhp1 + 1;
-    T.cur_nforests = c->d_forest.p + nhp1 + 2;
+    T.packing = c->d_forest.p;
+    T.slot_cap = c->slot_cap;
   }
   T.status = c->d_status.p;
   T.scratch = c->d_scratch.p;
@@ -380,15 +377,6 @@ int allocate_work(agbnp_hip_context* c) {
 
   HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
-  HIP_TRY(c, c->d_hx.alloc(nhp));
-  HIP_TRY(c, c->d_hy.alloc(nhp));
-  HIP_TRY(c, c->d_hz.alloc(nhp));
-  HIP_TRY(c, c->d_gx.alloc(nhp));
-  HIP_TRY(c, c->d_gy.alloc(nhp));
-  HIP_TRY(c, c->d_gz.alloc(nhp));
-  HIP_TRY(c, c->d_sv_vdw.alloc(nhp));
-  HIP_TRY(c, c->d_sv_large.alloc(nhp));
-  HIP_TRY(c, c->d_gam.alloc(nhp));
   {
     // level-2 candidate search: tiles of 64x64 heavy atoms (I <= J), per-atom record lists
     const int nhb = (nh + 63) / 64;
@@ -724,15 +712,15 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
     return AGBNP_HIP_OK;
   };
   switch (which) {
-    case 0: return heavy_to_atoms(c->d_sv_vdw.p, 0.0);
+    case 0: return heavy_to_atoms(c->hrow(kHvSvVdw), 0.0);
     case 1:
       if (c->version != 1) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "Born radii exist for version 1 only");
       HIP_TRY(c, hipMemcpy(out, c->d_born.p, sizeof(double) * n, hipMemcpyDeviceToHost));
       return AGBNP_HIP_OK;
-    case 2: return heavy_to_atoms(c->d_sv_vdw.p, 1.0);
+    case 2: return heavy_to_atoms(c->hrow(kHvSvVdw), 1.0);
     case 3:
       if (!c->diagnostics) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "enlarged-radius self volumes need agbnp_hip_set_diagnostics(ctx, 1) before the evaluation");
-      return heavy_to_atoms(c->d_sv_large.p, 0.0);
+      return heavy_to_atoms(c->hrow(kHvSvLarge), 0.0);
     case 4:
     case 5: {  // overlap-tree shape: nodes / local atoms of the subtree rooted at every heavy atom (0 for hydrogens)
       std::vector<int2> sz(std::max(nh, 1));

@@ -37,7 +37,6 @@ struct PairArgs {
   // ---- tree accumulators / outputs
   double *gx, *gy, *gz;    // [nh]
   double *sv_vdw, *sv_large;  // [nh]
-  double* gam;             // [nh] nu of the current tree pass
   double* epart;           // [2nh]
   int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
   int* order;              // [4 nh] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation, by forest

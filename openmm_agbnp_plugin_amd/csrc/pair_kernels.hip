@@ -186,7 +186,6 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.gz[h] = 0.0;
     P.sv_vdw[h] = 0.0;
     P.sv_large[h] = 0.0;
-    P.gam[h] = P.gam_cav[h];
     P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
   }
 }

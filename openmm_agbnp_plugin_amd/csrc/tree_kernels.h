@@ -38,36 +38,49 @@
 
 namespace agbnp {
 
+// Rows of the heavy-atom table: ONE device allocation [kHvRows][hstride] of doubles, heavy index.  The tree kernels
+// address it as base + (row * hstride + h): one 64-bit base in scalar registers instead of fifteen pointers (the
+// build kernel keeps ~100 scalar values live as it is; every pointer less is two fewer spilled).
+enum HeavyRow {
+  kHvX = 0, kHvY, kHvZ,        // positions (written by k_prep)
+  kHvALarge, kHvVLarge,        // Gaussian exponent / volume, enlarged radii
+  kHvAVdw, kHvVVdw,            // ... vdW radii
+  kHvGam,                      // gamma / roffset (pass 1 uses +gam, pass 2 -gam)
+  kHvInvVol,                   // 1 / (4 pi R^3 / 3), vdW radius
+  kHvGx, kHvGy, kHvGz,         // gradient accumulators (dE/dr)
+  kHvSvLarge, kHvSvVdw,        // self volumes (enlarged radii: diagnostic)
+  kHvRows
+};
+
 struct TreeArgs {
-  int nh;  // heavy atoms
-  const int* order;            // [nh] subtrees sorted by the previous evaluation's node count, descending
-  const int* forest_start;     // [nh+1] work slot s builds the subtrees order[forest_start[s] .. forest_start[s+1])
-  const int* cand_count;       // [nh] level-2 candidates listed by the k_prep launch (see kCandCap)
+  int nh;                      // heavy atoms
+  unsigned hstride;            // row stride of the heavy-atom table
+  double* hv;                  // [kHvRows][hstride]
+  int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
+  const int* order;            // [<= 4 nh] work items, by forest
+  const int* packing;          // [slot_cap + 1] forest_start: work slot s builds order[packing[s] .. packing[s+1]);
+                               // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
+                               // pair stages run), [slot_cap + 2] the copy k_tree_cavity takes for THIS evaluation
+  int slot_cap;
+  const int* cand_count;       // [nh] level-2 candidates listed by the k_prep launch (see kCandCap); null: no lists
   const double* cand_rec;      // [nh][kCandCap][kCandRecDoubles]
-  const int* nforests;         // [1] work slots in use (rewritten for the NEXT evaluation while this one's pair stages run)
-  int* cur_nforests;           // [1] copy taken by k_tree_cavity: the count the later kernels of THIS evaluation use
-  const double *hx, *hy, *hz;  // heavy-atom positions (SoA, heavy index)
-  const double *a_large, *v_large, *a_vdw, *v_vdw;  // Gaussian exponent / volume per heavy atom
-  const double* gam;  // per heavy atom: gamma/roffset (pass 1 uses +gam, pass 2 uses -gam)
   // pass 3 (pseudo-volume): nu_i = (W_i + U_i) / V_i (ReferenceAGBNPKernels.cpp:718-722,738-742), formed on the fly
-  const double* db_wu;      // [nh] W+U per heavy atom
-  const double* inv_vol_h;  // [nh]
-  const int* h2a;           // [nh]
-  double rcut2;       // conservative squared cutoff of the 2-body overlap search
-  double* gx;         // [nh] gradient accumulators (dE/dr), heavy index
-  double* gy;
-  double* gz;
-  double* sv_large;   // [nh] self volumes with enlarged radii (diagnostic; may be null)
-  double* sv_vdw;     // [nh] self volumes with vdW radii
-  double* epart;      // [2*nh] cavity energies E1,E2 per subtree
-  SubtreeHeader* hdr;  // [nh] by work slot
-  int2* sizes;         // [nh] {nodes, local atoms} of every subtree, compact copy for the bookkeeping block
-  unsigned long long* node_pool;  // [nh][NCAP] atom path of every node (all a replay needs), fixed stride per subtree
-  int* atom_pool;      // [nh][ACAP] local atom -> heavy index
-  unsigned short* pair_pool;  // [nh][4 NCAP] (atom, node) membership pairs sorted by atom (LDS variants up to 512 nodes)
-  int* status;  // [kStatWords]
-  char* scratch;  // GLOBAL variant: per-workgroup slab
+  const double* db_wu;         // [nh] W+U per heavy atom
+  double rcut2;                // conservative squared cutoff of the 2-body overlap search
+  double* epart;               // [2 * slots] cavity energies E1, E2 per work slot
+  SubtreeHeader* hdr;          // [slots] by work slot
+  int2* sizes;                 // [nh] {nodes, local atoms} of every subtree, compact copy for the bookkeeping block
+  unsigned long long* node_pool;  // [slots][NCAP] atom path of every node (all a replay needs), fixed stride per slot
+  int* atom_pool;              // [slots][ACAP] local atom -> heavy index
+  unsigned short* pair_pool;   // [slots][4 NCAP] (atom, node) membership pairs sorted by atom (variants up to 512 nodes)
+  int* status;                 // [kStatTotalWords]
+  char* scratch;               // GLOBAL variant: per-workgroup slab
   size_t scratch_stride;
+
+  __device__ __forceinline__ double& hvat(int row, int h) const { return hv[(unsigned)row * hstride + (unsigned)h]; }
+  __device__ __forceinline__ const int* forest_start() const { return packing; }
+  __device__ __forceinline__ const int* nforests() const { return packing + slot_cap + 1; }
+  __device__ __forceinline__ int* cur_nforests() const { return const_cast<int*>(packing) + slot_cap + 2; }
 };
 
 constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of the BS template parameter)
@@ -361,8 +374,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   if (tid < m) {
     const int item = roots[tid];
     const int hi = work_item_root(item);
-    const double rx = A.hx[hi], ry = A.hy[hi], rz = A.hz[hi];
-    const double ra = A.a_large[hi], rv = A.v_large[hi], rg = A.gam[hi];
+    const double rx = A.hvat(kHvX, hi), ry = A.hvat(kHvY, hi), rz = A.hvat(kHvZ, hi);
+    const double ra = A.hvat(kHvALarge, hi), rv = A.hvat(kHvVLarge, hi), rg = A.hvat(kHvGam, hi);
     S.at[0][tid] = rx;
     S.at[1][tid] = ry;
     S.at[2][tid] = rz;
@@ -504,9 +517,9 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           hs[k] = S.rt[kRtHeavy];  // any valid address
           qs[k] = -1;
         }
-        xs[k] = A.hx[hs[k]];
-        ys[k] = A.hy[hs[k]];
-        zs[k] = A.hz[hs[k]];
+        xs[k] = A.hvat(kHvX, hs[k]);
+        ys[k] = A.hvat(kHvY, hs[k]);
+        zs[k] = A.hvat(kHvZ, hs[k]);
       }
 #pragma unroll
       for (int k = 0; k < kSweep; k++)
@@ -526,7 +539,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       const int packed = __double2loint(S.nd[6][st]);
       const int q = mine ? packed >> 24 : 0;
       const int hjn = mine ? packed & 0xffffff : 0;
-      const double aj = A.a_large[hjn], vj = A.v_large[hjn], gj = A.gam[hjn];
+      const double aj = A.hvat(kHvALarge, hjn), vj = A.hvat(kHvVLarge, hjn), gj = A.hvat(kHvGam, hjn);
       double sv = 0.0, gvol = 0.0;
       if (mine) sv = dev_merge_volume2(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj, gvol);
       tree_barrier<NCAP>();  // the near records of this trip are in registers: accepted ones may take staging slots

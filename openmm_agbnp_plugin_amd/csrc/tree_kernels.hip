@@ -69,16 +69,16 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
-  int nforests = A.nforests[0];
+  int nforests = A.nforests()[0];
   if (!GLOBAL && nforests > (int)gridDim.x) {  // more work slots planned than launched: report it, the host repeats unpacked
     if (blockIdx.x == 0 && tid == 0) atomicAdd(&A.status[kStatPackOverflow], 1);
     nforests = gridDim.x;
   }
-  if (blockIdx.x == 0 && tid == 0) A.cur_nforests[0] = nforests;
+  if (blockIdx.x == 0 && tid == 0) A.cur_nforests()[0] = nforests;
 
   for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
-    const int f0 = A.forest_start[slot];
-    const int m = A.forest_start[slot + 1] - f0;  // 1..kMaxRoots roots, largest forests first
+    const int f0 = A.forest_start()[slot];
+    const int m = A.forest_start()[slot + 1] - f0;  // 1..kMaxRoots roots, largest forests first
     const int* roots = A.order + f0;
     for (int la = tid; la < ACAP; la += BS) {
       S.at[6][la] = 0.0;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
     // LDS variants: one atom per lane)
     const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : work_item_root(roots[0]);
-    const double a_vdw_mine = A.a_vdw[hj_mine], v_vdw_mine = A.v_vdw[hj_mine];
-    const bool want_sv1 = A.sv_large != nullptr;
+    const double a_vdw_mine = A.hvat(kHvAVdw, hj_mine), v_vdw_mine = A.hvat(kHvVVdw, hj_mine);
+    const bool want_sv1 = A.want_sv_large != 0;
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
     // The node slots still hold the Gaussians of the build, so only the atom paths and the membership list are
     // laid down before the gather.  Its gradient stays in the local accumulators and leaves with that of pass 2.
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     }
     if (want_sv1) {  // diagnostics: enlarged-radius self volumes
       for (int la = tid; la < natoms; la += BS) {
-        glb_add(&A.sv_large[S.at_gidx[la]], (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+        glb_add(&A.hvat(kHvSvLarge, S.at_gidx[la]), (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
         S.at[9][la] = 0.0;
       }
     }
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     } else {
       for (int la = tid; la < natoms; la += BS) {
         const int hj = S.at_gidx[la];
-        S.at[3][la] = A.a_vdw[hj];
-        S.at[4][la] = A.v_vdw[hj];
+        S.at[3][la] = A.hvat(kHvAVdw, hj);
+        S.at[4][la] = A.hvat(kHvVVdw, hj);
         S.at[5][la] = -S.at[5][la];
       }
     }
@@ -187,10 +187,10 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     // ---- flush per-atom sums (a root's self volume: its own sphere + every node of its tree)
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
-      glb_add(&A.gx[hj], S.at[6][la]);
-      glb_add(&A.gy[hj], S.at[7][la]);
-      glb_add(&A.gz[hj], S.at[8][la]);
-      glb_add(&A.sv_vdw[hj], (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+      glb_add(&A.hvat(kHvSvVdw, hj), (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
     }
     if (tid == 0) {
       double e2 = e_sum;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
   TreeStore<NCAP, ACAP> S;
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   const int tid = threadIdx.x;
-  const int nforests = A.cur_nforests[0];
+  const int nforests = A.cur_nforests()[0];
   for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
     PSTAMP_BEGIN();
     // One round trip to the stored topology: the paths, the membership list and the local atom list are requested
@@ -259,12 +259,12 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     for (int la = tid; la < natoms; la += BS) {
       const int hj = GLOBAL ? A.atom_pool[atom_off + la] : hj_pre;
       S.at_gidx[la] = hj;
-      S.at[0][la] = A.hx[hj];
-      S.at[1][la] = A.hy[hj];
-      S.at[2][la] = A.hz[hj];
-      S.at[3][la] = A.a_vdw[hj];
-      S.at[4][la] = A.v_vdw[hj];
-      S.at[5][la] = A.db_wu[hj] * A.inv_vol_h[hj];
+      S.at[0][la] = A.hvat(kHvX, hj);
+      S.at[1][la] = A.hvat(kHvY, hj);
+      S.at[2][la] = A.hvat(kHvZ, hj);
+      S.at[3][la] = A.hvat(kHvAVdw, hj);
+      S.at[4][la] = A.hvat(kHvVVdw, hj);
+      S.at[5][la] = A.db_wu[hj] * A.hvat(kHvInvVol, hj);
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
       S.at[8][la] = 0.0;
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     for (int la = tid; la < natoms; la += BS) {
       const int hj = S.at_gidx[la];
-      glb_add(&A.gx[hj], S.at[6][la]);
-      glb_add(&A.gy[hj], S.at[7][la]);
-      glb_add(&A.gz[hj], S.at[8][la]);
+      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
     }
     tree_barrier<NCAP>();
     PSTAMP(2);
