@@ -36,12 +36,13 @@ struct SubtreeHeader {
   int partners[8];  // level-2 partners of every root
 };
 
-// Level-2 candidates of every heavy atom (younger heavy atoms inside the conservative overlap cutoff), found by
-// the tile workgroups of the k_prep launch: up to kCandCap records of 8 doubles {x, y, z, exponent, volume, gamma,
-// heavy index (as an integer in the bits of a double), unused}.  A root with more candidates than that (dense
-// synthetic systems) is searched the long way by its tree workgroup.
-constexpr int kCandCap = 128;
-constexpr int kCandRecDoubles = 8;
+// Level-2 neighbour masks: for every heavy atom i and every block J of 64 heavy atoms (J >= the block of i), one
+// 64-bit word whose bit b says "heavy atom 64 J + b is YOUNGER than i (larger index) and inside the conservative
+// overlap cutoff".  Written by the tile workgroups of the k_prep launch (one per 64x64 tile, I <= J, each position
+// read once per tile), laid out [J][i] so that a tile stores 64 consecutive words; the tree workgroup of root i reads
+// its row of <= nhb words in one round trip and expands the set bits into the near-candidate list.  (Every tree
+// workgroup sweeping all younger positions itself moved 50 MB through the L2 per evaluation of 1dwc -- the sweep
+// was bound by that, not by its arithmetic.)
 
 // status/overflow word indices (device int array of kStatTotalWords).
 // Words [0, kStatEvalWords) belong to ONE evaluation: k_prep clears them.  The words from kStatEvalSeq on are STICKY:

@@ -86,8 +86,8 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot, d_cand_count;
-  DevBuf<double> d_cand_rec;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot;
+  DevBuf<unsigned long long> d_nbmask;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
   size_t hstride = 64;
@@ -299,15 +299,11 @@ void wire_args(agbnp_hip_context* c) {
   P.a_large = c->hrow(kHvALarge);
   P.v_large = c->hrow(kHvVLarge);
   P.rcut2 = c->T.rcut2;
-  // the level-2 candidate lists pay from a few thousand heavy atoms on (see build_forest); AGBNP_HIP_CAND_LISTS=0/1 forces
-  static const char* cand_env = getenv("AGBNP_HIP_CAND_LISTS");
-  const bool lists = c->nh > 0 && (cand_env ? atoi(cand_env) != 0 : c->nh >= 3000);
   const int nhb_c = (c->nh + 63) / 64;
-  P.cand_items_count = lists ? nhb_c * (nhb_c + 1) / 2 : 0;
-  P.cand_count = c->d_cand_count.p;
-  P.cand_rec = c->d_cand_rec.p;
-  T.cand_count = lists ? c->d_cand_count.p : nullptr;
-  T.cand_rec = c->d_cand_rec.p;
+  P.nb_tiles = nhb_c * (nhb_c + 1) / 2;
+  P.nbmask = c->d_nbmask.p;
+  T.nbmask = c->d_nbmask.p;
+  T.nhb = nhb_c;
   {
     const size_t nhp1 = (size_t)c->slot_cap;
     P.forest_start = c->d_forest.p;
@@ -378,12 +374,12 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
   {
-    // level-2 candidate search: tiles of 64x64 heavy atoms (I <= J), per-atom record lists
+    // level-2 neighbour search: tiles of 64x64 heavy atoms (I <= J), one 64-bit mask per (atom, block)
     const int nhb = (nh + 63) / 64;
     if (nhb > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 heavy atoms are not supported by the tile index encoding");
-    HIP_TRY(c, c->d_cand_count.alloc(nhp));
-    HIP_TRY(c, hipMemset(c->d_cand_count.p, 0, sizeof(int) * nhp));
-    HIP_TRY(c, c->d_cand_rec.alloc(nhp * (size_t)kCandCap * kCandRecDoubles));
+    const size_t words = (size_t)nhb * nhb * 64;
+    HIP_TRY(c, c->d_nbmask.alloc(std::max<size_t>(words, 64)));
+    HIP_TRY(c, hipMemset(c->d_nbmask.p, 0, sizeof(unsigned long long) * std::max<size_t>(words, 64)));
   }
   c->slot_cap = std::max(2 * std::max(nh, 1), c->tree_slots[0]);
   const size_t nslots = (size_t)c->slot_cap;

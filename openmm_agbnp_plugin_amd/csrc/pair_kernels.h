@@ -22,9 +22,8 @@ struct PairArgs {
   const double* gam_cav;   // [nh] gamma/roffset
   const double *a_large, *v_large;  // [nh] Gaussian exponent / volume with the enlarged radii
   double rcut2;            // conservative squared cutoff of the 2-body overlap search
-  int cand_items_count;    // tiles of 64x64 heavy atoms (I <= J) of the level-2 candidate search; 0 = no lists
-  int* cand_count;         // [nh] level-2 candidates found for every heavy atom (zero at the start of an evaluation)
-  double* cand_rec;        // [nh][kCandCap][kCandRecDoubles]
+  int nb_tiles;            // tiles of 64x64 heavy atoms (I <= J) of the level-2 neighbour search (k_prep launch)
+  unsigned long long* nbmask;  // [nhb][nhb * 64] neighbour masks, see agbnp_common.h
   const int2* ameta;       // [n] {screened type, screener type or -1}
   const double2* lut;      // [nti*ntj*16] {y, y2*dr^2/6}
   int nti, ntj, lut_entries;

@@ -75,14 +75,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- geometry in, accumulators cleared -------------------------------------------------------------------
-// Level-2 candidate search, one workgroup per 64x64 tile of heavy atoms (I <= J), riding in the k_prep launch
-// (it reads the caller's positions directly, so it does not depend on the rest of k_prep): every heavy atom i
-// collects the records of the YOUNGER heavy atoms j > i inside the conservative overlap cutoff.  The tree
-// workgroups then fetch ~30 ready records per root in two round trips instead of sweeping all younger atoms.
-__device__ void candidate_tile(const PairArgs& P, int tile) {
+// Level-2 neighbour search, one workgroup per 64x64 tile of heavy atoms (I <= J), riding in the k_prep launch (it
+// reads the caller's positions directly, so it does not depend on the rest of k_prep): lane i of every wave tests a
+// quarter of block J against atom 64 I + i; the four 16-bit pieces meet in LDS and leave as 64 consecutive 64-bit
+// masks nbmask[J][64 I + i] (see agbnp_common.h).  Same test as the tree workgroup's own: d^2 < rcut2, j younger.
+__device__ void neighbor_tile(const PairArgs& P, int tile) {
   __shared__ double s_x[128], s_y[128], s_z[128];
-  __shared__ double s_a[64], s_v[64], s_g[64];  // Gaussian parameters of block J, for the records
-  __shared__ int s_cnt[4][64], s_base[64];
+  __shared__ unsigned short s_bits[4][64];
   const int t = threadIdx.x;
   // tile -> (I, J), I <= J, rows of the upper triangle laid end to end (no table: one dependent load less)
   const int nhb = (P.nh + 63) >> 6;
@@ -94,13 +93,7 @@ __device__ void candidate_tile(const PairArgs& P, int tile) {
   const int J = I + (tile - (I * nhb - I * (I - 1) / 2));
   if (t < 128) {
     const int h = 64 * (t < 64 ? I : J) + (t & 63);
-    const int hc = h < P.nh ? h : P.nh - 1;
-    const int a = P.h2a[hc];
-    if (t >= 64) {
-      s_a[t - 64] = P.a_large[hc];
-      s_v[t - 64] = P.v_large[hc];
-      s_g[t - 64] = P.gam_cav[hc];
-    }
+    const int a = P.h2a[h < P.nh ? h : P.nh - 1];
     s_x[t] = P.pos[3 * a];
     s_y[t] = P.pos[3 * a + 1];
     s_z[t] = P.pos[3 * a + 2];
@@ -110,34 +103,23 @@ __device__ void candidate_tile(const PairArgs& P, int tile) {
   const double xi = s_x[li], yi = s_y[li], zi = s_z[li];
   const int j0 = 16 * jq;  // each of the four waves takes a quarter of block J
   unsigned hits = 0;
+#pragma unroll
   for (int jj = 0; jj < 16; jj++) {
     const int lj = j0 + jj, hj = 64 * J + lj;
     const double dx = s_x[64 + lj] - xi, dy = s_y[64 + lj] - yi, dz = s_z[64 + lj] - zi;
-    if (hi < P.nh && hj < P.nh && hj > hi && dx * dx + dy * dy + dz * dz < P.rcut2) hits |= 1u << jj;
+    if (hj < P.nh && hj > hi && dx * dx + dy * dy + dz * dz < P.rcut2) hits |= 1u << jj;
   }
-  // one global counter update per (tile, atom i): the four quarters meet in LDS first
-  s_cnt[jq][li] = __popc(hits);
+  s_bits[jq][li] = (unsigned short)hits;
   __syncthreads();
   if (jq == 0) {
-    const int total = (s_cnt[0][li] + s_cnt[1][li]) + (s_cnt[2][li] + s_cnt[3][li]);
-    s_base[li] = total > 0 ? atomicAdd(&P.cand_count[hi], total) : 0;
-  }
-  if (__syncthreads_or(hits != 0) == 0) return;
-  int k = s_base[li];
-  for (int q = 0; q < jq; q++) k += s_cnt[q][li];
-  for (; hits; hits &= hits - 1, k++) {
-    if (k >= kCandCap) break;  // the count keeps growing: the tree workgroup sees the overflow and sweeps by itself
-    const int lj = j0 + __builtin_ctz(hits), hj = 64 * J + lj;
-    double* r = P.cand_rec + ((size_t)hi * kCandCap + k) * kCandRecDoubles;
-    reinterpret_cast<double2*>(r)[0] = make_double2(s_x[64 + lj], s_y[64 + lj]);
-    reinterpret_cast<double2*>(r)[1] = make_double2(s_z[64 + lj], s_a[lj]);
-    reinterpret_cast<double2*>(r)[2] = make_double2(s_v[lj], s_g[lj]);
-    reinterpret_cast<double2*>(r)[3] = make_double2(__hiloint2double(0, hj), 0.0);
+    const unsigned long long m = (unsigned long long)s_bits[0][li] | ((unsigned long long)s_bits[1][li] << 16) |
+                                 ((unsigned long long)s_bits[2][li] << 32) | ((unsigned long long)s_bits[3][li] << 48);
+    P.nbmask[(size_t)J * ((size_t)nhb * 64) + hi] = hi < P.nh ? m : 0ull;
   }
 }
 
 __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
-  if ((int)blockIdx.x >= prep_blocks) return candidate_tile(P, blockIdx.x - prep_blocks);
+  if ((int)blockIdx.x >= prep_blocks) return neighbor_tile(P, blockIdx.x - prep_blocks);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the status words of ONE evaluation start from zero; the sticky ones (overflow log since the last
   // agbnp_hip_finish) are left alone, and the evaluation takes its running number
@@ -870,7 +852,6 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     fx = -P.gx[h];
     fy = -P.gy[h];
     fz = -P.gz[h];
-    P.cand_count[h] = 0;  // the next evaluation's candidate search appends from zero
   }
   if (version == 1) {
     fx += P.gb_fx[i] + P.db_fx[i];
@@ -902,7 +883,7 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_MARK(kKPrep);
   const int n = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
   const int prep_blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_prep, dim3(prep_blocks + P.cand_items_count), dim3(256), 0, st, P, prep_blocks);
+  hipLaunchKernelGGL(k_prep, dim3(prep_blocks + P.nb_tiles), dim3(256), 0, st, P, prep_blocks);
   return hipGetLastError();
 }
 

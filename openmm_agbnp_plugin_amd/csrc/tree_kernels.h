@@ -62,8 +62,8 @@ struct TreeArgs {
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
                                // pair stages run), [slot_cap + 2] the copy k_tree_cavity takes for THIS evaluation
   int slot_cap;
-  const int* cand_count;       // [nh] level-2 candidates listed by the k_prep launch (see kCandCap); null: no lists
-  const double* cand_rec;      // [nh][kCandCap][kCandRecDoubles]
+  const unsigned long long* nbmask;  // [nhb][nhb * 64] level-2 neighbour masks from the k_prep launch (agbnp_common.h)
+  int nhb;                     // blocks of 64 heavy atoms
   // pass 3 (pseudo-volume): nu_i = (W_i + U_i) / V_i (ReferenceAGBNPKernels.cpp:718-722,738-742), formed on the fly
   const double* db_wu;         // [nh] W+U per heavy atom
   double rcut2;                // conservative squared cutoff of the 2-body overlap search
@@ -97,7 +97,7 @@ enum RootWord {
   kRtPart = 4 * kMaxRoots,   // part | parts << 8: a big subtree is shared by `parts` work items; item `part` expands the
                              // level-2 nodes whose rank is congruent to it (branches under different level-2 nodes are
                              // independent) and treats the other level-2 nodes as siblings only
-  kRtCand = 5 * kMaxRoots,   // listed level-2 candidates of the root (-1: too many for the list, sweep all younger atoms)
+  kRtOff = 5 * kMaxRoots,    // first (root, block) pair of the root in the forest's list of neighbour-mask words
   kRtNum = 6 * kMaxRoots
 };
 // work item = heavy index | part << 24 | (parts - 1) << 26
@@ -395,8 +395,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.rt[kRtCount + tid] = 0;
     S.rt[kRtNodes + tid] = 0;
     S.rt[kRtPart + tid] = work_item_part(item) | (work_item_parts(item) << 8);
-    const int listed = A.cand_count ? A.cand_count[hi] : kCandCap + 1;  // no lists (small systems): sweep
-    S.rt[kRtCand + tid] = listed <= kCandCap ? listed : -1;
   }
   if (tid == 0) {
     S.ctl[0] = 0;  // level-2 candidate counter of the whole forest
@@ -407,14 +405,14 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   tree_barrier<NCAP>();
 
   // ---- level 2: for every root, all heavy atoms with a larger index whose overlap with the root survives the
-  // switch.  The k_prep launch has listed, per heavy atom, the records of the younger atoms inside the conservative
-  // cutoff; the lists of the roots are laid end to end and fetched two records per lane and trip (one round trip for
-  // ~60 records), each takes the exact test, and a hit takes a slot with an LDS counter and parks its atom record
-  // in the (still unused) upper node slots so that ranking never goes back to HBM.
-  // Two stages, because the exact test (a Gaussian merge: exp, sqrt, reciprocal) is two hundred instructions that a
-  // wave executes in full as soon as ONE of its lanes is inside the cutoff -- and with ~30 of ~1000 candidates inside,
-  // nearly every wave has one.  Stage 1 (here, per candidate) only appends the near ones to a staging list; stage 2
-  // (below, after the sweep) takes the exact test densely, one near candidate per lane.
+  // switch.  The tile workgroups of the k_prep launch have left, per heavy atom and block of 64 heavy atoms, a 64-bit
+  // mask of the younger atoms inside the conservative cutoff (agbnp_common.h).  Stage 1 (here): the (root, block)
+  // pairs of the forest's roots are laid end to end, one pair per lane and trip: fetch the word (one round trip for
+  // the whole forest in all but huge systems), reserve as many near slots as it has bits with one LDS add, expand
+  // the bits.  Stage 2 (below) takes the exact test (a Gaussian merge: exp, sqrt, reciprocal -- two hundred
+  // instructions that a wave executes in full as soon as ONE of its lanes has work) densely, one near candidate per
+  // lane; a hit takes a slot with an LDS counter and parks its atom record in the (still unused) upper node slots so
+  // that ranking never goes back to HBM.
   constexpr int kNearCap = NCAP - ACAP;  // staging slots NCAP-1-p, p < kNearCap: clear of the roots and level-2 nodes (< ACAP)
   auto accept = [&](int q, int hj, double sv, double gvol, double xj, double yj, double zj, double aj, double vj, double gj) {
     const int p = atomicAdd(&S.ctl[0], 1);
@@ -432,113 +430,53 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[6][st] = gvol;  // unswitched overlap with the root: the level-2 node's volume
     }
   };
-  auto consider = [&](int q, int hj, double xj, double yj, double zj) {
-    const double rx = S.at[0][q], ry = S.at[1][q], rz = S.at[2][q];
-    const double dx = xj - rx, dy = yj - ry, dz = zj - rz;
-    const double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 >= A.rcut2) return;
-    const int p = atomicAdd(&S.ctl[5], 1);
-    if (p < kNearCap) {
-      const int st = NCAP - 1 - p;
-      S.nd[0][st] = xj;
-      S.nd[1][st] = yj;
-      S.nd[2][st] = zj;
-      S.nd[6][st] = __hiloint2double(0, hj | (q << 24));
-    } else {
-      S.ctl[6] = 1;  // more near candidates than staging slots (dense synthetic systems): next capacity variant
-    }
-  };
   {
-    int off[kMaxRoots + 1];  // offsets of the roots' lists in the concatenated range (m <= kMaxRoots)
+    // pairs of root q: blocks (heavy_q >> 6) .. nhb-1; offsets of the roots' pair ranges (m <= kMaxRoots)
+    int off[kMaxRoots + 1];
     off[0] = 0;
 #pragma unroll
-    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? max(S.rt[kRtCand + q], 0) : 0);
-    const int nlisted = off[kMaxRoots];
-    auto fetch = [&](int c, int& q, int& hj, double2& r0, double2& r1, double2& r2) {
-      // root of candidate c and the start of that root's range: one fused pass over the (non-decreasing) offsets.
+    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? A.nhb - (S.rt[kRtHeavy + q] >> 6) : 0);
+    const int npairs = off[kMaxRoots];
+    const size_t mask_stride = (size_t)A.nhb * 64;
+    for (int base = 0; base < npairs; base += BS) {
+      const int c = base + tid;
+      // root of pair c and the start of that root's range: one fused pass over the (non-decreasing) offsets.
       // (Looking off[q] up after the count makes the compiler index the array dynamically, i.e. put it in scratch.)
-      q = 0;
-      int o = 0;
+      int q = 0, o = 0;
 #pragma unroll
       for (int k = 1; k < kMaxRoots; k++) {
         const bool past = k < m && c >= off[k];
         q += past ? 1 : 0;
         o = past ? off[k] : o;
       }
-      const double2* rec = reinterpret_cast<const double2*>(A.cand_rec + ((size_t)S.rt[kRtHeavy + q] * kCandCap + (c - o)) * kCandRecDoubles);
-      r0 = rec[0];
-      r1 = rec[1];
-      r2 = rec[2];
-      hj = __double2loint(rec[3].x);
-    };
-    for (int base = 0; base < nlisted; base += 2 * BS) {
-      const int c0 = base + tid, c1 = base + BS + tid;
-      const bool v0 = c0 < nlisted, v1 = c1 < nlisted;
-      int q0, h0, q1, h1;
-      double2 a0, b0, g0, a1, b1, g1;
-      fetch(v0 ? c0 : 0, q0, h0, a0, b0, g0);
-      fetch(v1 ? c1 : 0, q1, h1, a1, b1, g1);
-      if (v0) consider(q0, h0, a0.x, a0.y, b0.x);
-      if (v1) consider(q1, h1, a1.x, a1.y, b1.x);
-    }
-  }
-  // Roots without a list sweep all their younger atoms: the ranges of those roots are laid end to end and walked two
-  // per lane and trip, every field requested up front (one L2 round trip per 2*BS candidates).  This is the only
-  // search of a system too small for the lists to pay (the tile search costs ~4 us in the k_prep launch and saves
-  // one round trip per 512 candidates here), and the fallback of a root whose list overflowed (dense systems).
-  {
-    int off[kMaxRoots + 1];
-    off[0] = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + ((q < m && S.rt[kRtCand + q] < 0) ? A.nh - 1 - S.rt[kRtHeavy + q] : 0);
-    const int nswept = off[kMaxRoots];
-    auto locate = [&](int c, int& q, int& hj) {  // concatenated index -> (root, heavy atom)
-      q = 0;
-      int o = 0;
-#pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) {  // fused: see fetch
-        const bool past = k < m && c >= off[k];
-        q += past ? 1 : 0;
-        o = past ? off[k] : o;
-      }
-      hj = S.rt[kRtHeavy + q] + 1 + (c - o);
-    };
-    // positions only (the Gaussian parameters are fetched for the few near candidates in stage 2): every workgroup of the
-    // launch sweeps at the same time, and this traffic is what the L2 has to carry
-    constexpr int kSweep = 4;  // candidates per lane and trip
-    for (int base = 0; base < nswept; base += kSweep * BS) {
-      int qs[kSweep], hs[kSweep];
-      double xs[kSweep], ys[kSweep], zs[kSweep];
-#pragma unroll
-      for (int k = 0; k < kSweep; k++) {
-        const int c = base + k * BS + tid;
-        locate(c < nswept ? c : 0, qs[k], hs[k]);
-        if (c >= nswept) {
-          hs[k] = S.rt[kRtHeavy];  // any valid address
-          qs[k] = -1;
+      const int hq = S.rt[kRtHeavy + q];
+      const int J = (hq >> 6) + (c - o);
+      unsigned long long bits = c < npairs ? A.nbmask[(size_t)J * mask_stride + hq] : 0ull;
+      if (bits) {
+        int p = atomicAdd(&S.ctl[5], (int)__popcll(bits));
+        for (; bits; bits &= bits - 1, p++) {
+          if (p < kNearCap)
+            S.nd[6][NCAP - 1 - p] = __hiloint2double(0, (64 * J + __builtin_ctzll(bits)) | (q << 24));
+          else
+            S.ctl[6] = 1;  // more near candidates than staging slots (dense synthetic systems): next capacity variant
         }
-        xs[k] = A.hvat(kHvX, hs[k]);
-        ys[k] = A.hvat(kHvY, hs[k]);
-        zs[k] = A.hvat(kHvZ, hs[k]);
       }
-#pragma unroll
-      for (int k = 0; k < kSweep; k++)
-        if (qs[k] >= 0) consider(qs[k], hs[k], xs[k], ys[k], zs[k]);
     }
   }
   tree_barrier<NCAP>();
   if (S.ctl[6]) return kBuildAtomOverflow;  // more near candidates than staging slots: next capacity variant
   {
-    // stage 2: exact test, one near candidate per lane.  An accepted candidate moves to the staging slot of its
-    // running number, which is never above the near slots already read (numbers are handed out as trips complete).
+    // stage 2: exact test, one near candidate per lane: its record comes from the heavy-atom table (six gathers,
+    // one round trip per trip of BS candidates).  An accepted candidate moves to the staging slot of its running
+    // number, which is never above the near slots already read (numbers are handed out as trips complete).
     const int nnear = S.ctl[5];
     for (int base = 0; base < nnear; base += BS) {
       const bool mine = base + tid < nnear;
       const int st = NCAP - 1 - (mine ? base + tid : 0);
-      const double xj = S.nd[0][st], yj = S.nd[1][st], zj = S.nd[2][st];
       const int packed = __double2loint(S.nd[6][st]);
       const int q = mine ? packed >> 24 : 0;
       const int hjn = mine ? packed & 0xffffff : 0;
+      const double xj = A.hvat(kHvX, hjn), yj = A.hvat(kHvY, hjn), zj = A.hvat(kHvZ, hjn);
       const double aj = A.hvat(kHvALarge, hjn), vj = A.hvat(kHvVLarge, hjn), gj = A.hvat(kHvGam, hjn);
       double sv = 0.0, gvol = 0.0;
       if (mine) sv = dev_merge_volume2(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj, gvol);

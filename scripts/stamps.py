@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): per-phase shader-clock shares of k_tree_cavity from the -DAGBNP_STAMPS build.
-Usage: AGBNP_HIP_LIBRARY=scripts/_diag/libagbnp_hip_stamps.so python scripts/stamps.py [system]"""
+Usage: AGBNP_HIP_LIBRARY=build/diag/libagbnp_hip_stamps.so python scripts/stamps.py [system]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
