@@ -51,11 +51,11 @@ struct SubtreeHeader {
 enum StatusWord {
   kStatNodeOverflow = 0,   // a subtree needed more than NCAP nodes
   kStatAtomOverflow = 1,   // a node had more than ACAP children / level-2 partners
-  kStatPoolOverflow = 2,   // topology pool exhausted
+  kStatPseudoQueue = 2,    // work queue of k_tree_pseudo: forests handed out beyond the first one of every workgroup
   kStatMaxNodes = 3,       // max nodes of any subtree (diagnostic)
   kStatMaxAtoms = 4,       // max local atoms of any subtree (diagnostic)
-  kStatPoolUsed = 5,       // nodes allocated from the pool
-  kStatAtomPoolUsed = 6,   // ints allocated from the atom pool
+  kStatCavityQueue = 5,    // work queue of k_tree_cavity (same)
+  kStatUnused6 = 6,
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)

@@ -68,7 +68,7 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
-constexpr int kGlobalVariant = 3;
+constexpr int kGlobalVariant = 4;  // tree_kernels.hip: 0 (432, 64), 1 (512, 64), 2 (1024, 128), 3 (2048, 256) in LDS, 4 in HBM scratch
 constexpr int kGlobalGrid = 256;  // persistent workgroups of the global-scratch variant
 
 }  // namespace
@@ -96,6 +96,7 @@ struct agbnp_hip_context {
   DevBuf<double2> d_lut;
   // per-evaluation device data
   DevBuf<double> d_pbox, d_epart;
+  DevBuf<double4> d_hacc;  // [nh] tree-stage sums per heavy atom (tree_kernels.h)
   DevBuf<double4> d_aposq;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -117,7 +118,7 @@ struct agbnp_hip_context {
   std::vector<int> withheld;   // evaluations (numbered from the previous finish) that the last finish found withheld
   int withheld_count = 0;
   unsigned generation = 1;     // bumped whenever kernel arguments a captured graph has frozen go stale
-  int tree_slots[4] = {1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
+  int tree_slots[5] = {1280, 1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
   bool have_results = false;
@@ -207,7 +208,7 @@ int ensure_scratch(agbnp_hip_context* c) {
     c->T.node_pool = c->d_node_pool.p;
     c->generation++;
   }
-  const size_t need_pairs = c->variant == 0 ? 4 * need_nodes : 0;  // membership pairs of the 512-node variant
+  const size_t need_pairs = c->variant <= 1 ? 4 * need_nodes : 0;  // membership pairs of the variants up to 512 nodes
   if (c->d_pair_pool.count < need_pairs) {
     HIP_TRY(c, c->d_pair_pool.alloc(need_pairs));
     c->T.pair_pool = c->d_pair_pool.p;
@@ -256,10 +257,7 @@ void wire_args(agbnp_hip_context* c) {
   P.nhb = (c->nh + 63) / 64;
   P.db_items = c->d_db_items.p;
   P.db_items_count = (int)c->d_db_items.count;
-  P.gx = c->hrow(kHvGx);
-  P.gy = c->hrow(kHvGy);
-  P.gz = c->hrow(kHvGz);
-  P.sv_vdw = c->hrow(kHvSvVdw);
+  P.hacc = c->d_hacc.p;
   P.sv_large = c->hrow(kHvSvLarge);
   P.epart = c->d_epart.p;
   P.status = c->d_status.p;
@@ -285,6 +283,7 @@ void wire_args(agbnp_hip_context* c) {
   T.nh = c->nh;
   T.hv = c->d_heavy.p;
   T.hstride = (unsigned)c->hstride;
+  T.hacc = reinterpret_cast<double*>(c->d_hacc.p);
   T.db_wu = c->d_dbf.p + 3 * (size_t)c->n;
   T.want_sv_large = c->diagnostics ? 1 : 0;  // pass-1 self volumes cost extra HBM atomics: opt-in
   T.epart = c->d_epart.p;
@@ -313,12 +312,12 @@ void wire_args(agbnp_hip_context* c) {
     P.tree_slot_cap = c->slot_cap;
     P.tree_node_cap = tree_variant_node_cap(c->variant);
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
-    static const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
+    const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
     P.pack_enabled = no_pack ? 0 : 1;
-    static const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
+    const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
     P.round_permille = std::max(100, round_permille);
-    static const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 1;
-    static const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 720;
+    const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 3;
+    const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 550;
     // a full device has slot_cap = 2 x subtrees work slots: more parts per subtree than that could plan more work items
     // than forest_start / order / the topology pools hold
     P.split_big = std::min(std::min(4, c->slot_cap / std::max(c->nh, 1)), std::max(1, split_big));
@@ -381,11 +380,13 @@ int allocate_work(agbnp_hip_context* c) {
     HIP_TRY(c, c->d_nbmask.alloc(std::max<size_t>(words, 64)));
     HIP_TRY(c, hipMemset(c->d_nbmask.p, 0, sizeof(unsigned long long) * std::max<size_t>(words, 64)));
   }
-  c->slot_cap = std::max(2 * std::max(nh, 1), c->tree_slots[0]);
+  c->slot_cap = std::max(4 * std::max(nh, 1), c->tree_slots[0]);  // up to four work items per subtree (shared subtrees)
   const size_t nslots = (size_t)c->slot_cap;
   HIP_TRY(c, c->d_epart.alloc(2 * nslots));
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nslots));
   HIP_TRY(c, c->d_aposq.alloc(n));
+  HIP_TRY(c, c->d_hacc.alloc(nhp));
+  HIP_TRY(c, hipMemset(c->d_hacc.p, 0, sizeof(double4) * nhp));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
@@ -421,10 +422,9 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   HIP_TRY(c, launch_prep(c->P, st, tl));
   if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
-  // work slots to launch: the packing rarely needs more than the subtree count (a shared subtree on a roomy device
-  // aside); if it ever plans more than were launched the tree kernel reports a packing overflow and the host repeats
-  static const int grid_permille = getenv("AGBNP_HIP_GRID_PERMILLE") ? atoi(getenv("AGBNP_HIP_GRID_PERMILLE")) : 1250;
-  const int tree_grid = std::min(c->slot_cap, std::max(c->tree_slots[0], (int)((long long)c->nh * grid_permille / 1000)));
+  // workgroups of the tree launches: what the device keeps resident for this variant (they take forests from a queue);
+  // fewer if there cannot be that many forests
+  const int tree_grid = std::max(1, std::min(c->slot_cap, c->tree_slots[c->variant]));
   HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
@@ -573,10 +573,11 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
     // resident tree workgroups per capacity variant: what one "round" of the forest packing is
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    c->tree_slots[0] = 4 * cus;
-    c->tree_slots[1] = 2 * cus;
-    c->tree_slots[2] = cus;
-    c->tree_slots[3] = kGlobalGrid;
+    c->tree_slots[0] = 5 * cus;
+    c->tree_slots[1] = 4 * cus;
+    c->tree_slots[2] = 2 * cus;
+    c->tree_slots[3] = cus;
+    c->tree_slots[4] = kGlobalGrid;
   }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
@@ -697,26 +698,28 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
   HIP_TRY(c, hipSetDevice(c->device));
   const int n = c->n, nh = c->nh;
   std::vector<double> tmp(std::max(n, std::max(nh, 1)));
-  auto heavy_to_atoms = [&](const double* dsrc, double scale_by_inv_vol) -> int {
-    HIP_TRY(c, hipMemcpy(tmp.data(), dsrc, sizeof(double) * std::max(nh, 1), hipMemcpyDeviceToHost));
+  auto heavy_to_atoms = [&](const double* dsrc, size_t stride, size_t word, double scale_by_inv_vol) -> int {
+    std::vector<double> raw((size_t)std::max(nh, 1) * stride);
+    HIP_TRY(c, hipMemcpy(raw.data(), dsrc, sizeof(double) * raw.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) out[i] = 0.0;
     for (int h = 0; h < nh; h++) {
-      double v = tmp[h];
+      double v = raw[(size_t)h * stride + word];
       if (scale_by_inv_vol != 0.0) v /= (4. * M_PI * pow(c->r_vdw[c->h2a[h]], 3) / 3.);
       out[c->h2a[h]] = v;
     }
     return AGBNP_HIP_OK;
   };
+  const double* hacc = reinterpret_cast<const double*>(c->d_hacc.p);  // the self volume is the fourth word of every record
   switch (which) {
-    case 0: return heavy_to_atoms(c->hrow(kHvSvVdw), 0.0);
+    case 0: return heavy_to_atoms(hacc, 4, 3, 0.0);
     case 1:
       if (c->version != 1) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "Born radii exist for version 1 only");
       HIP_TRY(c, hipMemcpy(out, c->d_born.p, sizeof(double) * n, hipMemcpyDeviceToHost));
       return AGBNP_HIP_OK;
-    case 2: return heavy_to_atoms(c->hrow(kHvSvVdw), 1.0);
+    case 2: return heavy_to_atoms(hacc, 4, 3, 1.0);
     case 3:
       if (!c->diagnostics) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "enlarged-radius self volumes need agbnp_hip_set_diagnostics(ctx, 1) before the evaluation");
-      return heavy_to_atoms(c->hrow(kHvSvLarge), 0.0);
+      return heavy_to_atoms(c->hrow(kHvSvLarge), 1, 0, 0.0);
     case 4:
     case 5: {  // overlap-tree shape: nodes / local atoms of the subtree rooted at every heavy atom (0 for hydrogens)
       std::vector<int2> sz(std::max(nh, 1));

@@ -34,8 +34,8 @@ struct PairArgs {
   int nslots, nhb;         // slots (multiple of 64), heavy blocks
   double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
   // ---- tree accumulators / outputs
-  double *gx, *gy, *gz;    // [nh]
-  double *sv_vdw, *sv_large;  // [nh]
+  double4* hacc;           // [nh] {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}: atomic sums of the tree kernels
+  double* sv_large;        // [nh] (diagnostic)
   double* epart;           // [2nh]
   int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
   int* order;              // [4 nh] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation, by forest

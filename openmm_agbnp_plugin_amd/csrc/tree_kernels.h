@@ -47,8 +47,7 @@ enum HeavyRow {
   kHvAVdw, kHvVVdw,            // ... vdW radii
   kHvGam,                      // gamma / roffset (pass 1 uses +gam, pass 2 -gam)
   kHvInvVol,                   // 1 / (4 pi R^3 / 3), vdW radius
-  kHvGx, kHvGy, kHvGz,         // gradient accumulators (dE/dr)
-  kHvSvLarge, kHvSvVdw,        // self volumes (enlarged radii: diagnostic)
+  kHvSvLarge,                  // self volumes with the enlarged radii (diagnostic)
   kHvRows
 };
 
@@ -56,6 +55,10 @@ struct TreeArgs {
   int nh;                      // heavy atoms
   unsigned hstride;            // row stride of the heavy-atom table
   double* hv;                  // [kHvRows][hstride]
+  // per-heavy-atom sums of the tree stage, ONE 32-byte record per atom {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}:
+  // float atomics execute at the memory side in 64-byte requests (~20 G requests/s chip-wide), and a forest's atoms
+  // are scattered over the table, so an atom's four sums must share a request rather than sit in four rows
+  double* hacc;                // [nh][4]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   const int* order;            // [<= 4 nh] work items, by forest
   const int* packing;          // [slot_cap + 1] forest_start: work slot s builds order[packing[s] .. packing[s+1]);
@@ -109,11 +112,17 @@ __host__ __device__ inline int work_item_parts(int e) { return ((e >> 26) & 3) +
 // ---- LDS / scratch carve-out -----------------------------------------------------------------
 template <int NCAP, int ACAP>
 struct TreeStore {
-  static constexpr int TCAP = 8 * ACAP;  // tasks per expansion batch (tmap bytes live in cand_vol, volumes in nd[6])
-  static_assert(TCAP <= NCAP, "task volumes are staged in the spare node slot");
+  static constexpr int TCAP = 8 * ACAP < NCAP ? 8 * ACAP : NCAP;  // tasks per expansion batch (tmap bytes live in cand_vol, volumes in nd[6])
+  static_assert(TCAP <= NCAP && TCAP <= 8 * ACAP, "task volumes are staged in the spare node slot, the byte map in cand_vol");
+  static constexpr int kMaskWords = (TCAP + 63) / 64;
+  // Node rows.  Stores for up to 64 local atoms keep SIX: the node's gamma sum is not stored (a volume pass adds it up
+  // along the node's atoms) and the gather weight w_n takes the place of the unswitched volume; the larger variants keep
+  // a seventh row because their gather folds across waves through the volume row.
+  static constexpr int kRows = ACAP <= 64 ? 6 : 7;
   static_assert(2 * ACAP <= NCAP, "level-2 staging slots must not collide with the level-2 nodes");
-  double* nd[7];   // node slots: 0-2 centre, 3 exponent, 4 unswitched volume, 5 gamma_1..i, 6 scratch (task volumes)
-                   // after the bottom-up sweep of a node: 0 psi', 1 E, 2 F_E, 3-5 P_E
+  double* nd[7];   // node slots: 0-2 centre, 3 exponent, 4 unswitched volume, 6 scratch (task volumes, then atom paths);
+                   // [5] exists with seven rows only.  After the node step of a volume pass: 3 coef_n, wrow w_n
+  double* wrow;    // gather weights w_n: nd[4] (six rows) or nd[5] (seven)
   double* at[10];  // local atoms: 0-2 centre, 3 exponent, 4 volume, 5 gamma, 6-8 gradient acc, 9 self-volume acc
   double* cand_vol;  // [ACAP] level-2 candidate volumes; reused as the task->node byte map of a batch
   double* misc;      // [8]: per-wave partial sums of a volume pass
@@ -125,7 +134,7 @@ struct TreeStore {
                      // slot, node count (kMaxRoots each), then the number of roots
   unsigned short *nla, *npar, *ncs, *ncc;  // [NCAP]
   unsigned short *tstart, *cbase;          // [kTreeBlock + 2] per-batch task start / child base
-  unsigned long long* kmask;               // [TCAP/64] per 64 tasks of a batch: which ones survive the switch
+  unsigned long long* kmask;               // [kMaskWords] per 64 tasks of a batch: which ones survive the switch
   // (atom, node) membership pairs sorted by atom, one 16-bit word each (atom << 9 | node): the gather of a volume
   // pass walks this list instead of testing every node against every atom.  Built once per subtree after the
   // build, when the four 16-bit topology arrays are dead: the list lives in their place.
@@ -140,26 +149,26 @@ struct TreeStore {
   static constexpr size_t kStampBytes = 0;
 #endif
 
-  static constexpr size_t kBytes = sizeof(double) * (7 * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 8) +
+  static constexpr size_t kBytes = sizeof(double) * (kRows * (size_t)NCAP + 10 * (size_t)ACAP + ACAP + 8) +
                                    sizeof(int) * (2 * (size_t)ACAP + 24 + kRootWords) +
                                    sizeof(unsigned short) * (4 * (size_t)NCAP + 2 * (kTreeBlock + 2)) + 8 +
-                                   sizeof(unsigned long long) * (TCAP / 64) + kStampBytes;
+                                   sizeof(unsigned long long) * kMaskWords + kStampBytes;
 
-  // A replay (volume pass from stored atom paths) touches only the node rows 0-3, 5, 6, the local atom table and the
-  // per-wave partial sums: 3/4 of the full footprint, so five replay workgroups fit a CU instead of four.  (The
-  // variants whose gather may take several rounds keep row 4 as the exchange area of its cross-wave fold.)
-  static constexpr int kReplayRows = ACAP <= 64 ? 6 : 7;
+  // A replay (volume pass from stored atom paths) needs the node rows, the local atom table and the per-wave partial
+  // sums, but none of the build's bookkeeping arrays: 3/4 of the full footprint.
+  static constexpr int kReplayRows = kRows;
   static constexpr size_t kReplayBytes = sizeof(double) * (kReplayRows * (size_t)NCAP + 10 * (size_t)ACAP + 8) +
                                          sizeof(int) * ((size_t)ACAP + kRootWords) + kStampBytes;
   static_assert(!kPairGather || sizeof(unsigned short) * PCAP <= sizeof(double) * NCAP, "pair list fits the path row");
+  __device__ __forceinline__ void carve_rows(double* d) {
+    for (int k = 0; k < 5; k++) nd[k] = d + (size_t)k * NCAP;
+    nd[5] = kRows == 7 ? d + 5 * (size_t)NCAP : nullptr;
+    nd[6] = d + (size_t)(kRows - 1) * NCAP;
+    wrow = kRows == 7 ? nd[5] : nd[4];
+  }
   __device__ __forceinline__ void carve_replay(char* base) {
     double* d = reinterpret_cast<double*>(base);
-    if (kReplayRows == 7) {
-      for (int k = 0; k < 7; k++) nd[k] = d + (size_t)k * NCAP;
-    } else {
-      for (int k = 0; k < 7; k++) nd[k] = d + (size_t)(k < 4 ? k : k - 1) * NCAP;  // row 4 (unswitched volume) is not stored
-      nd[4] = nullptr;
-    }
+    carve_rows(d);
     d += kReplayRows * (size_t)NCAP;
     for (int k = 0; k < 10; k++) at[k] = d + (size_t)k * ACAP;
     d += 10 * (size_t)ACAP;
@@ -182,8 +191,8 @@ struct TreeStore {
 
   __device__ __forceinline__ void carve(char* base) {
     double* d = reinterpret_cast<double*>(base);
-    for (int k = 0; k < 7; k++) nd[k] = d + (size_t)k * NCAP;
-    d += 7 * (size_t)NCAP;
+    carve_rows(d);
+    d += kRows * (size_t)NCAP;
     for (int k = 0; k < 10; k++) at[k] = d + (size_t)k * ACAP;
     d += 10 * (size_t)ACAP;
     cand_vol = d;
@@ -212,7 +221,7 @@ struct TreeStore {
     cbase = tstart + (kTreeBlock + 2);
     kmask = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(cbase + (kTreeBlock + 2)) + 7) & ~(uintptr_t)7);
 #ifdef AGBNP_STAMPS
-    stamps = kmask + TCAP / 64;
+    stamps = kmask + kMaskWords;
 #endif
   }
 };
@@ -388,7 +397,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.nd[2][tid] = rz;
     S.nd[3][tid] = ra;
     S.nd[4][tid] = rv;
-    S.nd[5][tid] = rg;
     S.nla[tid] = (unsigned short)tid;
     S.npar[tid] = 0xFFFF;
     S.rt[kRtHeavy + tid] = hi;
@@ -426,7 +434,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[2][st] = zj;
       S.nd[3][st] = aj;
       S.nd[4][st] = vj;
-      S.nd[5][st] = gj;
+      S.at[9][p] = gj;  // (the self-volume accumulators are idle during the build; handed back as zeros below)
       S.nd[6][st] = gvol;  // unswitched overlap with the root: the level-2 node's volume
     }
   };
@@ -538,7 +546,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     }
     const int slot = bq + rank;  // level-2 node k <-> local atom k
     const int st = NCAP - 1 - c;
-    const double x2 = S.nd[0][st], y2 = S.nd[1][st], z2 = S.nd[2][st], a2 = S.nd[3][st], v2 = S.nd[4][st], g2 = S.nd[5][st];
+    const double x2 = S.nd[0][st], y2 = S.nd[1][st], z2 = S.nd[2][st], a2 = S.nd[3][st], v2 = S.nd[4][st], g2 = S.at[9][c];
+    S.at[9][c] = 0.0;
     S.at[0][slot] = x2;
     S.at[1][slot] = y2;
     S.at[2][slot] = z2;
@@ -554,7 +563,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.nd[2][slot] = cmz;
     S.nd[3][slot] = cma;
     S.nd[4][slot] = gv2;
-    S.nd[5][slot] = S.at[5][q] + g2;
     S.nla[slot] = (unsigned short)slot;
     S.npar[slot] = (unsigned short)q;
     S.ncs[slot] = (unsigned short)(bq + cq);  // until the node is expanded: end of its sibling list
@@ -745,7 +753,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           S.nd[2][slot] = mz;
           S.nd[3][slot] = ma;
           S.nd[4][slot] = v;
-          S.nd[5][slot] = S.nd[5][kk] + S.at[5][la];
           S.nla[slot] = (unsigned short)la;
           S.npar[slot] = (unsigned short)kk;
           S.ncs[slot] = (unsigned short)(cb + (int)S.ncc[kk]);  // end of this child's sibling list
@@ -829,7 +836,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
           if (((n - S.rt[kRtBase + par]) % (pp >> 8)) != (pp & 0xff)) {
             path[n] = (unsigned long long)par << 56;
             S.nd[3][n] = 0.0;
-            S.nd[5][n] = 0.0;
+            S.wrow[n] = 0.0;
             break;
           }
         }
@@ -841,17 +848,18 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         const int la = S.nla[p];
         pw = (pw << 8) | (unsigned long long)la;
         if (kPairs) atomicAdd(&S.pcnt[la], 1);
+        gam += S.at[5][la];  // gamma_1..i (gaussvol.cpp:224: the root's gamma plus that of every atom added)
         level++;
       }
       rootq = p;
+      gam += S.at[5][rootq];
       path[n] = pw | ((unsigned long long)rootq << 56);
       g = S.nd[4][n];
-      gam = S.nd[5][n];
     } else {
       const unsigned long long pwr = path[n];
       if ((pwr & kPartners) == 0ull) {  // inert (a level-2 node owned by another work item)
         S.nd[3][n] = 0.0;
-        S.nd[5][n] = 0.0;
+        S.wrow[n] = 0.0;
         break;
       }
       rootq = (int)(pwr >> 56);
@@ -886,7 +894,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
     const double sw = dev_switch(g, sp);
     w = cp * sw * g;
     S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
-    S.nd[5][n] = w;
+    S.wrow[n] = w;
     e_part += gam * w;
     } while (false);
     // The root is in every node of its tree: its self volume is the tree's sum of w (and its node count the count).
@@ -963,7 +971,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
     for (; k < kend; k++) {
       const int pr = S.pairs[k];
       const int a = pr >> 9, n = pr & 511;
-      const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
+      const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.wrow[n];
       if (a != cur) {
         if (cur >= 0) flush();
         cur = a;
@@ -998,7 +1006,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       // one LDS round trip instead of two (path -> test -> record)
       for (int n = m + slice; n < nnodes; n += nslices) {
         const unsigned long long x = path[n] ^ pat;
-        const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.nd[5][n];
+        const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.wrow[n];
         const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
         const double am = member ? cf * ea : 0.0;
         gx += am * (xa - cx);

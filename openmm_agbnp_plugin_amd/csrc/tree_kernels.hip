@@ -9,10 +9,15 @@ namespace agbnp {
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase; [15] = slowest workgroup in total
 __device__ unsigned long long g_stamps_slowest[24];  // the slowest workgroup's own phases [0..15] + slot, roots, nodes, atoms
+// per work slot: roots, nodes, local atoms, start / end on the 100 MHz wall clock, shader cycles, XCC id, CU id
+constexpr int kWgLogSlots = 8192;
+__device__ unsigned long long g_wg_log[kWgLogSlots][8];
 // per-workgroup sums live in the store (S.stamps); flushed once at the end (no contention inside phases)
 #define STAMP_BEGIN()                                   \
   if (tid < 16) S.stamps[tid] = 0;                      \
   __syncthreads();                                      \
+  const unsigned long long t_wall0__ = wall_clock64();  \
+  const unsigned long long t_cyc0__ = __builtin_readcyclecounter(); \
   unsigned long long t_prev__ = __builtin_readcyclecounter()
 #define STAMP(i)                                                   \
   do {                                                             \
@@ -26,6 +31,15 @@ __device__ unsigned long long g_stamps_slowest[24];  // the slowest workgroup's 
 #define STAMP_FLUSH()                                              \
   do {                                                             \
     __syncthreads();                                               \
+    if (tid == 0 && slot < kWgLogSlots) {                          \
+      unsigned xcc__ = 0, hw__ = 0;                                \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__)); \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));   \
+      g_wg_log[slot][0] = m; g_wg_log[slot][1] = nnodes; g_wg_log[slot][2] = natoms; \
+      g_wg_log[slot][3] = t_wall0__; g_wg_log[slot][4] = wall_clock64();            \
+      g_wg_log[slot][5] = __builtin_readcyclecounter() - t_cyc0__;                  \
+      g_wg_log[slot][6] = xcc__; g_wg_log[slot][7] = hw__;                          \
+    }                                                              \
     if (tid < 16) atomicAdd(&g_stamps[tid], S.stamps[tid]);        \
     if (tid < 16) atomicMax(&g_stamps_max[tid], S.stamps[tid]);    \
     if (tid == 0) {                                                \
@@ -62,21 +76,44 @@ __device__ unsigned long long g_stamps_slowest[24];  // the slowest workgroup's 
 // Build + cavity passes of one forest = the subtrees of up to kMaxRoots heavy atoms (reference steps A-D of
 // platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).  Work slot s holds the
 // roots order[forest_start[s] .. forest_start[s+1]); the packing comes from the previous evaluation's subtree sizes
-// (k_outputs' bookkeeping workgroup); slots beyond *nforests have nothing to do.
+// (the bookkeeping workgroup).
+//
+// Scheduling: the launch holds as many workgroups as the device keeps resident (or fewer, if there are fewer forests);
+// a workgroup starts on forest blockIdx.x and then takes forests from a device-wide queue until it is empty: one
+// returning atomic per forest, issued in the MIDDLE of the forest before it -- after that forest's last global load
+// has been consumed (the memory counter is in order: a load issued behind the atomic would have to wait for it, and
+// when every workgroup asks at once the queue word serves them one after the other) and long before its result is
+// needed.  Forests are ordered largest first, so this is longest-processing-time-first list scheduling over the CUs.  It matters because a
+// CU's time is proportional to the nodes it has to build (a workgroup timeline of 1dwc with one forest per
+// workgroup: CUs that happened to receive 1000 nodes finished at 68 us, CUs with 500 nodes at 35 us, and the kernel
+// lasts as long as its unluckiest CU), and the hardware dispatcher knows nothing about forest sizes.
+__device__ __forceinline__ int next_forest(int tid, int* lds_word, int ticket) {
+  // ticket: what this workgroup's atomicAdd on the queue returned (lane 0); every lane gets the same next slot
+  if (tid == 0) *lds_word = (int)gridDim.x + ticket;
+  lds_barrier();
+  const int slot = *lds_word;
+  lds_barrier();
+  return slot;
+}
+
+// Waves per SIMD the compiler is asked to leave room for = workgroups per CU that the variant's LDS footprint allows
+// (one wave of a workgroup per SIMD): 5 for the 432-node store (<= 96 VGPRs), 4 for 512 nodes (<= 128), fewer beyond.
+constexpr int tree_waves_per_simd(int ncap) { return ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2); }
+
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
+  __shared__ int s_next;  // hand-off word of the work queue (in LDS for every variant)
   const int tid = threadIdx.x;
-  int nforests = A.nforests()[0];
-  if (!GLOBAL && nforests > (int)gridDim.x) {  // more work slots planned than launched: report it, the host repeats unpacked
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&A.status[kStatPackOverflow], 1);
-    nforests = gridDim.x;
-  }
+  const int nforests = min(A.nforests()[0], A.slot_cap);  // (never above the slots the per-slot arrays hold)
   if (blockIdx.x == 0 && tid == 0) A.cur_nforests()[0] = nforests;
 
-  for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
+  const bool queued = nforests > (int)gridDim.x;  // otherwise every forest has a workgroup of its own
+  for (int slot = blockIdx.x; slot < nforests;) {
+    int ticket = nforests;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
+    do {
     const int f0 = A.forest_start()[slot];
     const int m = A.forest_start()[slot + 1] - f0;  // 1..kMaxRoots roots, largest forests first
     const int* roots = A.order + f0;
@@ -112,12 +149,13 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
         A.hdr[slot].natoms = 0;
       }
       tree_barrier<NCAP>();
-      continue;
+      break;  // on to the next forest
     }
     CSTAMP(1);
     // Take delivery of the prefetched vdW parameters HERE, while nothing else is in flight: the memory counter is in
     // order, so a wait placed after the topology stores below would also wait for every one of them.
     asm volatile("" ::"v"(a_vdw_mine), "v"(v_vdw_mine));
+    if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatCavityQueue], 1);  // the forest AFTER this one
     if (tid == 0) {
       // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141); once per subtree (its part 0)
       double e1 = e_sum;
@@ -185,12 +223,12 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     CSTAMP(5);
 
     // ---- flush per-atom sums (a root's self volume: its own sphere + every node of its tree)
-    for (int la = tid; la < natoms; la += BS) {
-      const int hj = S.at_gidx[la];
-      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
-      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
-      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
-      glb_add(&A.hvat(kHvSvVdw, hj), (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+    // four adjacent lanes carry one atom's record: one 64-byte atomic request per atom instead of four
+    for (int k = tid; k < 4 * natoms; k += BS) {
+      const int la = k >> 2, comp = k & 3;
+      double v = S.at[6 + comp][la];
+      if (comp == 3 && la < m && (S.rt[kRtPart + la] & 0xff) == 0) v += S.at[4][la];
+      glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], v);
     }
     if (tid == 0) {
       double e2 = e_sum;
@@ -200,6 +238,9 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
     tree_barrier<NCAP>();
     CSTAMP(6);
     CSTAMP_FLUSH();
+    } while (false);
+    if (!queued) break;
+    slot = next_forest(tid, &s_next, ticket);
   }
 }
 
@@ -207,13 +248,17 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_cavity(TreeArgs A) {
 // nu_i = (W_i+U_i)/V_i formed on the fly from the chain-rule sums, gradient only.  The reference does two passes
 // (W then U); the pass is linear in nu, so one pass with the sum gives the same gradient.
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
+  __shared__ int s_next;
   const int tid = threadIdx.x;
   const int nforests = A.cur_nforests()[0];
-  for (int slot = blockIdx.x; slot < nforests; slot += gridDim.x) {
+  const bool queued = nforests > (int)gridDim.x;
+  for (int slot = blockIdx.x; slot < nforests;) {
+    int ticket = nforests;
+    do {
     PSTAMP_BEGIN();
     // One round trip to the stored topology: the paths, the membership list and the local atom list are requested
     // together with the header (capacity-strided slots: reading past the forest's own entries is harmless, the
@@ -236,7 +281,10 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     }
     const int nnodes = H->nnodes, natoms = H->natoms, m = H->nroots;
     int npairs = H->npairs;
-    if (nnodes <= m) continue;  // not built (capacity overflow: the host repeats the evaluation) or lone atoms only
+    if (nnodes <= m) {  // not built (capacity overflow: the host repeats the evaluation) or lone atoms only
+      if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
+      break;
+    }
     if (tid == 0) {
       int run = m;
       for (int q = 0; q < m; q++) {
@@ -272,19 +320,22 @@ __global__ __launch_bounds__(BS, BS / 64) void k_tree_pseudo(TreeArgs A) {
     }
     tree_barrier<NCAP>();
     PSTAMP(0);
+    // every global load of this forest has been consumed: ask for the next one (see k_tree_cavity)
+    if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
     double e_sum = 0.0;
     volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, kPairs ? &pair_word : nullptr);
     PSTAMP(1);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
-    for (int la = tid; la < natoms; la += BS) {
-      const int hj = S.at_gidx[la];
-      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
-      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
-      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+    for (int k = tid; k < 4 * natoms; k += BS) {  // (lane 3 of every four idles: the record's fourth word is the self volume)
+      const int la = k >> 2, comp = k & 3;
+      if (comp < 3) glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], S.at[6 + comp][la]);
     }
     tree_barrier<NCAP>();
     PSTAMP(2);
     PSTAMP_FLUSH();
+    } while (false);
+    if (!queued) break;
+    slot = next_forest(tid, &s_next, ticket);
   }
 }
 
@@ -295,6 +346,9 @@ extern "C" void agbnp_debug_stamps(unsigned long long* out, int reset) {
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
   }
+}
+extern "C" void agbnp_debug_wg_log(unsigned long long* out, int slots) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 8 * (size_t)(slots < kWgLogSlots ? slots : kWgLogSlots));
 }
 extern "C" void agbnp_debug_stamps_slowest(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_slowest), sizeof(unsigned long long) * 24);
@@ -309,30 +363,35 @@ extern "C" void agbnp_debug_stamps_max(unsigned long long* out, int reset) {
 #endif
 
 // ---- host-side launchers -------------------------------------------------------------------------
-// variant: 0 = (512 nodes, 64 atoms) LDS, 1 = (1024,128) LDS, 2 = (2048,256) LDS, 3 = (32768,1024) global scratch
+// variant: 0 = (432 nodes, 64 local atoms) in LDS, five workgroups per CU; 1 = (512, 64), four; 2 = (1024, 128), two;
+// 3 = (2048, 256), one; 4 = (32768, 256) in a per-workgroup HBM slab
 constexpr int kGlobalNodeCap = 32768;
 constexpr int kGlobalAtomCap = 256;  // one byte per atom in the path words
 constexpr int kBS = AGBNP_TREE_BLOCK;  // lanes per subtree (compile-time knob, default kTreeBlock)
 static_assert(kBS <= kTreeBlock && kBS % 64 == 0, "tree block size");
+// LDS is handed out in granules of 1280 bytes on gfx950: five workgroups per CU need <= 25 granules each
+static_assert((TreeStore<432, 64>::kBytes + 16 + 1279) / 1280 * 5 <= 128, "five build workgroups per CU");
+static_assert((TreeStore<512, 64>::kBytes + 1279) / 1280 * 4 <= 128, "four build workgroups per CU");
 
 size_t tree_variant_lds_bytes(int variant) {
   switch (variant) {
-    case 0: return TreeStore<512, 64>::kBytes;
-    case 1: return TreeStore<1024, 128>::kBytes;
-    case 2: return TreeStore<2048, 256>::kBytes;
+    case 0: return TreeStore<432, 64>::kBytes;
+    case 1: return TreeStore<512, 64>::kBytes;
+    case 2: return TreeStore<1024, 128>::kBytes;
+    case 3: return TreeStore<2048, 256>::kBytes;
     default: return 0;
   }
 }
 size_t tree_variant_scratch_bytes(int variant) {
-  return variant == 3 ? ((TreeStore<kGlobalNodeCap, kGlobalAtomCap>::kBytes + 255) / 256) * 256 : 0;
+  return variant == 4 ? ((TreeStore<kGlobalNodeCap, kGlobalAtomCap>::kBytes + 255) / 256) * 256 : 0;
 }
 int tree_variant_node_cap(int variant) {
-  static const int caps[4] = {512, 1024, 2048, kGlobalNodeCap};
+  static const int caps[5] = {432, 512, 1024, 2048, kGlobalNodeCap};
   return caps[variant];
 }
 
 int tree_variant_atom_cap(int variant) {
-  static const int caps[4] = {64, 128, 256, kGlobalAtomCap};
+  static const int caps[5] = {64, 64, 128, 256, kGlobalAtomCap};
   return caps[variant];
 }
 
@@ -346,16 +405,18 @@ static hipError_t launch_tree(K kernel, int grid, size_t lds, const TreeArgs& A,
   return hipGetLastError();
 }
 
+// slots: workgroups to launch = min(work slots that may be planned, workgroups the device keeps resident)
 hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
 #ifdef AGBNP_STAMPS  // diagnostic build only: time the largest subtrees alone (results are incomplete)
   if (const char* env = getenv("AGBNP_DIAG_TREE_GRID"))
-    return launch_tree(k_tree_cavity<512, 64, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<512, 64>::kBytes, A, st);
+    return launch_tree(k_tree_cavity<432, 64, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<432, 64>::kBytes, A, st);
 #endif
   switch (variant) {
-    case 0: return launch_tree(k_tree_cavity<512, 64, kBS, false>, slots, TreeStore<512, 64>::kBytes, A, st);
-    case 1: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kBytes, A, st);
-    case 2: return launch_tree(k_tree_cavity<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kBytes, A, st);
+    case 0: return launch_tree(k_tree_cavity<432, 64, kBS, false>, slots, TreeStore<432, 64>::kBytes, A, st);
+    case 1: return launch_tree(k_tree_cavity<512, 64, kBS, false>, slots, TreeStore<512, 64>::kBytes, A, st);
+    case 2: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kBytes, A, st);
+    case 3: return launch_tree(k_tree_cavity<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kBytes, A, st);
     default:
       return launch_tree(k_tree_cavity<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
@@ -364,9 +425,10 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, slots, TreeStore<512, 64>::kReplayBytes, A, st);
-    case 1: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kReplayBytes, A, st);
-    case 2: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kReplayBytes, A, st);
+    case 0: return launch_tree(k_tree_pseudo<432, 64, kBS, false>, slots, TreeStore<432, 64>::kReplayBytes, A, st);
+    case 1: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, slots, TreeStore<512, 64>::kReplayBytes, A, st);
+    case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kReplayBytes, A, st);
+    case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kReplayBytes, A, st);
     default:
       return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
   }
