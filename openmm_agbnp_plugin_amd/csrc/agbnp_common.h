@@ -19,6 +19,9 @@ constexpr double kHBRadius = (1.4 * (0.1f));        // AGBNPForce.h:33
 constexpr double kSolventRadius = (1.0 * (0.1f));   // AGBNPForce.h:30
 constexpr double kI4MaxA = 2.0;                     // AGBNPUtils.h:124
 constexpr int kI4Nodes = 16;                        // AGBNPUtils.h:126
+// Row stride of the device copy of the tables, in 16-byte entries: one more than the knots, so that row r starts 4 r LDS
+// banks on from row 0 and lanes that look up the same knot of different type pairs do not meet in one bank
+constexpr int kLutStride = kI4Nodes + 1;
 constexpr long kRadiusPrecision = 10000;            // AGBNPUtils.h:155
 constexpr double kPi = 3.14159265358979323846;
 

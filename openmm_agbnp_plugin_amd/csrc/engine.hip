@@ -246,7 +246,7 @@ void wire_args(agbnp_hip_context* c) {
   P.lut = c->d_lut.p;
   P.nti = c->lut.nscreened;
   P.ntj = c->lut.nscreener;
-  P.lut_entries = c->lut.nscreened * c->lut.nscreener * kI4Nodes;
+  P.lut_entries = c->lut.nscreened * c->lut.nscreener * kLutStride;
   P.hx = c->hrow(kHvX);
   P.hy = c->hrow(kHvY);
   P.hz = c->hrow(kHvZ);
@@ -589,10 +589,11 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   for (int i = 0; i < n; i++) ameta[i] = make_int2(c->lut.type_screened[i], c->lut.type_screener[i]);
   CREATE_TRY(c->d_ameta.upload(ameta));
   const double dr = kI4MaxA / (kI4Nodes - 1);
-  std::vector<double2> lut(std::max<size_t>(1, c->lut.y.size()));
-  for (size_t k = 0; k < c->lut.y.size(); k++) lut[k] = make_double2(c->lut.y[k], c->lut.y2[k] * dr * dr / 6.0);
+  std::vector<double2> lut(std::max<size_t>(1, c->lut.y.size() / kI4Nodes * kLutStride), make_double2(0.0, 0.0));
+  for (size_t k = 0; k < c->lut.y.size(); k++)  // rows padded to kLutStride entries (LDS bank spreading)
+    lut[k / kI4Nodes * kLutStride + k % kI4Nodes] = make_double2(c->lut.y[k], c->lut.y2[k] * dr * dr / 6.0);
   CREATE_TRY(c->d_lut.upload(lut));
-  if ((size_t)c->lut.y.size() * sizeof(double2) > 128 * 1024)  // + 24 KB of tile records in k_dborn_tiles
+  if (lut.size() * sizeof(double2) > 128 * 1024)  // + 24 KB of tile records in k_dborn_tiles
     return bail(AGBNP_HIP_ERR_CAPACITY, "agbnp_hip_create: too many distinct radius pairs for the LDS-resident I4 tables", c);
 
   int rc = upload_parameters(c);

@@ -616,8 +616,8 @@ __device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const do
     const int tj = __double2loint(ty);  // screened type | screener type << 16
     if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(ty) >= 0 && (k != masked_step || lower)) {
       const double d = d2 * rsqrt_pos(d2);
-      sum_j = fma(si, spline_value(s_lut, ((tj & 0xffff) * ntj + tsr) * kI4Nodes, d), sum_j);   // i descreens j
-      if (kBoth) sum_i = fma(zs.y, spline_value(s_lut, (row + (tj >> 16)) * kI4Nodes, d), sum_i);  // j descreens i
+      sum_j = fma(si, spline_value(s_lut, ((tj & 0xffff) * ntj + tsr) * kLutStride, d), sum_j);   // i descreens j
+      if (kBoth) sum_i = fma(zs.y, spline_value(s_lut, (row + (tj >> 16)) * kLutStride, d), sum_i);  // j descreens i
     }
     sum_j = rot1(sum_j);
   }
@@ -716,12 +716,12 @@ __device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restri
       const double rinv = rsqrt_pos(d2);
       const double d = d2 * rinv;
       double q2, dq2;  // i descreens j
-      spline_value_deriv(s_lut, ((tj & 0xffff) * ntj + L.tsr) * kI4Nodes, d, q2, dq2);
+      spline_value_deriv(s_lut, ((tj & 0xffff) * ntj + L.tsr) * kLutStride, d, q2, dq2);
       L.wui = fma(zw.y, q2, L.wui);
       double t = zw.y * L.s * dq2;
       if (kBoth) {  // j descreens i
         double q1, dq1;
-        spline_value_deriv(s_lut, (L.row + (tj >> 16)) * kI4Nodes, d, q1, dq1);
+        spline_value_deriv(s_lut, (L.row + (tj >> 16)) * kLutStride, d, q1, dq1);
         L.wuj = fma(L.bw, q1, L.wuj);
         t = fma(L.bw * sm.x, dq1, t);
       }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     // four adjacent lanes carry one atom's record: one 64-byte atomic request per atom instead of four
     for (int k = tid; k < 4 * natoms; k += BS) {
       const int la = k >> 2, comp = k & 3;
-      double v = S.at[6 + comp][la];
+      double v = S.at[6][comp * ACAP + la];  // rows 6..9 are contiguous (no dynamic index into the row table)
       if (comp == 3 && la < m && (S.rt[kRtPart + la] & 0xff) == 0) v += S.at[4][la];
       glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], v);
     }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     for (int k = tid; k < 4 * natoms; k += BS) {  // (lane 3 of every four idles: the record's fourth word is the self volume)
       const int la = k >> 2, comp = k & 3;
-      if (comp < 3) glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], S.at[6 + comp][la]);
+      if (comp < 3) glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], S.at[6][comp * ACAP + la]);
     }
     tree_barrier<NCAP>();
     PSTAMP(2);
