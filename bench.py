@@ -9,7 +9,10 @@ metric / value : aggregate AGBNP-force-limited ns/day over all replicas at the 1
                  reference's example/1dwc_benchmark.py:20  ( ns/day = 86.4 / ms_per_eval per replica ).
 multi-GPU      : replicas only (the force evaluation does not shard).  One process per
                  GPU, independent geometries, no data-path collective; RCCL carries only the timing
-                 reduction (MAX of the elapsed time) and the throughput gather.
+                 reduction (MAX of the elapsed time) and the gather of the per-rank records.
+secondary      : on one GPU the same JSON line also carries BASELINE.json's other configurations (trpcage
+                 GaussVol, trpcage AGBNP1 with CutoffNonPeriodic 1.2 nm, the 16 608-atom HIV-RT stand-in) and the
+                 OpenCL-semantics fast mode, each with its own parity-on-sample figure.  --secondary 0 skips them.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -29,6 +32,17 @@ import numpy as np  # noqa: E402
 import openmm_agbnp_plugin_amd as P  # noqa: E402  (loads the HIP runtime shared with torch)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SIMDS = 1024           # 256 CUs x 4
+CLOCK_GHZ = 2.4        # max clock; the chip holds ~2.3 GHz in these kernels (profiles/r02/wg_timeline.txt)
+
+# Vector instructions of one pair step of one wave (64 pairs), read off the gfx950 assembly of the shipped kernels
+# (scripts/resource_table.py --keep-asm; loop bodies of k_gb_tiles / k_born_tiles / k_dborn_tiles): total VALU
+# and the FP64 ones among them.  {kernel: {tile kind: (valu, f64)}}
+PAIR_STEP_VALU = {
+    "k_gb_tiles": {"all": (65, 48.5)},
+    "k_born_tiles": {"hh": (47, 35), "hl": (34, 26)},
+    "k_dborn_tiles": {"hh": (74, 56), "hl": (52, 40)},
+}
 
 
 def algorithmic_bytes(n_atoms, slots):
@@ -51,9 +65,44 @@ def algorithmic_bytes(n_atoms, slots):
     return 8 * node + 4 * tile + atom, per_kernel
 
 
+def pair_wave_steps(system, pos):
+    """Wave-steps (one wave meeting 64 pairs) that the three pair kernels execute for this geometry: GB walks every
+    64x64 tile of atoms; the range-limited stages walk heavy x heavy and heavy x hydrogen tiles of the pair order and
+    skip tiles whose bounding boxes are more than the tables' 2 nm reach apart (same test as the kernels)."""
+    n = system.n
+    nb = (n + 63) // 64
+    gb = (nb * (nb - 1) // 2) * 64 + nb * 32
+    heavy = np.flatnonzero(system.ishydrogen == 0)
+    light = np.flatnonzero(system.ishydrogen == 1)
+    boxes = []
+    for idx in (heavy, light):
+        for b in range(0, len(idx), 64):
+            p = pos[idx[b:b + 64]]
+            boxes.append((p.min(axis=0), p.max(axis=0)))
+    nhb = (len(heavy) + 63) // 64
+    lo = np.array([b[0] for b in boxes])
+    hi = np.array([b[1] for b in boxes])
+    hh = hl = 0
+    for i in range(nhb):
+        gap = np.maximum(0.0, np.maximum(lo - hi[i], lo[i] - hi))
+        near = (gap ** 2).sum(axis=1) < 4.0
+        hh += 32 + 64 * int(near[i + 1:nhb].sum())  # diagonal tile: 32 wave-steps
+        hl += 64 * int(near[nhb:].sum())
+    return {"k_gb_tiles": {"all": gb}, "k_born_tiles": {"hh": hh, "hl": hl}, "k_dborn_tiles": {"hh": hh, "hl": hl}}
+
+
+def gather_records(dist, record, device):
+    """All-gather of one small python record per rank (backend nccl (= RCCL over xGMI) on GPUs, gloo in the CPU
+    tests).  Returns the list of records by rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [record]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, record)
+    return out
+
+
 def gather_throughput(dist, local_ns_day, local_ms, device):
-    """All-gather of the per-replica {ns/day, ms/eval} records (2 doubles per rank); backend nccl (= RCCL over
-    xGMI) on GPUs, gloo in the CPU tests.  Returns a list of (ns_day, ms) per rank."""
+    """All-gather of the per-replica {ns/day, ms/eval} records (2 doubles per rank).  Returns (ns_day, ms) per rank."""
     import torch
     rec = torch.tensor([local_ns_day, local_ms], dtype=torch.float64, device=device)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -72,11 +121,11 @@ def max_over_ranks(dist, seconds, device):
     return float(t[0])
 
 
-def cpu_baseline_leg(system, geometries, gpu_results, evals):
+def cpu_baseline_leg(system, geometries, gpu_results, evals, version=1, **oracle_kw):
     """The ONLY place bench.py touches the oracle: the CPU restatement timed on one host core over a bounded
     sample of the same geometries.  As a by-product the sample's GPU results are compared with it."""
     from oracle import Oracle
-    o = Oracle(*system.params(), version=1)
+    o = Oracle(*system.params(), version=version, **oracle_kw)
     o.execute(geometries[0])  # warm caches / page in
     t0 = time.perf_counter()
     outs = [o.execute(geometries[k]) for k in range(evals)]
@@ -87,6 +136,83 @@ def cpu_baseline_leg(system, geometries, gpu_results, evals):
     return ms, de, df
 
 
+def load_workload(name):
+    if name.endswith("_x4"):  # HIV-RT stand-in (BASELINE.json config 4): 2x2x1 lattice of copies, 7 nm pitch
+        return P.lattice(P.load_system(name[:-3]), 2, 2, 1, 7.0)
+    return P.load_system(name)
+
+
+class Replica:
+    """One context + its device-resident geometries, forces and energy."""
+
+    def __init__(self, torch, system, version, device, dev_index, steps, seed0, method=None, cutoff=1.0, mode=None):
+        self.torch, self.system, self.n = torch, system, system.n
+        force = P.AGBNPForce.from_arrays(*system.params(), version=version)
+        force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic if method is None else method)  # example/1dwc_benchmark.py:10
+        force.setCutoffDistance(cutoff)
+        self.kernel = P.HipCalcAGBNPForceKernel(device=dev_index, mode=mode) if mode else P.HipCalcAGBNPForceKernel(device=dev_index)
+        self.kernel.initialize(force)
+        self.geoms = np.stack([system.jittered(seed0 + s) for s in range(steps)])
+        self.d_pos = torch.tensor(self.geoms, dtype=torch.float64, device=device).contiguous()
+        self.d_force = torch.zeros((self.n, 3), dtype=torch.float64, device=device)
+        self.d_energy = torch.zeros((1,), dtype=torch.float64, device=device)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.step_bytes = self.n * 3 * 8
+
+    def run(self, first, count):
+        base = self.d_pos.data_ptr()
+        for s in range(first, first + count):
+            self.kernel.execute_device(base + s * self.step_bytes, self.d_force.data_ptr(), self.d_energy.data_ptr(), self.stream)
+
+    def settle(self, count):
+        """Warm-up: also settles the tree-capacity variant (repeat until no evaluation of the batch was withheld)."""
+        for _ in range(8):
+            self.run(0, max(count, 1))
+            if not self.kernel.finish(self.stream):
+                return
+        raise SystemExit("bench: tree capacity did not settle")
+
+    def timed(self, first, count, barrier=lambda: None):
+        torch = self.torch
+        for _ in range(3):
+            self.d_force.zero_()
+            self.d_energy.zero_()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.run(first, count)
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            # finish() reads the device's sticky overflow log: EVERY one of the timed evaluations is accounted for, not
+            # just the last.  Non-zero = some were withheld (capacity negotiation still under way): time the run again.
+            if not self.kernel.finish(self.stream):
+                return t1 - t0
+        raise SystemExit("bench: tree capacity did not settle")
+
+    def host_results(self, first, count):
+        out = []
+        for k in range(count):
+            f = np.zeros((self.n, 3))
+            e = self.kernel.execute(self.geoms[first + k], f)
+            out.append((e, f))
+        return out
+
+
+def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_evals, method=None, cutoff=1.0, mode=None, **oracle_kw):
+    """ms/eval, ns/day and parity-on-sample of another configuration (rank 0, one GPU)."""
+    system = load_workload(name)
+    r = Replica(torch, system, version, device, dev_index, steps + warmup, 7000, method=method, cutoff=cutoff, mode=mode)
+    r.settle(warmup)
+    ms = 1e3 * r.timed(warmup, steps) / steps
+    entry = {"workload": name, "atoms": system.n, "version": version, "ms_per_eval": ms, "ns_day": 86.4 / ms}
+    if cpu_evals > 0:
+        cpu_ms, de, df = cpu_baseline_leg(system, r.geoms[warmup:], r.host_results(warmup, cpu_evals), cpu_evals, version=version, **oracle_kw)
+        entry.update({"cpu_ms_per_eval": cpu_ms, "parity_on_sample": {"evals": cpu_evals, "max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df}})
+    return entry
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +220,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--system", default="1dwc")
     ap.add_argument("--cpu-evals", type=int, default=20, help="size of the CPU-baseline sample (0 disables the leg)")
+    ap.add_argument("--secondary", type=int, default=1, help="also time BASELINE.json's other configurations (one GPU only)")
+    ap.add_argument("--mode", default="reference", choices=["reference", "fast"],
+                    help="fast = the OpenCL platform's semantics (cutoff on every pair stage); printed as its own line")
     args = ap.parse_args()
 
     import torch
@@ -101,9 +230,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={world}")
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={env_world}")
     # one process per GPU.  AGBNP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks:
     # ranks then share devices (local_rank modulo the device count) and the two tiny collectives run on CPU tensors.
     backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
@@ -111,87 +240,53 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if env_world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+    world = dist.get_world_size() if dist.is_initialized() else 1  # what took part, not what the environment promised
 
     K, W = args.steps, args.warmup
-    if args.system.endswith("_x4"):  # HIV-RT stand-in (BASELINE.json config 4): 2x2x1 lattice of copies, 7 nm pitch
-        system = P.lattice(P.load_system(args.system[:-3]), 2, 2, 1, 7.0)
-    else:
-        system = P.load_system(args.system)
+    system = load_workload(args.system)
     n = system.n
-    force = P.AGBNPForce.from_arrays(*system.params(), version=1)
-    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)  # as example/1dwc_benchmark.py:10 (inert: Reference semantics)
-    force.setCutoffDistance(1.0)
-    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
-    kernel.initialize(force)
-
-    # synthetic geometries, different per replica; resident in HBM before the timed region
-    total = K + W
-    geoms = np.stack([system.jittered(1000 * rank + s) for s in range(total)])
-    d_pos = torch.tensor(geoms, dtype=torch.float64, device=device).contiguous()
-    d_force = torch.zeros((n, 3), dtype=torch.float64, device=device)
-    d_energy = torch.zeros((1,), dtype=torch.float64, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
-    step_bytes = n * 3 * 8
-
-    def run_steps(first, count):
-        base = d_pos.data_ptr()
-        for s in range(first, first + count):
-            kernel.execute_device(base + s * step_bytes, d_force.data_ptr(), d_energy.data_ptr(), stream)
-
-    # warm-up (also settles the tree-capacity variant: repeat until no evaluation asks for a re-run)
-    for _ in range(4):
-        run_steps(0, max(W, 1))
-        if not kernel.finish(stream):
-            break
+    mode = None if args.mode == "reference" else args.mode
+    rep = Replica(torch, system, 1, device, dev_index, K + W, 1000 * rank, mode=mode)
+    kernel = rep.kernel
+    rep.settle(W)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    elapsed = None
-    for _ in range(3):
-        d_force.zero_()
-        d_energy.zero_()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_steps(W, K)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        # finish() reads the device's sticky overflow log: EVERY one of the K timed evaluations is accounted for, not
-        # just the last.  Non-zero = some were withheld (capacity negotiation still under way): time the run again.
-        if not kernel.finish(stream):
-            elapsed = t1 - t0
-            break
-    if elapsed is None:
-        raise SystemExit("bench: tree capacity did not settle")
-    elapsed = max_over_ranks(dist if world > 1 else None, elapsed, coll_device)
+    elapsed_local = rep.timed(W, K, barrier)
+    elapsed = max_over_ranks(dist if world > 1 else None, elapsed_local, coll_device)
     ms_per_step = 1e3 * elapsed / K
-    local_ns_day = 86.4 / ms_per_step
-    per_rank = gather_throughput(dist if world > 1 else None, local_ns_day, ms_per_step, coll_device)
+    props = torch.cuda.get_device_properties(dev_index)
+    record = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
+              "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)),
+              "ms_per_eval": 1e3 * elapsed_local / K, "ns_day": 86.4 / (1e3 * elapsed_local / K), "pid": os.getpid()}
+    per_rank = gather_records(dist if world > 1 else None, record, coll_device)
     value = world * 86.4 / ms_per_step  # whole job: all replicas' steps / max-over-ranks time
 
     result = None
     if rank == 0:
         slots = int(kernel.scalar("total_nodes")) + (n - system.nheavy) + 1  # + hydrogen slots + root, as the reference counts
         b_eval, b_kernel = algorithmic_bytes(n, slots)
+        semantics = ("Reference semantics: all pairs" if mode is None else
+                     "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff")
         result = {
             "metric": "AGBNP1 force-eval-limited ns/day (1 fs step), thrombin 1dwc, independent replicas",
             "value": value, "unit": "ns/day", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "force_eval_ms": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.system} (thrombin, {n} atoms, {system.nheavy} heavy) AGBNP1 version=1, "
-                                   "CutoffNonPeriodic 1.0 nm (Reference semantics: all pairs), one jittered geometry per step "
+                                   f"CutoffNonPeriodic 1.0 nm ({semantics}), one jittered geometry per step "
                                    "(sigma 0.002 nm), positions/forces/energy resident in HBM",
-                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant"))},
-            "per_replica_ns_day": [round(r[0], 4) for r in per_rank],
+                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode},
+            "per_replica_ns_day": [round(r["ns_day"], 4) for r in per_rank],
+            "ranks": per_rank,
+            "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in per_rank}),
             "algorithmic_bytes_per_eval": b_eval,
             "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
         }
@@ -200,8 +295,8 @@ def main():
     #      that the events do not sit inside the timed region above)
     if rank == 0:
         kernel.set_profiling(True)
-        run_steps(W, K)
-        if kernel.finish(stream):
+        rep.run(W, K)
+        if kernel.finish(rep.stream):
             raise SystemExit("bench: an evaluation of the profiling pass overflowed after the timed pass had settled")
         times = kernel.kernel_times()
         kernel.set_profiling(False)
@@ -226,6 +321,22 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
+        # the roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave
+        # holds its SIMD for 4 cycles at FP64 rate), measured against the wave-steps this geometry makes them execute
+        steps_by_kernel = pair_wave_steps(system, rep.geoms[W])
+        issue = []
+        for kname, kinds in PAIR_STEP_VALU.items():
+            if kname not in avg_us:
+                continue
+            valu = sum(steps_by_kernel[kname][kind] * v for kind, (v, _) in kinds.items())
+            f64 = sum(steps_by_kernel[kname][kind] * f for kind, (_, f) in kinds.items())
+            bound_us = valu * 4 / SIMDS / (CLOCK_GHZ * 1e3)
+            issue.append({"bound": "fp64_issue", "kernel": kname, "wave_steps": int(sum(steps_by_kernel[kname].values())),
+                          "valu_instructions": int(valu), "fp64_instructions": int(f64), "cycles_per_instruction": 4,
+                          "bound_us": round(bound_us, 2), "avg_launch_us": round(avg_us[kname], 2),
+                          "frac": round(bound_us / avg_us[kname], 3) if avg_us[kname] > 0 else None,
+                          "achieved": round(2 * f64 * 64 / (avg_us[kname] * 1e-6) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s (FP64 FMA = 2)"})
+        result["rooflines_issue"] = issue
         result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
         result["kernel_sum_us"] = round(sum(avg_us.values()), 2)
         result["kernel_event_us"] = {k: round(v, 2) for k, v in raw_us.items()}
@@ -234,15 +345,23 @@ def main():
     # ---- CPU baseline (rank 0, single replica only)
     if rank == 0 and world == 1 and args.cpu_evals > 0:
         evals = min(args.cpu_evals, K)
-        gpu_results = []
-        for k in range(evals):
-            f = np.zeros((n, 3))
-            e = kernel.execute(geoms[W + k], f)
-            gpu_results.append((e, f))
-        cpu_ms, de, df = cpu_baseline_leg(system, geoms[W:], gpu_results, evals)
+        oracle_kw = {} if mode is None else {"cutoff": 1.0}
+        cpu_ms, de, df = cpu_baseline_leg(system, rep.geoms[W:], rep.host_results(W, evals), evals, **oracle_kw)
         result["cpu_baseline"] = {"value": 86.4 / cpu_ms, "unit": "ns/day", "ms_per_eval": cpu_ms, "cores": 1, "kind": "port",
                                   "sample": f"first {evals} of the {K} timed geometries, single-threaded FP64 oracle (oracle/agbnp_oracle.cpp, g++ -O2)"}
         result["parity_on_sample"] = {"max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df, "tolerance": 1e-4}
+
+    # ---- BASELINE.json's other configurations, bounded (rank 0, one GPU, Reference-semantics run only)
+    if rank == 0 and world == 1 and args.secondary and mode is None and args.system == "1dwc":
+        del rep
+        sec = []
+        sec.append(dict(config="1: trpcage GaussVol (version 0), NoCutoff",
+                        **secondary_entry(torch, "trpcage", 0, device, dev_index, 200, 20, 20, method=P.AGBNPForce.NoCutoff)))
+        sec.append(dict(config="2: trpcage AGBNP1 (version 1), CutoffNonPeriodic 1.2 nm",
+                        **secondary_entry(torch, "trpcage", 1, device, dev_index, 200, 20, 20, cutoff=1.2)))
+        sec.append(dict(config="4: HIV-RT stand-in = 2x2x1 lattice of 1dwc (synthetic), AGBNP1",
+                        **secondary_entry(torch, "1dwc_x4", 1, device, dev_index, 40, 6, 1)))
+        result["secondary"] = sec
 
     if rank == 0:
         print(json.dumps(result))

@@ -445,6 +445,22 @@ def test_config4_lattice_properties(gpu_required, systems):
     assert int(ctx.kernel.scalar("total_nodes")) == 4 * int(c1.kernel.scalar("total_nodes"))
 
 
+def test_config4_lattice_against_the_oracle_at_full_size(gpu_required, systems):
+    """BASELINE.json config 4 at size (16 608 atoms, 8336 heavy: 131 blocks of neighbour masks, more forests than
+    resident workgroups, so the work queue of the tree kernels runs, culled Born / chain-rule tiles): energy and every
+    force component against the CPU oracle on the file geometry and on a jittered one (the oracle takes ~8 s each)."""
+    s = P.lattice(systems("1dwc"), 2, 2, 1, 7.0)
+    oracle = Oracle(*s.params(), version=1)
+    ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    for pos in (s.pos, s.jittered(3, sigma=0.004)):
+        ctx.setPositions(pos)
+        e, f = ctx.getState()  # first evaluation: one subtree per workgroup; second: packed forests
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+    assert int(ctx.kernel.scalar("forests")) < s.nheavy
+    assert int(ctx.kernel.scalar("forests")) > 5 * 256  # more than fit the device at once
+
+
 def test_finite_difference_gradient_on_gpu(gpu_required, systems):
     s = systems("fixture264")
     force = P.AGBNPForce.from_arrays(*s.params(), version=1)

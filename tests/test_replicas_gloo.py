@@ -26,9 +26,11 @@ def _worker(rank, world, port, out):
     dev = torch.device("cpu")
     elapsed = bench.max_over_ranks(dist, 1.0 + rank, dev)          # slowest rank defines the job time
     recs = bench.gather_throughput(dist, 100.0 + rank, 0.5 + rank, dev)
+    ident = bench.gather_records(dist, {"rank": rank, "device_index": rank, "ms_per_eval": 0.5 + rank}, dev)
+    world = dist.get_world_size()  # what bench.py reports as n_gpus
     dist.barrier()
     dist.destroy_process_group()
-    out.put((rank, elapsed, recs))
+    out.put((rank, elapsed, recs, ident, world))
 
 
 def test_world_size_two_gather_and_max():
@@ -45,9 +47,11 @@ def test_world_size_two_gather_and_max():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, elapsed, recs in results:
+    for rank, elapsed, recs, ident, world in results:
         assert elapsed == 2.0
         assert recs == [(100.0, 0.5), (101.0, 1.5)]
+        assert world == 2
+        assert [r["rank"] for r in ident] == [0, 1] and [r["device_index"] for r in ident] == [0, 1]
 
 
 def test_single_process_passthrough():
@@ -56,6 +60,7 @@ def test_single_process_passthrough():
     import bench
     assert bench.max_over_ranks(None, 0.25, torch.device("cpu")) == 0.25
     assert bench.gather_throughput(None, 146.0, 0.59, torch.device("cpu")) == [(146.0, 0.59)]
+    assert bench.gather_records(None, {"rank": 0}, torch.device("cpu")) == [{"rank": 0}]
     total, per_kernel = bench.algorithmic_bytes(4152, 216146)
     assert total == 216146 * 128 * 8 + 2145 * 4096 * 4 + 4152 * 104  # 257 MB for 1dwc
     assert abs(total - 257e6) < 1e6
