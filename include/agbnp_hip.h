@@ -74,6 +74,22 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
 int agbnp_hip_execute_device(agbnp_hip_context* ctx, const double* d_positions, double* d_forces, double* d_energy,
                              void* stream);
 
+/* The same evaluation in the data conventions of an OpenMM GPU ComputeContext -- what the reference's OpenCL platform
+ * kernel reads and writes (platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556, kernels/GVolReduceTree.cl:92-121):
+ *   d_posq            real4 {x, y, z, q} per atom in the CONTEXT's atom order, float4 (posq_is_double = 0) or double4
+ *   d_posq_correction float4 low-order parts in mixed precision (position = posq + correction), else NULL
+ *   d_atom_index      [N] context slot -> particle index of the System/Force (ComputeContext::getAtomIndexArray);
+ *                     NULL = identity
+ *   d_force_buffer    the context's 64-bit fixed-point force buffer (value * 2^32), three planes of
+ *                     padded_num_atoms words [x | y | z] in context order; forces are ADDED with integer atomics
+ *   d_energy_buffer   the context's energy accumulator, double (energy_is_double) or float; the energy is ADDED to
+ *                     element energy_slot; NULL = no energy output
+ * Two adapter launches around the seven of agbnp_hip_execute_device; same asynchronous contract, same overflow
+ * contract (a withheld evaluation adds nothing to the context's buffers), same agbnp_hip_finish(). */
+int agbnp_hip_execute_openmm(agbnp_hip_context* ctx, const void* d_posq, int posq_is_double, const void* d_posq_correction,
+                             const int* d_atom_index, int padded_num_atoms, long long* d_force_buffer, void* d_energy_buffer,
+                             int energy_is_double, int energy_slot, void* stream);
+
 /* Waits for `stream`, then reads and clears the overflow log.  *must_repeat = the number of evaluations enqueued
  * since the previous agbnp_hip_finish() whose outputs were withheld (0: every one is complete and in the caller's
  * buffers).  If it is not 0 the context has already prepared the repeat (one subtree per workgroup, and the next

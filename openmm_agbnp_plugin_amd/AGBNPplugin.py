@@ -166,6 +166,19 @@ class HipCalcAGBNPForceKernel:
         if rc != _lib.OK:
             raise OpenMMException(_lib.last_error(self._h))
 
+    def execute_openmm(self, d_posq, posq_is_double, d_posq_correction, d_atom_index, padded_num_atoms, d_force_buffer,
+                       d_energy_buffer, energy_is_double, energy_slot=0, stream=None):
+        """The data conventions of an OpenMM GPU context (reference OpenCL platform): posq real4 in the context's
+        atom order (+ optional float4 correction), atomIndex map, 2^32 fixed-point force planes, energy buffer slot.
+        Raw device pointers (ints; 0 = NULL).  Asynchronous; call finish()."""
+        self._need()
+        rc = _lib.load().agbnp_hip_execute_openmm(self._h, C.c_void_p(d_posq), int(bool(posq_is_double)), C.c_void_p(d_posq_correction or 0),
+                                                  C.c_void_p(d_atom_index or 0), int(padded_num_atoms), C.c_void_p(d_force_buffer),
+                                                  C.c_void_p(d_energy_buffer or 0), int(bool(energy_is_double)), int(energy_slot),
+                                                  C.c_void_p(stream or 0))
+        if rc != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+
     def finish(self, stream=None):
         """Synchronise and read the device's overflow log: returns the number of evaluations enqueued since the
         previous finish() whose forces and energy were WITHHELD on the device (0 = all complete).  Those must be

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/agbnp_hip.h"
+#include "adapter_kernels.h"
 #include "agbnp_common.h"
 #include "i4_tables.h"
 #include "pair_kernels.h"
@@ -408,6 +409,8 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
+  HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * 3 * (size_t)n));
+  HIP_TRY(c, hipMemset(c->d_energy_tmp.p, 0, sizeof(double)));
   c->h_force_tmp.resize(3 * (size_t)n);
   return AGBNP_HIP_OK;
 }
@@ -637,6 +640,26 @@ int agbnp_hip_execute_device(agbnp_hip_context* c, const double* d_pos, double* 
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   return enqueue(c, d_pos, d_force, d_energy, st);
+}
+
+int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_is_double, const void* d_posq_correction,
+                             const int* d_atom_index, int padded_num_atoms, long long* d_force_buffer, void* d_energy_buffer,
+                             int energy_is_double, int energy_slot, void* stream) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!d_posq || !d_force_buffer) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_openmm: null pointer");
+  if (padded_num_atoms < c->n) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_openmm: padded atom count below the particle count");
+  if (posq_is_double && d_posq_correction)
+    return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_openmm: a position correction only exists beside float positions");
+  if (energy_slot < 0) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_openmm: negative energy slot");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  // the staging buffers start as zeros (allocation) and every output adapter hands them back as zeros
+  HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, st));
+  int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, st);
+  if (rc != AGBNP_HIP_OK) return rc;
+  HIP_TRY(c, launch_adapt_outputs(c->n, padded_num_atoms, d_atom_index, c->d_force_tmp.p, c->d_energy_tmp.p,
+                                  reinterpret_cast<unsigned long long*>(d_force_buffer), d_energy_buffer, energy_is_double, energy_slot, st));
+  return AGBNP_HIP_OK;
 }
 
 int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {

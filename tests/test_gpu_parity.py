@@ -166,6 +166,57 @@ def test_device_resident_entry_point(gpu_required, systems):
     assert np.abs((frc.cpu().numpy() - 1.5) / 3 - fo).max() < TIGHT
 
 
+@pytest.mark.parametrize("precision", ["double", "mixed", "single"])
+def test_openmm_context_data_conventions(gpu_required, systems, precision):
+    """agbnp_hip_execute_openmm: posq real4 in a REORDERED atom order with padding (+ the float correction array of
+    mixed precision), atomIndex map, 2^32 fixed-point force planes [x | y | z] over the padded count, energy added to
+    one slot of the context's accumulator -- the conventions of the reference's OpenCL platform
+    (OpenCLAGBNPKernels.cpp:541-556, GVolReduceTree.cl:92-121).  Against the oracle through a random permutation."""
+    torch = pytest.importorskip("torch")
+    s = systems("trpcage")
+    n, padded = s.n, 288  # OpenMM pads the atom count to a multiple of 32
+    rng = np.random.default_rng(5)
+    atom_index = rng.permutation(n).astype(np.int32)  # context slot -> particle
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    posq64 = np.zeros((padded, 4))
+    posq64[:n, :3] = s.pos[atom_index]
+    posq64[:n, 3] = s.charge[atom_index]
+    if precision == "double":
+        posq = torch.tensor(posq64, dtype=torch.float64, device=dev)
+        corr = None
+        used = posq64[:n, :3]
+    else:
+        hi = posq64.astype(np.float32)
+        posq = torch.tensor(hi, dtype=torch.float32, device=dev)
+        lo = (posq64 - hi.astype(np.float64)).astype(np.float32)
+        corr = torch.tensor(lo, dtype=torch.float32, device=dev) if precision == "mixed" else None
+        used = (hi.astype(np.float64) + (lo.astype(np.float64) if precision == "mixed" else 0.0))[:n, :3]
+    geometry = np.zeros((n, 3))
+    geometry[atom_index] = used  # the positions the engine actually sees, in particle order
+    eo, fo = Oracle(*s.params(), version=1).execute(geometry)
+    index = torch.tensor(atom_index, device=dev)
+    start = rng.integers(-2 ** 40, 2 ** 40, size=3 * padded)
+    fixed = torch.tensor(start, dtype=torch.int64, device=dev)
+    energy_is_double = precision != "single"
+    ebuf = torch.full((64,), 2.5, dtype=torch.float64 if energy_is_double else torch.float32, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    reps = 2
+    for _ in range(reps):
+        k.execute_openmm(posq.data_ptr(), precision == "double", corr.data_ptr() if corr is not None else 0, index.data_ptr(), padded,
+                         fixed.data_ptr(), ebuf.data_ptr(), energy_is_double, 7, stream)
+    assert k.finish(stream) == 0
+    got = (fixed.cpu().numpy() - start).reshape(3, padded).astype(np.float64) / 2.0 ** 32 / reps
+    assert not got[:, n:].any()  # padding slots untouched
+    f_slots = got[:, :n].T       # forces by context slot
+    assert np.abs(f_slots - fo[atom_index]).max() < 1e-6  # the fixed point resolves 2^-32 = 2.3e-10 per add
+    e = (ebuf.cpu().numpy().astype(np.float64) - 2.5)
+    assert not np.delete(e, 7).any()
+    assert abs(e[7] / reps - eo) < (TIGHT if energy_is_double else 2e-3)  # a float accumulator holds 7 digits of 2e3 kJ/mol
+
+
 def test_evaluation_is_graph_capturable(gpu_required, systems):
     """One evaluation = seven kernel launches on the caller's stream, no host synchronisation, no allocation after
     the first call: it can be captured into a HIP graph and replayed on new positions (MD inner loops)."""
