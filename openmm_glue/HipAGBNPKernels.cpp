@@ -1,92 +1,125 @@
-// OpenMM-side glue for the gfx950 engine: a CalcAGBNPForceKernel implementation and its kernel factory,
-// written against the reference's own interfaces
-//   openmmapi/include/AGBNPKernels.h:19-47           (CalcAGBNPForceKernel)
-//   platforms/reference/src/ReferenceAGBNPKernelFactory.cpp:14-36  (plugin entry points, factory)
-// It needs the OpenMM headers and the reference's openmmapi headers, neither of which exists in the
-// build image, so it is NOT compiled by build(); a maintainer adds it to the plugin's CMake as a third
-// platform library next to platforms/reference and platforms/opencl.
+// OpenMM-side glue of the gfx950 engine: the platform plugin a maintainer adds to Gallicchio-Lab/openmm_agbnp_plugin next
+// to platforms/reference and platforms/opencl.  Written against
+//   openmmapi/include/AGBNPKernels.h:19-47                          (CalcAGBNPForceKernel: what it implements)
+//   platforms/reference/src/ReferenceAGBNPKernelFactory.cpp:14-36   (plugin entry points, factory)
+//   platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556             (GPU data conventions: device posq in, forces and
+//                                                                    energy added on the device, execute returns 0.0)
+// and OpenMM's HIP platform (HipPlatform::PlatformData::contexts, HipContext, HipArray).  It registers on the platform
+// named "HIP" only -- not on the Reference platform, whose "CalcAGBNPForce" factory belongs to AGBNPPluginReference.
 //
-// Data convention used here: the CPU-platform one (positions/forces as std::vector<Vec3>, energy
-// returned), so the kernel can be registered on the Reference or CPU platform of any OpenMM build
-// and still run its arithmetic on the MI355X.  For a GPU platform whose context owns FP64 device
-// buffers, call agbnp_hip_execute_device with those pointers instead.
-#include <string>
-#include <vector>
+// Compiled and run by tests/test_openmm_glue.py against tests/openmm_mock (OpenMM is not in the build image) and, in the
+// build container, also against the reference's own openmmapi/include headers taken in place.
+#include "HipAGBNPKernels.h"
 
-#include "AGBNPKernels.h"
-#include "agbnp_hip.h"
+#include <cstdlib>
+
 #include "openmm/OpenMMException.h"
+#include "openmm/hip/HipPlatform.h"
 #include "openmm/internal/ContextImpl.h"
-#include "openmm/reference/ReferencePlatform.h"
 
 using namespace AGBNPPlugin;
 using namespace OpenMM;
 
 namespace {
 
-class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
- public:
-  HipCalcAGBNPForceKernel(std::string name, const Platform& platform) : CalcAGBNPForceKernel(name, platform), ctx(nullptr) {}
-  ~HipCalcAGBNPForceKernel() { agbnp_hip_destroy(ctx); }
-
-  void initialize(const System& system, const AGBNPForce& force) override {
-    std::vector<double> r, g, a, q;
-    std::vector<int> h;
-    gather(force, r, g, a, q, h);
-    int device = 0;  // one context <-> one device, as the reference's OpenCL platform (OpenCLAGBNPKernels.cpp:411-413)
-    if (agbnp_hip_create(&ctx, (int)r.size(), r.data(), g.data(), a.data(), q.data(), h.data(), (int)force.getVersion(),
-                         (int)force.getNonbondedMethod(), force.getCutoffDistance(), device) != AGBNP_HIP_OK)
-      throw OpenMMException(agbnp_hip_last_error(nullptr));
+void gatherParameters(const AGBNPForce& force, std::vector<double>& r, std::vector<double>& g, std::vector<double>& a,
+                      std::vector<double>& q, std::vector<int>& h) {
+  const int n = force.getNumParticles();
+  r.resize(n), g.resize(n), a.resize(n), q.resize(n), h.resize(n);
+  for (int i = 0; i < n; i++) {
+    bool ish;
+    force.getParticleParameters(i, r[i], g[i], a[i], q[i], ish);
+    h[i] = ish ? 1 : 0;
   }
-
-  double execute(ContextImpl& context, bool includeForces, bool includeEnergy) override {
-    ReferencePlatform::PlatformData* data = reinterpret_cast<ReferencePlatform::PlatformData*>(context.getPlatformData());
-    std::vector<Vec3>& pos = *((std::vector<Vec3>*)data->positions);
-    std::vector<Vec3>& frc = *((std::vector<Vec3>*)data->forces);
-    double energy = 0.0;  // Vec3 is three contiguous doubles: the vectors are [3N] arrays
-    if (agbnp_hip_execute_host(ctx, &pos[0][0], &frc[0][0], &energy) != AGBNP_HIP_OK) throw OpenMMException(agbnp_hip_last_error(ctx));
-    return energy;
-  }
-
-  void copyParametersToContext(ContextImpl& context, const AGBNPForce& force) override {
-    std::vector<double> r, g, a, q;
-    std::vector<int> h;
-    gather(force, r, g, a, q, h);
-    if (agbnp_hip_update_parameters(ctx, (int)r.size(), r.data(), g.data(), a.data(), q.data(), h.data()) != AGBNP_HIP_OK)
-      throw OpenMMException(agbnp_hip_last_error(ctx));
-  }
-
- private:
-  static void gather(const AGBNPForce& force, std::vector<double>& r, std::vector<double>& g, std::vector<double>& a,
-                     std::vector<double>& q, std::vector<int>& h) {
-    const int n = force.getNumParticles();
-    r.resize(n), g.resize(n), a.resize(n), q.resize(n), h.resize(n);
-    for (int i = 0; i < n; i++) {
-      bool ish;
-      force.getParticleParameters(i, r[i], g[i], a[i], q[i], ish);
-      h[i] = ish ? 1 : 0;
-    }
-  }
-  agbnp_hip_context* ctx;
-};
+}
 
 class HipAGBNPKernelFactory : public KernelFactory {
  public:
   KernelImpl* createKernelImpl(std::string name, const Platform& platform, ContextImpl& context) const override {
-    if (name == CalcAGBNPForceKernel::Name()) return new HipCalcAGBNPForceKernel(name, platform);
+    HipPlatform::PlatformData& data = *static_cast<HipPlatform::PlatformData*>(context.getPlatformData());
+    if (data.contexts.size() > 1)  // as the reference's OpenCL platform (OpenCLAGBNPKernels.cpp:411-413)
+      throw OpenMMException("AGBNPForce does not support using multiple HIP devices");
+    if (name == CalcAGBNPForceKernel::Name()) return new HipCalcAGBNPForceKernel(name, platform, *data.contexts[0]);
     throw OpenMMException((std::string("Tried to create kernel with illegal kernel name '") + name + "'").c_str());
   }
 };
 
 }  // namespace
 
+HipCalcAGBNPForceKernel::HipCalcAGBNPForceKernel(std::string name, const Platform& platform, HipContext& cu)
+    : CalcAGBNPForceKernel(name, platform), cu(cu), engine(nullptr), checkInterval(1), sinceCheck(0) {
+  if (const char* env = getenv("AGBNP_HIP_CHECK_INTERVAL")) setCheckInterval(atoi(env));
+}
+
+HipCalcAGBNPForceKernel::~HipCalcAGBNPForceKernel() { agbnp_hip_destroy(engine); }
+
+void HipCalcAGBNPForceKernel::setCheckInterval(int evaluations) { checkInterval = evaluations < 1 ? 1 : evaluations; }
+
+void HipCalcAGBNPForceKernel::initialize(const System& system, const AGBNPForce& force) {
+  if (force.getNumParticles() != system.getNumParticles())
+    throw OpenMMException("AGBNPForce must have exactly as many particles as the System it belongs to.");
+  if (force.getVersion() == 2)
+    throw OpenMMException("HipCalcAGBNPForceKernel: AGBNP version 2 is not implemented on the HIP platform (versions 0 and 1 are)");
+  std::vector<double> r, g, a, q;
+  std::vector<int> h;
+  gatherParameters(force, r, g, a, q, h);
+  agbnp_hip_destroy(engine);
+  engine = nullptr;
+  if (agbnp_hip_create(&engine, (int)r.size(), r.data(), g.data(), a.data(), q.data(), h.data(), (int)force.getVersion(),
+                       (int)force.getNonbondedMethod(), force.getCutoffDistance(), cu.getDeviceIndex()) != AGBNP_HIP_OK)
+    throw OpenMMException(agbnp_hip_last_error(nullptr));
+}
+
+void HipCalcAGBNPForceKernel::enqueue() {
+  const bool dbl = cu.getUseDoublePrecision(), mixed = cu.getUseMixedPrecision();
+  if (agbnp_hip_execute_openmm(engine, cu.getPosq().getDevicePointer(), dbl ? 1 : 0,
+                               mixed ? cu.getPosqCorrection().getDevicePointer() : nullptr,
+                               static_cast<const int*>(cu.getAtomIndexArray().getDevicePointer()), cu.getPaddedNumAtoms(),
+                               static_cast<long long*>(cu.getLongForceBuffer().getDevicePointer()),
+                               cu.getEnergyBuffer().getDevicePointer(), (dbl || mixed) ? 1 : 0, /*energy slot*/ 0,
+                               cu.getCurrentStream()) != AGBNP_HIP_OK)
+    throw OpenMMException(agbnp_hip_last_error(engine));
+}
+
+double HipCalcAGBNPForceKernel::execute(ContextImpl& context, bool includeForces, bool includeEnergy) {
+  if (!engine) throw OpenMMException("HipCalcAGBNPForceKernel: initialize() has not been called");
+  // both are always computed, as in the reference (ReferenceAGBNPKernels.cpp:139-149 ignores the two flags)
+  enqueue();
+  if (++sinceCheck >= checkInterval) {
+    sinceCheck = 0;
+    for (int attempt = 0;; attempt++) {
+      int withheld = 0;
+      if (agbnp_hip_finish(engine, cu.getCurrentStream(), &withheld) != AGBNP_HIP_OK) throw OpenMMException(agbnp_hip_last_error(engine));
+      if (withheld == 0) break;
+      // a withheld evaluation added nothing to the context's buffers.  With a check after every evaluation it is this
+      // one: run it again on the capacity the engine has just switched to (forces invalidated and recomputed in the
+      // reference's words, OpenCLAGBNPKernels.cpp:3613-3634).
+      if (checkInterval != 1)
+        throw OpenMMException("AGBNPForce (HIP): an overlap tree outgrew its capacity in an earlier step of this check interval; "
+                              "its forces were not applied.  Restart from the last checkpoint (the capacity has been raised) "
+                              "or run with AGBNP_HIP_CHECK_INTERVAL=1");
+      if (attempt >= 8) throw OpenMMException("AGBNPForce (HIP): capacity negotiation did not converge");
+      enqueue();
+    }
+  }
+  return 0.0;  // the energy went into the context's energy buffer (OpenCLAGBNPKernels.cpp:555)
+}
+
+void HipCalcAGBNPForceKernel::copyParametersToContext(ContextImpl& context, const AGBNPForce& force) {
+  if (!engine) throw OpenMMException("HipCalcAGBNPForceKernel: initialize() has not been called");
+  std::vector<double> r, g, a, q;
+  std::vector<int> h;
+  gatherParameters(force, r, g, a, q, h);
+  if (agbnp_hip_update_parameters(engine, (int)r.size(), r.data(), g.data(), a.data(), q.data(), h.data()) != AGBNP_HIP_OK)
+    throw OpenMMException(agbnp_hip_last_error(engine));
+}
+
 extern "C" void registerPlatforms() {}
 
 extern "C" void registerKernelFactories() {
   for (int i = 0; i < Platform::getNumPlatforms(); i++) {
     Platform& platform = Platform::getPlatform(i);
-    if (dynamic_cast<ReferencePlatform*>(&platform) != NULL)
-      platform.registerKernelFactory(CalcAGBNPForceKernel::Name(), new HipAGBNPKernelFactory());
+    if (platform.getName() == "HIP") platform.registerKernelFactory(CalcAGBNPForceKernel::Name(), new HipAGBNPKernelFactory());
   }
 }
 
