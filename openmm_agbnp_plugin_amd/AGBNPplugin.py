@@ -20,6 +20,26 @@ class OpenMMException(Exception):
     """Same role as OpenMM::OpenMMException in the reference: every API error surfaces as this type."""
 
 
+def _md_unit_system():
+    """OpenMM's md_unit_system (nm, ps, amu, kJ/mol, e, K) if a units module is importable in this process."""
+    for name in ("openmm.unit", "simtk.unit"):
+        try:
+            module = __import__(name, fromlist=["md_unit_system"])
+            return module.md_unit_system
+        except Exception:
+            continue
+    return "md_unit_system"
+
+
+def _strip_units(value):
+    """The SWIG layer of the reference accepts OpenMM unit Quantities for every double argument and hands the C++
+    class the bare number in the MD unit system (python/AGBNPPlugin.i:3-4: OpenMM's swig/typemaps.i calls
+    value_in_unit_system(md_unit_system)).  Duck-typed here: anything with that method is converted, plain numbers pass."""
+    if hasattr(value, "value_in_unit_system"):
+        return float(value.value_in_unit_system(_md_unit_system()))
+    return float(value)
+
+
 class AGBNPForce:
     # enum NonbondedMethod (openmmapi/include/AGBNPForce.h:44-59)
     NoCutoff = 0
@@ -40,7 +60,7 @@ class AGBNPForce:
 
     def addParticle(self, radius, gamma, vdw_alpha, charge, ishydrogen):
         """radius nm, gamma kJ/mol/nm^2, vdw_alpha kJ/mol nm^3... (as the reference), charge e. Returns the index."""
-        self._particles.append([float(radius), float(gamma), float(vdw_alpha), float(charge), bool(ishydrogen)])
+        self._particles.append([_strip_units(radius), _strip_units(gamma), _strip_units(vdw_alpha), _strip_units(charge), bool(ishydrogen)])
         return len(self._particles) - 1
 
     def _check_index(self, index):
@@ -49,7 +69,7 @@ class AGBNPForce:
 
     def setParticleParameters(self, index, radius, gamma, vdw_alpha, charge, ishydrogen):
         self._check_index(index)
-        self._particles[index] = [float(radius), float(gamma), float(vdw_alpha), float(charge), bool(ishydrogen)]
+        self._particles[index] = [_strip_units(radius), _strip_units(gamma), _strip_units(vdw_alpha), _strip_units(charge), bool(ishydrogen)]
 
     def getParticleParameters(self, index):
         """Returns the tuple (radius, gamma, vdw_alpha, charge, ishydrogen), as the SWIG wrapper does."""
@@ -66,7 +86,7 @@ class AGBNPForce:
         return self._cutoff
 
     def setCutoffDistance(self, distance):
-        self._cutoff = float(distance)
+        self._cutoff = _strip_units(distance)
 
     def getSolventRadius(self):
         return self._solvent_radius

@@ -140,3 +140,33 @@ def test_cxx_host_mirror_compiles_and_links():
             # without a device the program must fail loudly with the engine's message, not fall back to anything
             out = subprocess.run([exe, "1"], input="1\n0 0 0 0 1.7 0.1 0.117 0\n", text=True, capture_output=True, timeout=60)
             assert out.returncode != 0 and "no HIP device" in out.stdout
+
+
+def test_top_level_module_keeps_the_reference_import_line():
+    """The reference's scripts say `from AGBNPplugin import AGBNPForce` (python/AGBNPPlugin.i:1: %module AGBNPplugin)."""
+    import AGBNPplugin
+    assert AGBNPplugin.AGBNPForce is P.AGBNPForce
+    for method in ("getNumParticles", "addParticle", "setParticleParameters", "updateParametersInContext", "setCutoffDistance",
+                   "setNonbondedMethod", "setVersion", "getParticleParameters"):  # the SWIG interface's method list (:46-84)
+        assert callable(getattr(AGBNPplugin.AGBNPForce, method))
+    assert (AGBNPplugin.AGBNPForce.NoCutoff, AGBNPplugin.AGBNPForce.CutoffNonPeriodic, AGBNPplugin.AGBNPForce.CutoffPeriodic) == (0, 1, 2)
+
+
+def test_unit_quantities_are_stripped_like_the_swig_layer():
+    """OpenMM's SWIG typemaps hand the C++ class the value in the MD unit system; anything with
+    value_in_unit_system() is treated that way (no units module is needed for plain numbers)."""
+    class Quantity:  # stand-in for openmm.unit.Quantity
+        def __init__(self, value, to_md):
+            self.value, self.to_md = value, to_md
+
+        def value_in_unit_system(self, system):
+            return self.value * self.to_md
+
+    f = P.AGBNPForce()
+    f.addParticle(Quantity(1.7, 0.1), Quantity(0.117, 418.4), -1.2, Quantity(0.3, 1.0), False)  # Angstrom, kcal/mol/A^2
+    r, g, a, q, h = f.getParticleParameters(0)
+    assert r == pytest.approx(0.17) and g == pytest.approx(48.9528) and (a, q, h) == (-1.2, 0.3, False)
+    f.setParticleParameters(0, Quantity(2.0, 0.1), 1.0, 2.0, 3.0, True)
+    assert f.getParticleParameters(0) == (pytest.approx(0.2), 1.0, 2.0, 3.0, True)
+    f.setCutoffDistance(Quantity(12.0, 0.1))
+    assert f.getCutoffDistance() == pytest.approx(1.2)
