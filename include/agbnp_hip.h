@@ -109,6 +109,18 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, i
  * agbnp_hip_update_parameters() does NOT change it: parameters are rewritten in place at unchanged addresses. */
 unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
 
+/* Evaluation mode (default 0 = the Reference platform's semantics: the descreening sums reach as far as the tables,
+ * 2 nm, GB meets ALL pairs, nonbonded method and cutoff are inert -- parity target of this engine).
+ * AGBNP_HIP_MODE_FAST = the semantics of the reference's GPU (OpenCL) platform: every pair stage of AGBNP1 -- Born-radius
+ * descreening sums, GB pair energy / direct forces / Y sums, chain-rule W/U sums and forces -- only meets pairs with
+ * r^2 < cutoff_distance^2 (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186; that
+ * platform applies the cutoff for every nonbonded method, OpenCLAGBNPKernels.cpp:490,1155), tiles beyond it are culled.
+ * FP64 throughout; version 0 has no pair stage and is unaffected.  For comparisons with the OpenCL plugin; results
+ * differ from the Reference platform by the truncated pairs.  Synchronises the device; bumps agbnp_hip_generation(). */
+enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1 };
+int agbnp_hip_set_mode(agbnp_hip_context* ctx, int mode);
+int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
+
 /* Diagnostics of the LAST completed evaluation (test support; mirrors the quantities the reference
  * prints at verbose_level > 0, ReferenceAGBNPKernels.cpp:333-352,459-462,519).
  * scalars: 0 E_vol1  1 E_vol2  2 E_atom (vdW + GB self)  3 E_GB pair  4 max subtree nodes

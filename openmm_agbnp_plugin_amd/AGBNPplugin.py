@@ -139,9 +139,14 @@ class HipCalcAGBNPForceKernel:
     def Name():
         return "CalcAGBNPForce"
 
-    def __init__(self, device=0):
+    MODES = dict(reference=0, fast=1)
+
+    def __init__(self, device=0, mode="reference"):
+        """mode "reference" (default): the Reference platform's semantics, the parity target.  mode "fast": the
+        OpenCL platform's semantics -- every pair stage truncated at the force's cutoff distance (include/agbnp_hip.h)."""
         self._h = None
         self._device = device
+        self._mode = self.MODES[mode]
         self.numParticles = 0
 
     def initialize(self, force):
@@ -155,6 +160,14 @@ class HipCalcAGBNPForceKernel:
         if rc != _lib.OK:
             raise OpenMMException(_lib.last_error(None))
         self._h = handle
+        if self._mode and lib.agbnp_hip_set_mode(self._h, self._mode) != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
+
+    def set_mode(self, mode):
+        self._need()
+        self._mode = self.MODES[mode]
+        if _lib.load().agbnp_hip_set_mode(self._h, self._mode) != _lib.OK:
+            raise OpenMMException(_lib.last_error(self._h))
 
     def _need(self):
         if self._h is None:

@@ -16,7 +16,7 @@ SYMBOLS = [
     "agbnp_hip_execute_openmm", "agbnp_hip_finish", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
     "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
-    "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
+    "agbnp_hip_set_mode", "agbnp_hip_get_mode", "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
 ]
 
 _lib = None
@@ -73,6 +73,8 @@ def load():
     lib.agbnp_hip_destroy.argtypes = [vp]
     lib.agbnp_hip_destroy.restype = None
     lib.agbnp_hip_device_count.argtypes = []
+    lib.agbnp_hip_set_mode.argtypes = [vp, C.c_int]
+    lib.agbnp_hip_get_mode.argtypes = [vp]
     lib.agbnp_hip_set_diagnostics.argtypes = [vp, C.c_int]
     lib.agbnp_hip_set_profiling.argtypes = [vp, C.c_int]
     lib.agbnp_hip_num_kernels.argtypes = []

@@ -96,7 +96,8 @@ struct agbnp_hip_context {
   DevBuf<int2> d_ameta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
-  DevBuf<double> d_pbox, d_epart;
+  DevBuf<double> d_pbox, d_abox, d_epart;
+  int mode = 0;  // AGBNP_HIP_MODE_* bits
   DevBuf<double4> d_hacc;  // [nh] tree-stage sums per heavy atom (tree_kernels.h)
   DevBuf<double4> d_aposq;
   DevBuf<int2> d_sizes;
@@ -253,6 +254,10 @@ void wire_args(agbnp_hip_context* c) {
   P.hz = c->hrow(kHvZ);
   P.aposq = c->d_aposq.p;
   P.pbox = c->d_pbox.p;
+  P.abox = c->d_abox.p;
+  P.fast = (c->mode & AGBNP_HIP_MODE_FAST) ? 1 : 0;
+  P.range2 = P.fast ? std::min(kI4MaxA * kI4MaxA, c->cutoff * c->cutoff) : kI4MaxA * kI4MaxA;
+  P.gb_cut2 = P.fast ? c->cutoff * c->cutoff : 1e300;
   P.pslot = c->d_pslot.p;
   P.nslots = (int)c->d_pslot.count;
   P.nhb = (c->nh + 63) / 64;
@@ -389,6 +394,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_hacc.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_hacc.p, 0, sizeof(double4) * nhp));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
+  HIP_TRY(c, c->d_abox.alloc(6 * (size_t)nblk));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
   HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
   HIP_TRY(c, c->d_born_part.alloc((size_t)n));
@@ -771,6 +777,21 @@ int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_
   memcpy(type_screener, c->lut.type_screener.data(), sizeof(int) * c->n);
   return AGBNP_HIP_OK;
 }
+
+int agbnp_hip_set_mode(agbnp_hip_context* c, int mode) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (mode & ~(AGBNP_HIP_MODE_FAST)) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: unknown mode bits");
+  if ((mode & AGBNP_HIP_MODE_FAST) && !(c->cutoff > 0.0))
+    return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: the fast mode needs a positive cutoff distance");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  if (mode != c->mode) c->generation++;  // other kernel arguments: a captured graph is stale
+  c->mode = mode;
+  wire_args(c);
+  return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_get_mode(const agbnp_hip_context* c) { return c ? c->mode : -1; }
 
 int agbnp_hip_set_diagnostics(agbnp_hip_context* c, int enabled) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;

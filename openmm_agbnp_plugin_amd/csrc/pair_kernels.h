@@ -33,6 +33,13 @@ struct PairArgs {
   const int* pslot;        // [nslots] pair order: heavy atoms, padding (-1) to a block of 64, hydrogens, padding
   int nslots, nhb;         // slots (multiple of 64), heavy blocks
   double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
+  double* abox;            // [ceil(n/64)][6] the same for the 64-atom blocks in ATOM order (GB tiles; fast mode only)
+  // Pair range.  Reference semantics: the descreening stages reach as far as the tables (2 nm), GB has no limit.
+  // Fast mode (the semantics of the reference's OpenCL platform, AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186):
+  // every pair stage only meets pairs with r^2 < cutoff^2.
+  double range2;           // squared reach of the Born / chain-rule stages: min(2 nm, cutoff)^2 in fast mode, else 4
+  double gb_cut2;          // squared GB cutoff (fast mode) -- the GB kernel is compiled twice, this is read by the cut one
+  int fast;                // 1 = fast mode
   // ---- tree accumulators / outputs
   double4* hacc;           // [nh] {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}: atomic sums of the tree kernels
   double* sv_large;        // [nh] (diagnostic)

@@ -146,6 +146,23 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
       }
     }
   }
+  if (P.fast && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; d++) {
+      lo[d] = i < P.n ? P.pos[3 * i + d] : 1e30;
+      hi[d] = i < P.n ? lo[d] : -1e30;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+      for (int d = 0; d < 3; d++) {
+        lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
+        hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
+      }
+    if ((i & 63) == 0)
+      for (int d = 0; d < 3; d++) {
+        P.abox[6 * (i >> 6) + d] = lo[d];
+        P.abox[6 * (i >> 6) + 3 + d] = hi[d];
+      }
+  }
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
@@ -477,6 +494,7 @@ __device__ __forceinline__ double tile_sums_fold(const TileSums& T, int row, int
   return (T.red[0][row][lane] + T.red[1][row][lane]) + (T.red[2][row][lane] + T.red[3][row][lane]);
 }
 
+template <bool kCut>
 __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                   const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
                                                   const double* __restrict__ alpha, double* __restrict__ born,
@@ -501,6 +519,17 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
+  if (kCut && !diag) {  // fast mode: a tile whose two blocks are further apart than the cutoff has no pair to meet
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(P.abox[6 * J + d] - P.abox[6 * I + 3 + d], P.abox[6 * I + d] - P.abox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    if (gap2 >= P.gb_cut2) {
+      if (threadIdx.x == 0) egb_part[blockIdx.x - 1] = 0.0;
+      return;
+    }
+  }
   // Born radii from the finished descreening sums (every tile recomputes them for its 128 atoms: a few dozen
   // flops per atom against 4096 pair evaluations, and one kernel launch less per evaluation):
   // wave 0 prepares block J, wave 1 block I
@@ -555,7 +584,8 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
     const double bb = bi * bj.x;
     const double et = exp2_nonpositive(d2 * (ci * bj.y));  // exp(-d^2 / (4 B_i B_j))
     const double fgb = rsqrt_pos(fma(bb, et, d2));
-    const double qq = (k == masked_step ? qlast : qi) * zq.y;
+    double qq = (k == masked_step ? qlast : qi) * zq.y;
+    if (kCut) qq = d2 < P.gb_cut2 ? qq : 0.0;  // (a pair beyond the cutoff contributes to nothing: every term carries qq)
     const double s1 = qq * fgb;
     e += s1;
     const double s3 = s1 * (fgb * fgb);
@@ -606,7 +636,7 @@ template <bool kBoth>
 __device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const double2* __restrict__ s_lut,
                                           const double2* __restrict__ jxy, const double2* __restrict__ jzs,
                                           const double* __restrict__ jty, double xi, double yi, double zi, double si, int row,
-                                          int tsr, int nsteps, int masked_step, bool vi, bool lower, int ntj) {
+                                          int tsr, int nsteps, int masked_step, bool vi, bool lower, int ntj, double range2) {
 #pragma unroll 4
   for (int k = 0; k < nsteps; k++) {
     const double2 xy = jxy[k], zs = jzs[k];
@@ -614,7 +644,7 @@ __device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const do
     const double dx = xy.x - xi, dy = xy.y - yi, dz = zs.x - zi;
     const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
     const int tj = __double2loint(ty);  // screened type | screener type << 16
-    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(ty) >= 0 && (k != masked_step || lower)) {
+    if (d2 < range2 && vi && __double2hiint(ty) >= 0 && (k != masked_step || lower)) {
       const double d = d2 * rsqrt_pos(d2);
       sum_j = fma(si, spline_value(s_lut, ((tj & 0xffff) * ntj + tsr) * kLutStride, d), sum_j);   // i descreens j
       if (kBoth) sum_i = fma(zs.y, spline_value(s_lut, (row + (tj >> 16)) * kLutStride, d), sum_i);  // j descreens i
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
                                                    const double* __restrict__ pos, const int2* __restrict__ ameta,
                                                    const double4* __restrict__ hacc, const double* __restrict__ inv_vol_h,
-                                                   const double2* __restrict__ lut, double* __restrict__ born_part) {
+                                                   const double2* __restrict__ lut, double* __restrict__ born_part, double range2) {
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
   __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
@@ -643,7 +673,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
       const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
       gap2 += g * g;
     }
-    if (gap2 >= kI4MaxA * kI4MaxA) return;
+    if (gap2 >= range2) return;
   }
   for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
   auto scale_of = [&](int slot, bool valid) { return valid && slot < nh ? hacc[slot].w * inv_vol_h[slot] : 0.0; };
@@ -672,9 +702,9 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
     born_walk<true>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, mi.x * ntj, mi.y, nsteps,
-                    diag ? 32 - start : -1, vi, lane < 32, ntj);
+                    diag ? 32 - start : -1, vi, lane < 32, ntj, range2);
   else
-    born_walk<false>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, 0, mi.y, nsteps, -1, vi, true, ntj);
+    born_walk<false>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, 0, mi.y, nsteps, -1, vi, true, ntj, range2);
   s_red[wave][0][lane] = sum_i;
   s_red[wave][1][(lane + start + nsteps) & 63] = sum_j;  // whose sum the lane holds after the rotations
   __syncthreads();
@@ -705,14 +735,14 @@ struct DbornLane {
 template <bool kBoth>
 __device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restrict__ s_lut, const double2* __restrict__ jxy,
                                            const double2* __restrict__ jzw, const double2* __restrict__ jsm, int nsteps,
-                                           int masked_step, bool vi, bool lower, int ntj) {
+                                           int masked_step, bool vi, bool lower, int ntj, double range2) {
 #pragma unroll 4
   for (int k = 0; k < nsteps; k++) {
     const double2 xy = jxy[k], zw = jzw[k], sm = jsm[k];
     const double dx = xy.x - L.x, dy = xy.y - L.y, dz = zw.x - L.z;
     const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
     const int tj = __double2loint(sm.y);  // screened type | screener type << 16
-    if (d2 < kI4MaxA * kI4MaxA && vi && __double2hiint(sm.y) >= 0 && (k != masked_step || lower)) {
+    if (d2 < range2 && vi && __double2hiint(sm.y) >= 0 && (k != masked_step || lower)) {
       const double rinv = rsqrt_pos(d2);
       const double d = d2 * rinv;
       double q2, dq2;  // i descreens j
@@ -767,7 +797,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
       const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
       gap2 += g * g;
     }
-    if (gap2 >= kI4MaxA * kI4MaxA) return;
+    if (gap2 >= P.range2) return;
   }
   for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
   // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
@@ -807,9 +837,9 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   __syncthreads();
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
-    dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj);
+    dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj, P.range2);
   else
-    dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj);
+    dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj, P.range2);
   __syncthreads();  // every wave is done with the spline tables: their LDS now carries the sums of the four waves
   TileSums& s_sums = *reinterpret_cast<TileSums*>(s_lut);
   {
@@ -896,11 +926,15 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
-                       (const double*)P.pbox, P.pos, P.ameta, (const double4*)P.hacc, P.inv_vol_h, P.lut, P.born_part);
+                       (const double*)P.pbox, P.pos, P.ameta, (const double4*)P.hacc, P.inv_vol_h, P.lut, P.born_part, P.range2);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
-  hipLaunchKernelGGL(k_gb_tiles, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+  if (P.fast)
+    hipLaunchKernelGGL(k_gb_tiles<true>, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+  else
+    hipLaunchKernelGGL(k_gb_tiles<false>, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
   // (+ 1: the energy workgroup; with no heavy atom there is no tile but the role still runs)

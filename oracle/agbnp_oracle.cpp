@@ -596,6 +596,14 @@ struct Oracle {
     return run_cavity(pos, force, sv);
   }
 
+  // FAST-MODE switch (not the Reference platform): cutoff2 > 0 restates the pair truncation of the reference's OpenCL
+  // platform on top of the same FP64 arithmetic -- every pair loop of AGBNP1 skips pairs with r^2 >= CUTOFF_SQUARED
+  // (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430 descreening sums and their derivative pass,
+  // AGBNPGBEnergy.cl:145,186 GB pairs; CUTOFF_SQUARED = cutoffDistance^2 for every nonbonded method,
+  // OpenCLAGBNPKernels.cpp:490,1155).  No reference-held vector exists for that platform: this mode is PARITY UNPINNED;
+  // it is tied to the pinned path by the limit cutoff -> infinity (tests/test_oracle_golden.py).
+  double cutoff2 = 0.0;
+
   double run_v1(const std::vector<V3>& pos, std::vector<V3>& force) {
     std::vector<double> selfv;
     double energy = run_cavity(pos, force, selfv);
@@ -615,6 +623,7 @@ struct Oracle {
         if (i == j) continue;
         if (ish[j] > 0) continue;
         V3 dist = pos[j] - pos[i];
+        if (cutoff2 > 0.0 && dot(dist, dist) >= cutoff2) continue;
         double d = sqrt(dot(dist, dist));
         if (d < kI4MaxA) invbr[i] -= pifac * scale[j] * lut.eval(d, lut.type_screened[i], lut.type_screener[j]);
       }
@@ -633,6 +642,7 @@ struct Oracle {
       for (int j = i + 1; j < n; j++) {
         V3 dist = pos[j] - pos[i];
         double d2 = dot(dist, dist);
+        if (cutoff2 > 0.0 && d2 >= cutoff2) continue;
         double qqf = charge[j] * charge[i];
         double qq = diel * qqf;
         double bb = born[i] * born[j];
@@ -672,6 +682,7 @@ struct Oracle {
         if (i == j) continue;
         if (ish[j] > 0) continue;
         V3 dist = pos[j] - pos[i];
+        if (cutoff2 > 0.0 && dot(dist, dist) >= cutoff2) continue;
         double d = sqrt(dot(dist, dist));
         double Q = 0.0, dQ = 0.0;
         if (d < kI4MaxA) {
@@ -757,6 +768,9 @@ void* agbnp_oracle_create(int n, const double* radius, const double* gamma, cons
 }
 
 void agbnp_oracle_destroy(void* h) { delete (Oracle*)h; }
+
+// fast-mode switch (see Oracle::cutoff2): cutoff <= 0 restores the Reference platform's semantics
+void agbnp_oracle_set_cutoff(void* h, double cutoff) { ((Oracle*)h)->cutoff2 = cutoff > 0.0 ? cutoff * cutoff : 0.0; }
 
 // copyParametersToContext semantics; returns 0 ok, -1 error (message in errbuf)
 int agbnp_oracle_update(void* h, int n, const double* radius, const double* gamma, const double* alpha, const double* charge,

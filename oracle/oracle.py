@@ -33,6 +33,7 @@ def _load():
         lib.agbnp_oracle_create.restype = C.c_void_p
         lib.agbnp_oracle_create.argtypes = [C.c_int, dp, dp, dp, dp, ip, C.c_int, C.c_char_p, C.c_int]
         lib.agbnp_oracle_destroy.argtypes = [C.c_void_p]
+        lib.agbnp_oracle_set_cutoff.argtypes = [C.c_void_p, C.c_double]
         lib.agbnp_oracle_update.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, ip, C.c_char_p, C.c_int]
         lib.agbnp_oracle_execute.argtypes = [C.c_void_p, dp, dp, dp]
         lib.agbnp_oracle_scalar.restype = C.c_double
@@ -66,7 +67,9 @@ class Oracle:
     SCALARS = dict(e_vol1=0, e_vol2=1, e_gb=2, e_vdw=3, volume1=4, volume2=5, slots=6, nscreened=7, nscreener=8)
     VECTORS = dict(selfvol_large=0, selfvol_vdw=1, born=2, scale=3, brw=4, bru=5, Y=6, W=7, U=8, freevol_vdw=9)
 
-    def __init__(self, radius, gamma, alpha, charge, ishydrogen, version=1):
+    def __init__(self, radius, gamma, alpha, charge, ishydrogen, version=1, cutoff=None):
+        """cutoff=None: the Reference platform's semantics (the pinned oracle).  cutoff=c: the FAST-mode restatement of
+        the reference's OpenCL platform -- every AGBNP1 pair loop truncated at r < c (parity unpinned, see the .cpp)."""
         lib = _load()
         self.n = len(radius)
         self._p = [_d(radius), _d(gamma), _d(alpha), _d(charge), np.ascontiguousarray(ishydrogen, dtype=np.int32)]
@@ -76,6 +79,8 @@ class Oracle:
         if not self._h:
             raise OracleError(err.value.decode())
         self.version = version
+        if cutoff is not None:
+            lib.agbnp_oracle_set_cutoff(self._h, float(cutoff))
 
     def update(self, radius, gamma, alpha, charge, ishydrogen):
         p = [_d(radius), _d(gamma), _d(alpha), _d(charge), np.ascontiguousarray(ishydrogen, dtype=np.int32)]

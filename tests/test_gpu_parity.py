@@ -70,6 +70,50 @@ def test_config3_thrombin(gpu_required, systems, version):
     assert int(ctx.kernel.scalar("max_subtree_nodes")) == 376 + 1
 
 
+# ---- fast mode: the OpenCL platform's semantics (cutoff on every pair stage), reported separately --------------------
+FAST_TOL = 1e-7  # FP64 on both sides, same truncation rule: the same tolerance as the reference mode
+
+
+@pytest.mark.parametrize("name,cutoff", [("trpcage", 1.2), ("1dwc", 1.0), ("fixture264", 0.8), ("1dwc", 2.5)])
+def test_fast_mode_matches_the_cutoff_oracle(gpu_required, systems, name, cutoff):
+    """AGBNP_HIP_MODE_FAST against the oracle's cutoff switch (oracle/agbnp_oracle.cpp: restatement of
+    AGBNPBornRadii.cl:268,430 / AGBNPGBEnergy.cl:145,186), on the file geometry and a jittered one.  A cutoff beyond the
+    tables' 2 nm reach (2.5 nm) only truncates GB."""
+    s = systems(name)
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    force.setCutoffDistance(cutoff)
+    k = P.HipCalcAGBNPForceKernel(mode="fast")
+    k.initialize(force)
+    oracle = Oracle(*s.params(), version=1, cutoff=cutoff)
+    reference = Oracle(*s.params(), version=1)
+    for pos in (s.pos, s.jittered(1, sigma=0.004)):
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo, tol=FAST_TOL)
+        er, fr = reference.execute(pos)
+        assert abs(e - er) > 1e-3  # and it IS a different model: the truncated pairs are missing
+    # back to the reference semantics on the same context
+    k.set_mode("reference")
+    f = np.zeros((s.n, 3))
+    e = k.execute(s.pos, f)
+    er, fr = reference.execute(s.pos)
+    assert_close(e, f, er, fr)
+
+
+def test_fast_mode_with_a_huge_cutoff_is_the_reference_mode(gpu_required, systems):
+    s = systems("trpcage")
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    force.setCutoffDistance(100.0)
+    k = P.HipCalcAGBNPForceKernel(mode="fast")
+    k.initialize(force)
+    f = np.zeros((s.n, 3))
+    e = k.execute(s.pos, f)
+    eo, fo = Oracle(*s.params(), version=1).execute(s.pos)
+    assert_close(e, f, eo, fo)
+
+
 # ---- the reference's own fixture and known answers -------------------------------------------------------
 @pytest.mark.parametrize("version", [0, 1])
 def test_reference_fixture_known_answers(gpu_required, systems, version):
