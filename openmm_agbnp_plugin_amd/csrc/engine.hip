@@ -346,10 +346,20 @@ int allocate_work(agbnp_hip_context* c) {
   {
     // work items of the symmetric GB tile kernel: one workgroup per tile, off-diagonal tiles first
     if (nblk > 4095) return c->fail(AGBNP_HIP_ERR_CAPACITY, "more than 262080 particles are not supported by the tile index encoding");
+    // away from the diagonal: strips of two i blocks (2p, 2p + 1) against one j block (flag bit 24, see gb_strip);
+    // around it: single 64 x 64 tiles
+    constexpr int kStrip = 1 << 24;
     std::vector<int> items;
-    items.reserve((size_t)nblk * nblk);
-    for (int I = 0; I < nblk; I++)
-      for (int J = I + 1; J < nblk; J++) items.push_back(I | (J << 12));
+    items.reserve((size_t)nblk * nblk / 2 + 4);
+    const bool strips = getenv("AGBNP_HIP_NO_GB_STRIPS") == nullptr;
+    if (strips) {
+      for (int p2 = 0; 2 * p2 + 1 < nblk; p2++)
+        for (int J = 2 * p2 + 2; J < nblk; J++) items.push_back((2 * p2) | (J << 12) | kStrip);
+      for (int p2 = 0; 2 * p2 + 1 < nblk; p2++) items.push_back((2 * p2) | ((2 * p2 + 1) << 12));
+    } else {
+      for (int I = 0; I < nblk; I++)
+        for (int J = I + 1; J < nblk; J++) items.push_back(I | (J << 12));
+    }
     for (int I = 0; I < nblk; I++) items.push_back(I | (I << 12));
     HIP_TRY(c, c->d_gb_items.upload(items));
     c->P.egb_parts = (int)items.size();

@@ -494,6 +494,138 @@ __device__ __forceinline__ double tile_sums_fold(const TileSums& T, int row, int
   return (T.red[0][row][lane] + T.red[1][row][lane]) + (T.red[2][row][lane] + T.red[3][row][lane]);
 }
 
+// ---- GB strips: 128 x 64 --------------------------------------------------------------------------------------------
+// Away from the diagonal a workgroup takes a STRIP: blocks I0 and I0 + 1 against block J.  A lane keeps TWO i atoms
+// (one of each block) and meets the 64 j atoms once: the j record (three LDS reads) and the wave rotation of the j sums
+// (eight DPP moves) -- a fifth of the instructions of a pair step -- are paid once for two pairs, and the i-side
+// prologue / epilogue and the J atomics once for two tiles.  (The kernel runs at its instruction-issue bound: fewer
+// instructions per pair is the only lever.)
+struct StripSums {
+  double red[4][12][64];  // per wave: rows 0-3 block I0 {fx, fy, fz, Y}, 4-7 block I0 + 1, 8-11 block J
+};
+constexpr int kGbStripFlag = 1 << 24;  // work item = I0 | J << 12 | flag
+
+template <bool kCut>
+__device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __restrict__ aposq, const double* __restrict__ born_part,
+                                         const double* __restrict__ inv_rvdw, double* __restrict__ gb_rows, double* __restrict__ egb_out,
+                                         const PairArgs& P, char* s_area, double* s_e) {
+  double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over
+  double2* const s_zq = s_xy + 128;
+  double2* const s_bb = s_zq + 128;
+  double2* const s_i = s_bb + 128;  // blocks I0, I0 + 1: [block][{x, y}, {z, q}, {B, -log2(e)/(4 B)}][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (kCut) {  // fast mode: both tiles of the strip beyond the cutoff
+    double gmin = 1e300;
+    for (int b = 0; b < 2; b++) {
+      double gap2 = 0.0;
+      for (int d = 0; d < 3; d++) {
+        const double g = fmax(0.0, fmax(P.abox[6 * J + d] - P.abox[6 * (I0 + b) + 3 + d], P.abox[6 * (I0 + b) + d] - P.abox[6 * J + 3 + d]));
+        gap2 += g * g;
+      }
+      gmin = fmin(gmin, gap2);
+    }
+    if (gmin >= P.gb_cut2) {
+      if (threadIdx.x == 0) egb_out[0] = 0.0;
+      return;
+    }
+  }
+  if (wave < 3) {  // wave 0 prepares block J, waves 1 and 2 the two i blocks
+    const int a = 64 * (wave == 0 ? J : I0 + wave - 1) + lane;
+    const bool va = a < n;
+    const int ac = va ? a : n - 1;
+    const double4 pa = aposq[ac];
+    const BornRadius bra = born_radius(inv_rvdw[ac], born_part[ac]);
+    const double qa = va ? pa.w : 0.0;  // zero charge switches a padded atom off
+    if (wave == 0) {
+      s_xy[lane] = s_xy[lane + 64] = make_double2(pa.x, pa.y);
+      s_zq[lane] = s_zq[lane + 64] = make_double2(pa.z, qa);
+      s_bb[lane] = s_bb[lane + 64] = make_double2(bra.br, bra.inv_br);
+    } else {
+      double2* r = s_i + (wave - 1) * 192;
+      r[lane] = make_double2(pa.x, pa.y);
+      r[64 + lane] = make_double2(pa.z, qa);
+      r[128 + lane] = make_double2(bra.br, (-0.25 * 1.4426950408889634074) * bra.inv_br);
+    }
+  }
+  __syncthreads();
+  const int start = 16 * wave;  // the four waves take a quarter of the cyclic distances each
+  const double2 axy = s_i[lane], azq = s_i[64 + lane], abc = s_i[128 + lane];
+  const double2 cxy = s_i[192 + lane], czq = s_i[256 + lane], cbc = s_i[320 + lane];
+  const int base = (lane + start) & 63;
+  const double2* __restrict__ jxy = s_xy + base;
+  const double2* __restrict__ jzq = s_zq + base;
+  const double2* __restrict__ jbb = s_bb + base;
+  double fxa = 0, fya = 0, fza = 0, ya = 0, fxc = 0, fyc = 0, fzc = 0, yc = 0, fxj = 0, fyj = 0, fzj = 0, yj = 0, e = 0;
+#pragma unroll 4
+  for (int k = 0; k < 16; k++) {
+    const double2 xy = jxy[k], zq = jzq[k], bj = jbb[k];
+    // pair (atom of block I0, j)
+    const double dxa = xy.x - axy.x, dya = xy.y - axy.y, dza = zq.x - azq.x;
+    const double d2a = fma(dza, dza, fma(dya, dya, dxa * dxa));
+    const double bba = abc.x * bj.x;
+    const double eta = exp2_nonpositive(d2a * (abc.y * bj.y));
+    const double fa = rsqrt_pos(fma(bba, eta, d2a));
+    double qqa = azq.y * zq.y;
+    if (kCut) qqa = d2a < P.gb_cut2 ? qqa : 0.0;
+    const double s1a = qqa * fa;
+    const double s3a = s1a * (fa * fa);
+    const double mwa = fma(-0.25, eta, 1.0) * s3a;
+    const double yta = fma(0.25, d2a, bba) * (eta * s3a);
+    // pair (atom of block I0 + 1, j)
+    const double dxc = xy.x - cxy.x, dyc = xy.y - cxy.y, dzc = zq.x - czq.x;
+    const double d2c = fma(dzc, dzc, fma(dyc, dyc, dxc * dxc));
+    const double bbc = cbc.x * bj.x;
+    const double etc = exp2_nonpositive(d2c * (cbc.y * bj.y));
+    const double fc = rsqrt_pos(fma(bbc, etc, d2c));
+    double qqc = czq.y * zq.y;
+    if (kCut) qqc = d2c < P.gb_cut2 ? qqc : 0.0;
+    const double s1c = qqc * fc;
+    const double s3c = s1c * (fc * fc);
+    const double mwc = fma(-0.25, etc, 1.0) * s3c;
+    const double ytc = fma(0.25, d2c, bbc) * (etc * s3c);
+    e += s1a + s1c;
+    fxa = fma(dxa, mwa, fxa);
+    fya = fma(dya, mwa, fya);
+    fza = fma(dza, mwa, fza);
+    ya += yta;
+    fxc = fma(dxc, mwc, fxc);
+    fyc = fma(dyc, mwc, fyc);
+    fzc = fma(dzc, mwc, fzc);
+    yc += ytc;
+    fxj = rot1(fma(-dxa, mwa, fma(-dxc, mwc, fxj)));
+    fyj = rot1(fma(-dya, mwa, fma(-dyc, mwc, fyj)));
+    fzj = rot1(fma(-dza, mwa, fma(-dzc, mwc, fzj)));
+    yj = rot1(yj + (yta + ytc));
+  }
+  const double kf = -2.0 * kDielFactor;
+  __syncthreads();  // every wave is done with the records
+  StripSums& S = *reinterpret_cast<StripSums*>(s_area);
+  const int jslot = (lane + start + 16) & 63;  // whose sums the lane holds after the rotations
+  S.red[wave][0][lane] = kf * fxa;
+  S.red[wave][1][lane] = kf * fya;
+  S.red[wave][2][lane] = kf * fza;
+  S.red[wave][3][lane] = ya;
+  S.red[wave][4][lane] = kf * fxc;
+  S.red[wave][5][lane] = kf * fyc;
+  S.red[wave][6][lane] = kf * fzc;
+  S.red[wave][7][lane] = yc;
+  S.red[wave][8][jslot] = kf * fxj;
+  S.red[wave][9][jslot] = kf * fyj;
+  S.red[wave][10][jslot] = kf * fzj;
+  S.red[wave][11][jslot] = yj;
+  e = wave_sum(e);
+  if (lane == 0) s_e[wave] = e;
+  __syncthreads();
+  // thread (wave q, lane l) adds quantity q of atom l of the three blocks: rows gb_fx, gb_fy, gb_fz, gb_y
+  double* __restrict__ row = gb_rows + (size_t)wave * n;
+  auto fold = [&](int r) { return (S.red[0][r][lane] + S.red[1][r][lane]) + (S.red[2][r][lane] + S.red[3][r][lane]); };
+  const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
+  if (ia < n) hbm_add(&row[ia], fold(wave));
+  if (ic < n) hbm_add(&row[ic], fold(4 + wave));
+  if (j < n) hbm_add(&row[j], fold(8 + wave));
+  if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
+}
+
 template <bool kCut>
 __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                   const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
@@ -502,10 +634,12 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
                                                   double* __restrict__ e_atom, double* __restrict__ gb_rows,
                                                   double* __restrict__ egb_part, PairArgs P) {
   // one LDS area, two lives: the atom records during the walk, the sums of the four waves after it
-  __shared__ __align__(16) char s_area[sizeof(TileSums)];
-  static_assert(sizeof(TileSums) >= kRoleScratchBytes, "the bookkeeping workgroup borrows the tile area");
+  __shared__ __align__(16) char s_area[sizeof(StripSums)];
+  static_assert(sizeof(StripSums) >= sizeof(TileSums) && sizeof(TileSums) >= kRoleScratchBytes, "the bookkeeping workgroup borrows the tile area");
+  static_assert(sizeof(StripSums) >= sizeof(double2) * (3 * 128 + 6 * 64), "strip records fit the area of the sums");
   // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): ~20 us of mostly
   // serial work that hides underneath this launch, the longest of the pair stages
+  __shared__ double s_e[4];
   if (blockIdx.x == 0) return bookkeeping_role(P, s_area);
   static_assert(sizeof(TileSums) >= sizeof(double2) * (3 * 128 + 3 * 64), "records fit the area of the sums");
   double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over: entry m and m + 64 are atom 64 J + m
@@ -514,10 +648,10 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   double2* const s_ixy = s_bb + 128;                          // block I: {x, y}, {z, q}, {B, -log2(e)/(4 B)}
   double2* const s_izq = s_ixy + 64;
   double2* const s_ibc = s_izq + 64;
-  __shared__ double s_e[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
+  if (item & kGbStripFlag) return gb_strip<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
   const bool diag = I == J;
   if (kCut && !diag) {  // fast mode: a tile whose two blocks are further apart than the cutoff has no pair to meet
     double gap2 = 0.0;
