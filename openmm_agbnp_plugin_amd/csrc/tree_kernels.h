@@ -675,88 +675,62 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       tree_barrier<NCAP>();
       AGBNP_BUILD_STAMP(11);
 
-      // phase 2: children per node, their base slots (wave 0, or all waves for a wide batch)
-      auto kept_children = [&](int j) {
-        // a node has up to ACAP - 2 younger siblings: 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
-        const int ts = S.tstart[j], te = S.tstart[j + 1];
-        int c = __popcll(kept_bits(S.kmask, ts, ACAP <= 64 || te - ts <= 63 ? te : ts + 63));
-        if (ACAP > 64)
-          for (int s0 = ts + 63; s0 < te; s0 += 63) c += __popcll(kept_bits(S.kmask, s0, s0 + 63 < te ? s0 + 63 : te));
+      // phases 2 + 3 in one: no scan over the nodes.  The survivor masks of phase 1 say everything: the children of
+      // node j start at  tail + (number of survivors among the tasks before the node's first task)  -- a prefix
+      // popcount over at most kMaskWords words, the same for every lane of a node -- and a kept task's rank inside its
+      // node comes from the node's own piece of the mask.  One barrier-delimited phase less per batch.
+      const int nwords = (T + 63) >> 6;  // words written by phase 1 of THIS batch (later ones are stale)
+      int created = 0;
+      for (int w = 0; w < nwords; w++) created += __popcll(S.kmask[w]);  // (same address on every lane: LDS broadcasts)
+      if (tail + created > NCAP) return kBuildNodeOverflow;
+      auto kept_before = [&](int ts) {  // survivors among the tasks [0, ts)
+        const int wi = ts >> 6;
+        int c = __popcll(S.kmask[wi] & ((1ull << (ts & 63)) - 1ull));
+        for (int w = 0; w < wi; w++) c += __popcll(S.kmask[w]);
         return c;
       };
-      if (!wide) {
-        if (tid < 64) {
-          const int c = tid < nin ? kept_children(tid) : 0;
-          const int cincl = wave_inclusive_scan(c);
-          const int cb = tail + cincl - c;
-          if (tid < nin) {
-            S.cbase[tid] = (unsigned short)cb;
-            if (c > 0) {
-              S.ncs[nb + tid] = (unsigned short)cb;  // from here on: first child
-              S.ncc[nb + tid] = (unsigned short)c;
-            }
-          }
-          if (tid == 63) S.ctl[3] = cincl;
-        }
-      } else {
-        const int wv = tid >> 6, ln = tid & 63;
-        const int c = tid < nin ? kept_children(tid) : 0;
-        const int local = wave_inclusive_scan(c);
-        if (ln == 63) S.ctl[4 + wv] = local;
-        tree_barrier<NCAP>();
-        int woff = 0, all = 0;
-        for (int w = 0; w < BS / 64; w++) {
-          const int v = S.ctl[4 + w];
-          woff += w < wv ? v : 0;
-          all += v;
-        }
-        const int cb = tail + woff + local - c;
-        if (tid < nin) {
-          S.cbase[tid] = (unsigned short)cb;
-          if (c > 0) {
-            S.ncs[nb + tid] = (unsigned short)cb;  // from here on: first child
-            S.ncc[nb + tid] = (unsigned short)c;
-          }
-        }
-        if (tid == 0) S.ctl[3] = all;
-      }
-      tree_barrier<NCAP>();
-      const int created = S.ctl[3];
-      if (tail + created > NCAP) return kBuildNodeOverflow;
       AGBNP_BUILD_STAMP(12);
-
-      // phase 3: every kept task finds its rank inside its node's kept set and writes the child there
       for (int t = tid; t < T; t += BS) {
         const double v = tvol[t];
-        if (v > 0.0) {
-          const int j = tmap[t];
-          const int kk = nb + j;
-          const int ts = S.tstart[j], te = S.tstart[j + 1];
-          int rank = 0;
+        const int j = tmap[t];
+        const int kk = nb + j;
+        const int ts = S.tstart[j], te = S.tstart[j + 1];
+        if (v > 0.0 || t == ts) {
+          // the node's survivors: count (all pieces), and this task's rank among them (descending volume, index on ties)
+          int rank = 0, c = 0;
           for (int s0 = ts; s0 < te; s0 += 63) {  // 63-bit pieces of the survivor mask (one piece when ACAP <= 64)
             const int s1 = (ACAP <= 64 || s0 + 63 >= te) ? te : s0 + 63;
-            for (unsigned long long m = kept_bits(S.kmask, s0, s1); m; m &= m - 1) {  // kept siblings only
-              const int u = s0 + __builtin_ctzll(m);
-              const double vu = tvol[u];
-              rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
-            }
+            unsigned long long m = kept_bits(S.kmask, s0, s1);
+            c += __popcll(m);
+            if (v > 0.0)
+              for (; m; m &= m - 1) {  // kept siblings only
+                const int u = s0 + __builtin_ctzll(m);
+                const double vu = tvol[u];
+                rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
+              }
             if (ACAP <= 64) break;
           }
-          const int cb = S.cbase[j];
-          const int slot = cb + rank;
-          const int la = S.nla[kk + 1 + (t - ts)];
-          double mx, my, mz, ma;
-          dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
-                          mx, my, mz, ma);
-          S.nd[0][slot] = mx;
-          S.nd[1][slot] = my;
-          S.nd[2][slot] = mz;
-          S.nd[3][slot] = ma;
-          S.nd[4][slot] = v;
-          S.nla[slot] = (unsigned short)la;
-          S.npar[slot] = (unsigned short)kk;
-          S.ncs[slot] = (unsigned short)(cb + (int)S.ncc[kk]);  // end of this child's sibling list
-          S.ncc[slot] = 0;
+          const int cb = tail + kept_before(ts);
+          if (t == ts && c > 0) {  // the node's first task also records the node's children
+            S.ncs[kk] = (unsigned short)cb;  // from here on: first child
+            S.ncc[kk] = (unsigned short)c;
+          }
+          if (v > 0.0) {
+            const int slot = cb + rank;
+            const int la = S.nla[kk + 1 + (t - ts)];
+            double mx, my, mz, ma;
+            dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
+                            mx, my, mz, ma);
+            S.nd[0][slot] = mx;
+            S.nd[1][slot] = my;
+            S.nd[2][slot] = mz;
+            S.nd[3][slot] = ma;
+            S.nd[4][slot] = v;
+            S.nla[slot] = (unsigned short)la;
+            S.npar[slot] = (unsigned short)kk;
+            S.ncs[slot] = (unsigned short)(cb + c);  // end of this child's sibling list
+            S.ncc[slot] = 0;
+          }
         }
       }
       tree_barrier<NCAP>();
