@@ -307,6 +307,10 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void glb_add(double* p, double v) {
+#ifdef AGBNP_TIMING_NO_ATOMICS  // timing experiment only: results are wrong
+  if (v == 1.2345e300) *p = v;
+  return;
+#endif
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
