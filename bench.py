@@ -221,8 +221,9 @@ def main():
     ap.add_argument("--system", default="1dwc")
     ap.add_argument("--cpu-evals", type=int, default=20, help="size of the CPU-baseline sample (0 disables the leg)")
     ap.add_argument("--secondary", type=int, default=1, help="also time BASELINE.json's other configurations (one GPU only)")
-    ap.add_argument("--mode", default="reference", choices=["reference", "fast"],
-                    help="fast = the OpenCL platform's semantics (cutoff on every pair stage); printed as its own line")
+    ap.add_argument("--mode", default="reference", choices=["reference", "fast", "deterministic"],
+                    help="fast = the OpenCL platform's semantics (cutoff on every pair stage); deterministic = bit-reproducible "
+                         "sums (Reference semantics); each printed as its own line")
     args = ap.parse_args()
 
     import torch
@@ -273,8 +274,9 @@ def main():
     if rank == 0:
         slots = int(kernel.scalar("total_nodes")) + (n - system.nheavy) + 1  # + hydrogen slots + root, as the reference counts
         b_eval, b_kernel = algorithmic_bytes(n, slots)
-        semantics = ("Reference semantics: all pairs" if mode is None else
-                     "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff")
+        semantics = {None: "Reference semantics: all pairs",
+                     "fast": "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff",
+                     "deterministic": "Reference semantics: all pairs; DETERMINISTIC mode: quantized order-dependent sums"}[mode]
         result = {
             "metric": "AGBNP1 force-eval-limited ns/day (1 fs step), thrombin 1dwc, independent replicas",
             "value": value, "unit": "ns/day", "n_gpus": world, "steps": K, "warmup": W,
@@ -345,7 +347,7 @@ def main():
     # ---- CPU baseline (rank 0, single replica only)
     if rank == 0 and world == 1 and args.cpu_evals > 0:
         evals = min(args.cpu_evals, K)
-        oracle_kw = {} if mode is None else {"cutoff": 1.0}
+        oracle_kw = {"cutoff": 1.0} if mode == "fast" else {}
         cpu_ms, de, df = cpu_baseline_leg(system, rep.geoms[W:], rep.host_results(W, evals), evals, **oracle_kw)
         result["cpu_baseline"] = {"value": 86.4 / cpu_ms, "unit": "ns/day", "ms_per_eval": cpu_ms, "cores": 1, "kind": "port",
                                   "sample": f"first {evals} of the {K} timed geometries, single-threaded FP64 oracle (oracle/agbnp_oracle.cpp, g++ -O2)"}

@@ -116,8 +116,15 @@ unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
  * r^2 < cutoff_distance^2 (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186; that
  * platform applies the cutoff for every nonbonded method, OpenCLAGBNPKernels.cpp:490,1155), tiles beyond it are culled.
  * FP64 throughout; version 0 has no pair stage and is unaffected.  For comparisons with the OpenCL plugin; results
- * differ from the Reference platform by the truncated pairs.  Synchronises the device; bumps agbnp_hip_generation(). */
-enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1 };
+ * differ from the Reference platform by the truncated pairs.  Synchronises the device; bumps agbnp_hip_generation().
+ *
+ * AGBNP_HIP_MODE_DETERMINISTIC (may be combined with either): bit-identical results from run to run.  By default sums
+ * that many workgroups contribute to are FP64 atomics whose order is not fixed, so results differ by ~1e-16 relative
+ * between runs.  In this mode every term that enters an order-dependent sum is first rounded to a fixed quantum
+ * (2^-34 kJ/mol/nm for forces, 2^-52 nm^3 for self volumes, 2^-44 / 2^-40 for the pair-stage sums, 2^-36 kJ/mol for
+ * energies): sums of such terms are exact in FP64, hence independent of their order.  Results stay within 1e-8 of the
+ * default mode's (far inside the 1e-4 parity bar). */
+enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1, AGBNP_HIP_MODE_DETERMINISTIC = 2 };
 int agbnp_hip_set_mode(agbnp_hip_context* ctx, int mode);
 int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
 

@@ -38,6 +38,21 @@ __device__ __forceinline__ double rsqrt_pos(double u) {
 // exp(x) for x <= 0 through the same core
 __device__ __forceinline__ double exp_nonpositive(double x) { return exp2_nonpositive(x * 1.4426950408889634074); }
 
+// ---- deterministic mode ---------------------------------------------------------------------------------------
+// Run-to-run differences come from floating-point sums whose ORDER is not fixed: FP64 atomics (LDS and HBM), terms
+// that reach a lane in an order decided by atomic cursors, and the composition of a forest (decided by the order in
+// which the bookkeeping's atomics are served).  In deterministic mode every term that enters such a sum is first
+// rounded to a multiple of 2^-k.  Sums of multiples of 2^-k are exact in FP64 as long as they stay below 2^(53-k),
+// and exact sums do not depend on their order -- the same ds_add_f64 / global_atomic_add_f64 then give bit-identical
+// results, and nothing downstream changes.  (Beyond the range a sum merely rounds again, as in the default mode.)
+// Quantum per kind of sum:                                  exact while |sum| <
+constexpr double kQGrad = 17179869184.0;        // 2^34  forces, gradients (kJ/mol/nm): 5.8e-11   5.2e5
+constexpr double kQVol = 4503599627370496.0;    // 2^52  self volumes (nm^3): 2.2e-16             2
+constexpr double kQBorn = 17592186044416.0;     // 2^44  descreening sums (1/nm): 5.7e-14         512
+constexpr double kQSum = 1099511627776.0;       // 2^40  GB Y sums, W+U sums: 9.1e-13             8192
+constexpr double kQEnergy = 68719476736.0;      // 2^36  energies (kJ/mol): 1.5e-11               1.3e5
+__device__ __forceinline__ double quantize(double v, double scale, bool det) { return det ? rint(v * scale) * (1.0 / scale) : v; }
+
 // q^(3/2) for normal positive q: q^2 / sqrt(q)
 __device__ __forceinline__ double pow_three_halves(double q) { return (q * q) * rsqrt_pos(q); }
 

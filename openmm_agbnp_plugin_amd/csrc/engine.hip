@@ -256,6 +256,7 @@ void wire_args(agbnp_hip_context* c) {
   P.pbox = c->d_pbox.p;
   P.abox = c->d_abox.p;
   P.fast = (c->mode & AGBNP_HIP_MODE_FAST) ? 1 : 0;
+  P.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
   P.range2 = P.fast ? std::min(kI4MaxA * kI4MaxA, c->cutoff * c->cutoff) : kI4MaxA * kI4MaxA;
   P.gb_cut2 = P.fast ? c->cutoff * c->cutoff : 1e300;
   P.pslot = c->d_pslot.p;
@@ -292,6 +293,7 @@ void wire_args(agbnp_hip_context* c) {
   T.hacc = reinterpret_cast<double*>(c->d_hacc.p);
   T.db_wu = c->d_dbf.p + 3 * (size_t)c->n;
   T.want_sv_large = c->diagnostics ? 1 : 0;  // pass-1 self volumes cost extra HBM atomics: opt-in
+  T.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
   T.epart = c->d_epart.p;
   T.hdr = c->d_hdr.p;
   T.node_pool = c->d_node_pool.p;
@@ -790,7 +792,8 @@ int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_
 
 int agbnp_hip_set_mode(agbnp_hip_context* c, int mode) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
-  if (mode & ~(AGBNP_HIP_MODE_FAST)) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: unknown mode bits");
+  if (mode & ~(AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_DETERMINISTIC))
+    return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: unknown mode bits");
   if ((mode & AGBNP_HIP_MODE_FAST) && !(c->cutoff > 0.0))
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: the fast mode needs a positive cutoff distance");
   HIP_TRY(c, hipSetDevice(c->device));

@@ -40,6 +40,7 @@ struct PairArgs {
   double range2;           // squared reach of the Born / chain-rule stages: min(2 nm, cutoff)^2 in fast mode, else 4
   double gb_cut2;          // squared GB cutoff (fast mode) -- the GB kernel is compiled twice, this is read by the cut one
   int fast;                // 1 = fast mode
+  int det;                 // 1 = deterministic mode (device_math.h)
   // ---- tree accumulators / outputs
   double4* hacc;           // [nh] {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}: atomic sums of the tree kernels
   double* sv_large;        // [nh] (diagnostic)

@@ -620,9 +620,11 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   double* __restrict__ row = gb_rows + (size_t)wave * n;
   auto fold = [&](int r) { return (S.red[0][r][lane] + S.red[1][r][lane]) + (S.red[2][r][lane] + S.red[3][r][lane]); };
   const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
-  if (ia < n) hbm_add(&row[ia], fold(wave));
-  if (ic < n) hbm_add(&row[ic], fold(4 + wave));
-  if (j < n) hbm_add(&row[j], fold(8 + wave));
+  const bool det = P.det != 0;  // deterministic mode: a tile's totals are rounded to the sums' quantum (device_math.h)
+  const double qs = wave == 3 ? kQSum : kQGrad;
+  if (ia < n) hbm_add(&row[ia], quantize(fold(wave), qs, det));
+  if (ic < n) hbm_add(&row[ic], quantize(fold(4 + wave), qs, det));
+  if (j < n) hbm_add(&row[j], quantize(fold(8 + wave), qs, det));
   if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
@@ -751,8 +753,10 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   // thread (wave q, lane l) adds quantity q of atom l of block I and of block J: rows gb_fx, gb_fy, gb_fz, gb_y
   double* __restrict__ row = gb_rows + (size_t)wave * n;
   const int i = 64 * I + lane, j = 64 * J + lane;
-  if (i < n) hbm_add(&row[i], tile_sums_fold(s_sums, wave, lane));
-  if (j < n) hbm_add(&row[j], tile_sums_fold(s_sums, 4 + wave, lane));
+  const bool det = P.det != 0;
+  const double qs = wave == 3 ? kQSum : kQGrad;
+  if (i < n) hbm_add(&row[i], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
+  if (j < n) hbm_add(&row[j], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
   if (threadIdx.x == 0) egb_part[blockIdx.x - 1] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
                                                    const double* __restrict__ pos, const int2* __restrict__ ameta,
                                                    const double4* __restrict__ hacc, const double* __restrict__ inv_vol_h,
-                                                   const double2* __restrict__ lut, double* __restrict__ born_part, double range2) {
+                                                   const double2* __restrict__ lut, double* __restrict__ born_part, double range2, int det) {
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
   __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
@@ -845,7 +849,8 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   if (wave < 2) {  // wave 0 adds the sums of block I, wave 1 those of block J
     if (wave == 0 && !both) return;
     const int a = wave == 0 ? ai : pslot[64 * J + lane];
-    if (a >= 0) hbm_add(&born_part[a], (s_red[0][wave][lane] + s_red[1][wave][lane]) + (s_red[2][wave][lane] + s_red[3][wave][lane]));
+    if (a >= 0)
+      hbm_add(&born_part[a], quantize((s_red[0][wave][lane] + s_red[1][wave][lane]) + (s_red[2][wave][lane] + s_red[3][wave][lane]), kQBorn, det != 0));
   }
 }
 
@@ -984,9 +989,11 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   // thread (wave q, lane l) adds quantity q of slot l of block I and of block J: rows db_fx, db_fy, db_fz by atom,
   // row db_wu by heavy index (= the slot of a heavy block: only heavy atoms collect W+U, and the tree reads it so)
   double* __restrict__ row = db_rows + (size_t)wave * n;
-  if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], tile_sums_fold(s_sums, wave, lane));
+  const bool det = P.det != 0;
+  const double qs = wave == 3 ? kQSum : kQGrad;
+  if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
   const int aj = pslot[64 * J + lane];
-  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], tile_sums_fold(s_sums, 4 + wave, lane));
+  if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1060,7 +1067,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
-                       (const double*)P.pbox, P.pos, P.ameta, (const double4*)P.hacc, P.inv_vol_h, P.lut, P.born_part, P.range2);
+                       (const double*)P.pbox, P.pos, P.ameta, (const double4*)P.hacc, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
   if (P.fast)

@@ -60,6 +60,7 @@ struct TreeArgs {
   // are scattered over the table, so an atom's four sums must share a request rather than sit in four rows
   double* hacc;                // [nh][4]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
+  int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
   const int* order;            // [<= 4 nh] work items, by forest
   const int* packing;          // [slot_cap + 1] forest_start: work slot s builds order[packing[s] .. packing[s+1]);
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
@@ -783,7 +784,7 @@ __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
 // others.  Returns false (workgroup-uniform) if the list does not fit: the caller reports a capacity overflow.
 template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
 __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int nnodes, int natoms, bool with_selfvol,
-                            double* e_sum, int* npairs, const uint4* pair_word = nullptr) {
+                            double* e_sum, int* npairs, bool det, const uint4* pair_word = nullptr) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
   constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
@@ -870,10 +871,10 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
     const double cp = ((level & 1) ? 1.0 : -1.0) / (double)level;
     double sp;
     const double sw = dev_switch(g, sp);
-    w = cp * sw * g;
+    w = quantize(cp * sw * g, kQVol, det);  // (the self-volume sums are order-dependent: LDS atomics, list order)
     S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
     S.wrow[n] = w;
-    e_part += gam * w;
+    e_part += quantize(gam * (cp * sw * g), kQEnergy, det);  // (which nodes a lane sums depends on the forest's composition)
     } while (false);
     // The root is in every node of its tree: its self volume is the tree's sum of w (and its node count the count).
     // The lanes of a wave mostly share one root (levels are contiguous runs per tree): fold per root inside the wave
@@ -957,9 +958,15 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         gx = gy = gz = sv = 0.0;
       }
       const double am = cf * ea;
-      gx = fma(am, xa - cx, gx);
-      gy = fma(am, ya - cy, gy);
-      gz = fma(am, za - cz, gz);
+      if (det) {  // the list's order inside a run comes from atomic cursors: exact sums of quantized terms
+        gx += quantize(am * (xa - cx), kQGrad, true);
+        gy += quantize(am * (ya - cy), kQGrad, true);
+        gz += quantize(am * (za - cz), kQGrad, true);
+      } else {
+        gx = fma(am, xa - cx, gx);
+        gy = fma(am, ya - cy, gy);
+        gz = fma(am, za - cz, gz);
+      }
       sv += wn;
     }
     if (cur >= 0) flush();
@@ -987,9 +994,9 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.wrow[n];
         const bool member = live && (((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0ull);
         const double am = member ? cf * ea : 0.0;
-        gx += am * (xa - cx);
-        gy += am * (ya - cy);
-        gz += am * (za - cz);
+        gx += quantize(am * (xa - cx), kQGrad, det);  // (node numbering = summation order depends on the forest's composition)
+        gy += quantize(am * (ya - cy), kQGrad, det);
+        gz += quantize(am * (za - cz), kQGrad, det);
         sv += member ? wn : 0.0;
       }
       // fold the slices that live in this wave (lanes A, 2A, ... apart)

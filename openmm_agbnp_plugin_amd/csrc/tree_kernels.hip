@@ -138,7 +138,8 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
     // The node slots still hold the Gaussians of the build, so only the atom paths and the membership list are
     // laid down before the gather.  Its gradient stays in the local accumulators and leaves with that of pass 2.
-    if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs))
+    const bool det = A.det != 0;
+    if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs, det))
       rc = kBuildNodeOverflow;  // the membership list does not fit: same protocol as a node overflow
     if (rc != kBuildOk) {
       if (tid == 0) {
@@ -159,12 +160,13 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     if (tid == 0) {
       // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141); once per subtree (its part 0)
       double e1 = e_sum;
-      for (int q = 0; q < m; q++) e1 += (S.rt[kRtPart + q] & 0xff) == 0 ? S.at[5][q] * S.at[4][q] : 0.0;
+      for (int q = 0; q < m; q++) e1 += (S.rt[kRtPart + q] & 0xff) == 0 ? quantize(S.at[5][q] * S.at[4][q], kQEnergy, det) : 0.0;
       A.epart[2 * slot] = e1;
     }
     if (want_sv1) {  // diagnostics: enlarged-radius self volumes
       for (int la = tid; la < natoms; la += BS) {
-        glb_add(&A.hvat(kHvSvLarge, S.at_gidx[la]), (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + S.at[4][la] : S.at[9][la]);
+        glb_add(&A.hvat(kHvSvLarge, S.at_gidx[la]),
+                (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + quantize(S.at[4][la], kQVol, det) : S.at[9][la]);
         S.at[9][la] = 0.0;
       }
     }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     CSTAMP(3);
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
-    volume_pass<NCAP, ACAP, BS, true>(S, tid, m, nnodes, natoms, true, &e_sum, &npairs);
+    volume_pass<NCAP, ACAP, BS, true>(S, tid, m, nnodes, natoms, true, &e_sum, &npairs, det);
     CSTAMP(4);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     CSTAMP(5);
@@ -227,12 +229,12 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     for (int k = tid; k < 4 * natoms; k += BS) {
       const int la = k >> 2, comp = k & 3;
       double v = S.at[6][comp * ACAP + la];  // rows 6..9 are contiguous (no dynamic index into the row table)
-      if (comp == 3 && la < m && (S.rt[kRtPart + la] & 0xff) == 0) v += S.at[4][la];
+      if (comp == 3 && la < m && (S.rt[kRtPart + la] & 0xff) == 0) v += quantize(S.at[4][la], kQVol, det);
       glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], v);
     }
     if (tid == 0) {
       double e2 = e_sum;
-      for (int q = 0; q < m; q++) e2 += (S.rt[kRtPart + q] & 0xff) == 0 ? S.at[5][q] * S.at[4][q] : 0.0;
+      for (int q = 0; q < m; q++) e2 += (S.rt[kRtPart + q] & 0xff) == 0 ? quantize(S.at[5][q] * S.at[4][q], kQEnergy, det) : 0.0;
       A.epart[2 * slot + 1] = e2;
     }
     tree_barrier<NCAP>();
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     // every global load of this forest has been consumed: ask for the next one (see k_tree_cavity)
     if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
     double e_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, kPairs ? &pair_word : nullptr);
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, A.det != 0, kPairs ? &pair_word : nullptr);
     PSTAMP(1);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     for (int k = tid; k < 4 * natoms; k += BS) {  // (lane 3 of every four idles: the record's fourth word is the self volume)

@@ -114,6 +114,37 @@ def test_fast_mode_with_a_huge_cutoff_is_the_reference_mode(gpu_required, system
     assert_close(e, f, eo, fo)
 
 
+# ---- deterministic mode ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["1dwc", "trpcage"])
+def test_deterministic_mode_is_bit_reproducible(gpu_required, systems, name):
+    """AGBNP_HIP_MODE_DETERMINISTIC: the same geometries evaluated by two independent contexts, in different sequences
+    (so that the forests are packed differently and the atomics land in different orders), give BIT-identical energies
+    and forces; the default mode is allowed to differ in the last bits and usually does.  Both stay at the oracle."""
+    s = systems(name)
+    geoms = [s.pos, s.jittered(1, sigma=0.004), s.jittered(2, sigma=0.004)]
+
+    def run(mode, order):
+        k = P.HipCalcAGBNPForceKernel(mode=mode)
+        k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+        out = {}
+        for g in order:
+            f = np.zeros((s.n, 3))
+            out[g] = (k.execute(geoms[g], f), f)
+        return out
+
+    a = run("deterministic", [0, 1, 2, 0])
+    b = run("deterministic", [2, 2, 1, 0])
+    for g in range(3):
+        assert a[g][0] == b[g][0], f"energy of geometry {g} differs between two runs: {a[g][0]!r} vs {b[g][0]!r}"
+        assert np.array_equal(a[g][1], b[g][1]), f"forces of geometry {g} differ by {np.abs(a[g][1] - b[g][1]).max():.3e}"
+    oracle = Oracle(*s.params(), version=1)
+    for g in range(3):
+        eo, fo = oracle.execute(geoms[g])
+        assert_close(a[g][0], a[g][1], eo, fo)
+    c = run("reference", [0, 1, 2, 0])
+    assert abs(c[0][0] - a[0][0]) < 1e-6 and np.abs(c[0][1] - a[0][1]).max() < 1e-7  # the quanta are far below the parity bar
+
+
 # ---- the reference's own fixture and known answers -------------------------------------------------------
 @pytest.mark.parametrize("version", [0, 1])
 def test_reference_fixture_known_answers(gpu_required, systems, version):
