@@ -98,7 +98,6 @@ struct agbnp_hip_context {
   // per-evaluation device data
   DevBuf<double> d_pbox, d_abox, d_epart;
   int mode = 0;  // AGBNP_HIP_MODE_* bits
-  DevBuf<double4> d_hacc;  // [nh] tree-stage sums per heavy atom (tree_kernels.h)
   DevBuf<double4> d_aposq;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -264,7 +263,10 @@ void wire_args(agbnp_hip_context* c) {
   P.nhb = (c->nh + 63) / 64;
   P.db_items = c->d_db_items.p;
   P.db_items_count = (int)c->d_db_items.count;
-  P.hacc = c->d_hacc.p;
+  P.gx = c->hrow(kHvGx);
+  P.gy = c->hrow(kHvGy);
+  P.gz = c->hrow(kHvGz);
+  P.sv_vdw = c->hrow(kHvSvVdw);
   P.sv_large = c->hrow(kHvSvLarge);
   P.epart = c->d_epart.p;
   P.status = c->d_status.p;
@@ -290,7 +292,6 @@ void wire_args(agbnp_hip_context* c) {
   T.nh = c->nh;
   T.hv = c->d_heavy.p;
   T.hstride = (unsigned)c->hstride;
-  T.hacc = reinterpret_cast<double*>(c->d_hacc.p);
   T.db_wu = c->d_dbf.p + 3 * (size_t)c->n;
   T.want_sv_large = c->diagnostics ? 1 : 0;  // pass-1 self volumes cost extra HBM atomics: opt-in
   T.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
@@ -403,8 +404,6 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_epart.alloc(2 * nslots));
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nslots));
   HIP_TRY(c, c->d_aposq.alloc(n));
-  HIP_TRY(c, c->d_hacc.alloc(nhp));
-  HIP_TRY(c, hipMemset(c->d_hacc.p, 0, sizeof(double4) * nhp));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
   HIP_TRY(c, c->d_abox.alloc(6 * (size_t)nblk));
   HIP_TRY(c, c->d_sizes.alloc(nhp));
@@ -751,14 +750,13 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
     }
     return AGBNP_HIP_OK;
   };
-  const double* hacc = reinterpret_cast<const double*>(c->d_hacc.p);  // the self volume is the fourth word of every record
   switch (which) {
-    case 0: return heavy_to_atoms(hacc, 4, 3, 0.0);
+    case 0: return heavy_to_atoms(c->hrow(kHvSvVdw), 1, 0, 0.0);
     case 1:
       if (c->version != 1) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "Born radii exist for version 1 only");
       HIP_TRY(c, hipMemcpy(out, c->d_born.p, sizeof(double) * n, hipMemcpyDeviceToHost));
       return AGBNP_HIP_OK;
-    case 2: return heavy_to_atoms(hacc, 4, 3, 1.0);
+    case 2: return heavy_to_atoms(c->hrow(kHvSvVdw), 1, 0, 1.0);
     case 3:
       if (!c->diagnostics) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "enlarged-radius self volumes need agbnp_hip_set_diagnostics(ctx, 1) before the evaluation");
       return heavy_to_atoms(c->hrow(kHvSvLarge), 1, 0, 0.0);

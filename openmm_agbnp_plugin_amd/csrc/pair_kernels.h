@@ -42,8 +42,8 @@ struct PairArgs {
   int fast;                // 1 = fast mode
   int det;                 // 1 = deterministic mode (device_math.h)
   // ---- tree accumulators / outputs
-  double4* hacc;           // [nh] {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}: atomic sums of the tree kernels
-  double* sv_large;        // [nh] (diagnostic)
+  double *gx, *gy, *gz;    // [nh] tree sums: gradient
+  double *sv_vdw, *sv_large;  // [nh] self volumes (enlarged radii: diagnostic)
   double* epart;           // [2nh]
   int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
   int* order;              // [4 nh] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation, by forest

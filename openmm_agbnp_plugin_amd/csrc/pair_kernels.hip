@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.hx[h] = x;
     P.hy[h] = y;
     P.hz[h] = z;
-    P.hacc[h] = make_double4(0.0, 0.0, 0.0, 0.0);
+    P.gx[h] = 0.0;
+    P.gy[h] = 0.0;
+    P.gz[h] = 0.0;
+    P.sv_vdw[h] = 0.0;
     P.sv_large[h] = 0.0;
     P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
   }
@@ -794,7 +797,7 @@ __device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const do
 __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
                                                    const double* __restrict__ pos, const int2* __restrict__ ameta,
-                                                   const double4* __restrict__ hacc, const double* __restrict__ inv_vol_h,
+                                                   const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
                                                    const double2* __restrict__ lut, double* __restrict__ born_part, double range2, int det) {
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
     if (gap2 >= range2) return;
   }
   for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
-  auto scale_of = [&](int slot, bool valid) { return valid && slot < nh ? hacc[slot].w * inv_vol_h[slot] : 0.0; };
+  auto scale_of = [&](int slot, bool valid) { return valid && slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0; };
   if (wave == 0) {
     const int slot = 64 * J + lane;
     const int aj = pslot[slot];
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
                                                     const double4* __restrict__ aposq, const int2* __restrict__ ameta,
                                                     const double* __restrict__ born, const double* __restrict__ born_fp,
                                                     const double* __restrict__ brw, const double* __restrict__ gb_y,
-                                                    const double4* __restrict__ hacc, const double* __restrict__ inv_vol_h,
+                                                    const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
                                                     int nh, const double2* __restrict__ lut, double* __restrict__ db_rows,
                                                     PairArgs P, double* __restrict__ energy_out,
                                                     double* __restrict__ components) {
@@ -944,7 +947,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   // (slot h of a heavy block is heavy atom h: its volume scaling factor comes straight from the tree's self volume)
   auto weights = [&](int a, int slot, double q) {
     const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
-    return make_double2(brw[a] + bru, slot < nh ? hacc[slot].w * inv_vol_h[slot] : 0.0);
+    return make_double2(brw[a] + bru, slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0);
   };
   if (wave == 0) {
     const int aj = pslot[64 * J + lane];
@@ -1017,10 +1020,9 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   double fx = 0, fy = 0, fz = 0;
   const int h = P.a2h[i];
   if (h >= 0) {  // cavity + pseudo-volume gradients -> force
-    const double4 g = P.hacc[h];
-    fx = -g.x;
-    fy = -g.y;
-    fz = -g.z;
+    fx = -P.gx[h];
+    fy = -P.gy[h];
+    fz = -P.gz[h];
   }
   if (version == 1) {
     fx += P.gb_fx[i] + P.db_fx[i];
@@ -1067,7 +1069,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
-                       (const double*)P.pbox, P.pos, P.ameta, (const double4*)P.hacc, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
+                       (const double*)P.pbox, P.pos, P.ameta, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
   if (P.fast)
@@ -1081,7 +1083,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   // (+ 1: the energy workgroup; with no heavy atom there is no tile but the role still runs)
   hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 1), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
                      (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
-                     (const double4*)P.hacc, P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components);
+                     (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }

@@ -48,6 +48,8 @@ enum HeavyRow {
   kHvGam,                      // gamma / roffset (pass 1 uses +gam, pass 2 -gam)
   kHvInvVol,                   // 1 / (4 pi R^3 / 3), vdW radius
   kHvSvLarge,                  // self volumes with the enlarged radii (diagnostic)
+  kHvGx, kHvGy, kHvGz,         // tree sums: gradient dE/dr ...
+  kHvSvVdw,                    // ... and self volumes (vdW radii); the four rows are consecutive (row kHvGx + c)
   kHvRows
 };
 
@@ -55,10 +57,6 @@ struct TreeArgs {
   int nh;                      // heavy atoms
   unsigned hstride;            // row stride of the heavy-atom table
   double* hv;                  // [kHvRows][hstride]
-  // per-heavy-atom sums of the tree stage, ONE 32-byte record per atom {dE/dx, dE/dy, dE/dz, self volume (vdW radii)}:
-  // float atomics execute at the memory side in 64-byte requests (~20 G requests/s chip-wide), and a forest's atoms
-  // are scattered over the table, so an atom's four sums must share a request rather than sit in four rows
-  double* hacc;                // [nh][4]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
   const int* order;            // [<= 4 nh] work items, by forest

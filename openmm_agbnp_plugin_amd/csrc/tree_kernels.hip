@@ -11,7 +11,7 @@ __device__ unsigned long long g_stamps_max[16];  // slowest workgroup per phase;
 __device__ unsigned long long g_stamps_slowest[24];  // the slowest workgroup's own phases [0..15] + slot, roots, nodes, atoms
 // per work slot: roots, nodes, local atoms, start / end on the 100 MHz wall clock, shader cycles, XCC id, CU id
 constexpr int kWgLogSlots = 8192;
-__device__ unsigned long long g_wg_log[kWgLogSlots][8];
+__device__ unsigned long long g_wg_log[kWgLogSlots][24];
 // per-workgroup sums live in the store (S.stamps); flushed once at the end (no contention inside phases)
 #define STAMP_BEGIN()                                   \
   if (tid < 16) S.stamps[tid] = 0;                      \
@@ -39,6 +39,7 @@ __device__ unsigned long long g_wg_log[kWgLogSlots][8];
       g_wg_log[slot][3] = t_wall0__; g_wg_log[slot][4] = wall_clock64();            \
       g_wg_log[slot][5] = __builtin_readcyclecounter() - t_cyc0__;                  \
       g_wg_log[slot][6] = xcc__; g_wg_log[slot][7] = hw__;                          \
+      for (int i__ = 0; i__ < 16; i__++) g_wg_log[slot][8 + i__] = S.stamps[i__];  \
     }                                                              \
     if (tid < 16) atomicAdd(&g_stamps[tid], S.stamps[tid]);        \
     if (tid < 16) atomicMax(&g_stamps_max[tid], S.stamps[tid]);    \
@@ -225,12 +226,15 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
     CSTAMP(5);
 
     // ---- flush per-atom sums (a root's self volume: its own sphere + every node of its tree)
-    // four adjacent lanes carry one atom's record: one 64-byte atomic request per atom instead of four
-    for (int k = tid; k < 4 * natoms; k += BS) {
-      const int la = k >> 2, comp = k & 3;
-      double v = S.at[6][comp * ACAP + la];  // rows 6..9 are contiguous (no dynamic index into the row table)
-      if (comp == 3 && la < m && (S.rt[kRtPart + la] & 0xff) == 0) v += quantize(S.at[4][la], kQVol, det);
-      glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], v);
+    // (one row per quantity: an atom's four adds go to four memory channels.  One 32-byte record per atom -- a quarter
+    // of the 64-byte atomic requests -- measured 1.3 us SLOWER: same-line adds queue at the memory side.)
+    for (int la = tid; la < natoms; la += BS) {
+      const int hj = S.at_gidx[la];
+      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+      glb_add(&A.hvat(kHvSvVdw, hj),
+              (la < m && (S.rt[kRtPart + la] & 0xff) == 0) ? S.at[9][la] + quantize(S.at[4][la], kQVol, det) : S.at[9][la]);
     }
     if (tid == 0) {
       double e2 = e_sum;
@@ -328,9 +332,11 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, A.det != 0, kPairs ? &pair_word : nullptr);
     PSTAMP(1);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
-    for (int k = tid; k < 4 * natoms; k += BS) {  // (lane 3 of every four idles: the record's fourth word is the self volume)
-      const int la = k >> 2, comp = k & 3;
-      if (comp < 3) glb_add(&A.hacc[4 * (size_t)S.at_gidx[la] + comp], S.at[6][comp * ACAP + la]);
+    for (int la = tid; la < natoms; la += BS) {
+      const int hj = S.at_gidx[la];
+      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
     }
     tree_barrier<NCAP>();
     PSTAMP(2);
@@ -350,7 +356,7 @@ extern "C" void agbnp_debug_stamps(unsigned long long* out, int reset) {
   }
 }
 extern "C" void agbnp_debug_wg_log(unsigned long long* out, int slots) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 8 * (size_t)(slots < kWgLogSlots ? slots : kWgLogSlots));
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_log), sizeof(unsigned long long) * 24 * (size_t)(slots < kWgLogSlots ? slots : kWgLogSlots));
 }
 extern "C" void agbnp_debug_stamps_slowest(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_slowest), sizeof(unsigned long long) * 24);

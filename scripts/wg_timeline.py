@@ -16,9 +16,9 @@ for k in range(4):
     ctx.setPositions(s.jittered(k)); ctx.getState()
 nf = int(ctx.kernel.scalar("forests"))
 ctx.setPositions(s.jittered(5)); ctx.getState()
-buf = (C.c_ulonglong * (8 * 8192))()
+buf = (C.c_ulonglong * (24 * 8192))()
 lib.agbnp_debug_wg_log(buf, 8192)
-log = np.array(list(buf), dtype=np.float64).reshape(8192, 8)[:nf]
+log = np.array(list(buf), dtype=np.float64).reshape(8192, 24)[:nf]
 t0 = log[:, 3].min()
 start, end = (log[:, 3] - t0) / 100.0, (log[:, 4] - t0) / 100.0  # us (100 MHz wall clock)
 life = end - start
@@ -56,3 +56,12 @@ print("slowest CUs (last end, forests, nodes, atoms, key):", rows[:8])
 print("fastest CUs:", rows[-5:])
 ends = np.array([r[0] for r in rows]); nodes_cu = np.array([r[2] for r in rows]); atoms_cu = np.array([r[3] for r in rows])
 print("corr(last end of CU, nodes on CU) = %.2f, with atoms %.2f" % (np.corrcoef(ends, nodes_cu)[0, 1], np.corrcoef(ends, atoms_cu)[0, 1]))
+
+# per-phase cycles by XCC (phases as in scripts/stamps.py): which phases make the slow XCCs slow?
+names = {8: "level-2 search", 9: "level-2 rank+create", 10: "phase0", 11: "phase1", 12: "phase2/3a", 13: "phase3", 1: "pass 1", 2: "topology out",
+         3: "switch radii", 4: "pass 2", 5: "root gradient", 6: "flush", 7: "node steps", 14: "gathers"}
+print("phase cycles (mean per forest) by xcc:")
+print("  %-22s" % "phase" + " ".join(f"xcc{x:d}".rjust(8) for x in range(8)))
+for k, nm in names.items():
+    row = [log[xcc == x, 8 + k].mean() if (xcc == x).any() else 0 for x in range(8)]
+    print("  %-22s" % nm + " ".join(f"{v:8.0f}" for v in row))
