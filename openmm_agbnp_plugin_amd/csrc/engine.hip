@@ -31,6 +31,7 @@ size_t tree_variant_lds_bytes(int variant);
 size_t tree_variant_scratch_bytes(int variant);
 int tree_variant_node_cap(int variant);
 int tree_variant_atom_cap(int variant);
+int tree_variant_wgs_per_cu(int variant);
 hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
@@ -322,7 +323,7 @@ void wire_args(agbnp_hip_context* c) {
     P.tree_node_cap = tree_variant_node_cap(c->variant);
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
     const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
-    P.pack_enabled = no_pack ? 0 : 1;
+    P.pack_enabled = no_pack ? 0 : (getenv("AGBNP_HIP_ITEMS_ALONE") ? 2 : 1);
     const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
     P.round_permille = std::max(100, round_permille);
     const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 3;
@@ -593,11 +594,8 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
     // resident tree workgroups per capacity variant: what one "round" of the forest packing is
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    c->tree_slots[0] = 5 * cus;
-    c->tree_slots[1] = 4 * cus;
-    c->tree_slots[2] = 2 * cus;
-    c->tree_slots[3] = cus;
-    c->tree_slots[4] = kGlobalGrid;
+    for (int v = 0; v < kGlobalVariant; v++) c->tree_slots[v] = tree_variant_wgs_per_cu(v) * cus;
+    c->tree_slots[kGlobalVariant] = kGlobalGrid;
   }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 

@@ -414,10 +414,11 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   }
   __syncthreads();
   const int nitems = imax[18];
-  const int na = pack ? imax[12] : nitems;      // forests of one heavy item
-  const int nab = pack ? imax[14] : nitems;     // ... plus the forests led by a class-B item
+  const bool forests = pack && P.pack_enabled != 2;  // (2: every work item alone, big subtrees still shared)
+  const int na = forests ? imax[12] : nitems;      // forests of one heavy item
+  const int nab = forests ? imax[14] : nitems;     // ... plus the forests led by a class-B item
   const int nb = nab - na;
-  const int npair = pack ? min(nb, nitems - imax[16]) : 0;  // class-B items that get a light partner
+  const int npair = forests ? min(nb, nitems - imax[16]) : 0;  // class-B items that get a light partner
   const int nc = nitems - nab - npair;          // items dealt over the remaining forests
   int fs = 0;
   if (nc > 0) {

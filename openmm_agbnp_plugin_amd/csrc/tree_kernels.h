@@ -926,7 +926,9 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       tree_barrier<NCAP>();
     }
     if (pair_word) {  // replay: the pair list arrives in registers and takes the place of the atom paths
-      if (tid < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid] = *pair_word;
+#pragma unroll
+      for (int k = 0; k < (PCAP / 8 + BS - 1) / BS; k++)
+        if (tid + k * BS < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid + k * BS] = pair_word[k];
       tree_barrier<NCAP>();
     }
     // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom), sums

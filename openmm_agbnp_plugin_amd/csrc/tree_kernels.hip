@@ -99,10 +99,12 @@ __device__ __forceinline__ int next_forest(int tid, int* lds_word, int ticket) {
 
 // Waves per SIMD the compiler is asked to leave room for = workgroups per CU that the variant's LDS footprint allows
 // (one wave of a workgroup per SIMD): 5 for the 432-node store (<= 96 VGPRs), 4 for 512 nodes (<= 128), fewer beyond.
-constexpr int tree_waves_per_simd(int ncap) { return ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2); }
+constexpr int tree_waves_per_simd(int ncap, int bs) {
+  return bs >= 256 ? (ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2)) : (ncap <= 192 ? 3 : 2);  // (one-wave workgroups: ~10 per CU for the small store)
+}
 
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(TreeArgs A) {
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_cavity(T
 // nu_i = (W_i+U_i)/V_i formed on the fly from the chain-rule sums, gradient only.  The reference does two passes
 // (W then U); the pass is linear in nu, so one pass with the sum gives the same gradient.
 template <int NCAP, int ACAP, int BS, bool GLOBAL>
-__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(TreeArgs A) {
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
@@ -271,16 +273,20 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     // values are masked below), a second one to the per-atom parameters.
     const SubtreeHeader* H = &A.hdr[slot];  // written by k_tree_cavity's workgroup of the same slot
     const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
-    static_assert(GLOBAL || (NCAP <= 8 * BS && ACAP <= BS), "prefetch registers");
-    unsigned long long pw[GLOBAL ? 1 : (NCAP + BS - 1) / BS];
+    constexpr bool kPrefetch = !GLOBAL && NCAP <= 8 * BS && ACAP <= BS;  // topology requested together with the header
+    unsigned long long pw[kPrefetch ? (NCAP + BS - 1) / BS : 1];
     int hj_pre = 0;
     constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
     constexpr int kPairWords = kPairs ? TreeStore<NCAP, ACAP>::PCAP / 8 : 1;  // 16-byte words of the pair list
-    static_assert(!kPairs || kPairWords <= BS, "one 16-byte word of the pair list per lane");
-    uint4 pair_word = make_uint4(0, 0, 0, 0);
-    if (kPairs && tid < kPairWords)
-      pair_word = reinterpret_cast<const uint4*>(A.pair_pool + (size_t)slot * TreeStore<NCAP, ACAP>::PCAP)[tid];
-    if (!GLOBAL) {
+    constexpr int kPairRegs = (kPairWords + BS - 1) / BS;                       // ... per lane
+    uint4 pair_word[kPairRegs];
+#pragma unroll
+    for (int k = 0; k < kPairRegs; k++) {
+      pair_word[k] = make_uint4(0, 0, 0, 0);
+      if (kPairs && tid + k * BS < kPairWords)
+        pair_word[k] = reinterpret_cast<const uint4*>(A.pair_pool + (size_t)slot * TreeStore<NCAP, ACAP>::PCAP)[tid + k * BS];
+    }
+    if (kPrefetch) {
 #pragma unroll
       for (int k = 0; k < (NCAP + BS - 1) / BS; k++) pw[k] = tid + k * BS < NCAP ? A.node_pool[pool_off + tid + k * BS] : 0ull;
       hj_pre = tid < ACAP ? A.atom_pool[atom_off + tid] : 0;
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     }
     {
       unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
-      if (GLOBAL) {
+      if (!kPrefetch) {
         for (int n = m + tid; n < nnodes; n += BS) path[n] = A.node_pool[pool_off + n];
       } else {
 #pragma unroll
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
       }
     }
     for (int la = tid; la < natoms; la += BS) {
-      const int hj = GLOBAL ? A.atom_pool[atom_off + la] : hj_pre;
+      const int hj = kPrefetch ? hj_pre : A.atom_pool[atom_off + la];
       S.at_gidx[la] = hj;
       S.at[0][la] = A.hvat(kHvX, hj);
       S.at[1][la] = A.hvat(kHvY, hj);
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP)) void k_tree_pseudo(T
     // every global load of this forest has been consumed: ask for the next one (see k_tree_cavity)
     if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
     double e_sum = 0.0;
-    volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, A.det != 0, kPairs ? &pair_word : nullptr);
+    volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, A.det != 0, kPairs ? pair_word : nullptr);
     PSTAMP(1);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     for (int la = tid; la < natoms; la += BS) {
@@ -380,10 +386,29 @@ static_assert(kBS <= kTreeBlock && kBS % 64 == 0, "tree block size");
 // LDS is handed out in granules of 1280 bytes on gfx950: five workgroups per CU need <= 25 granules each
 static_assert((TreeStore<432, 64>::kBytes + 16 + 1279) / 1280 * 5 <= 128, "five build workgroups per CU");
 static_assert((TreeStore<512, 64>::kBytes + 1279) / 1280 * 4 <= 128, "four build workgroups per CU");
+// Experimental build (-DAGBNP_TREE_BLOCK=64): one-wave workgroups, one subtree (or part of one) each, in a small store
+#if AGBNP_TREE_BLOCK == 64
+#define AGBNP_SMALL_STORE 192, 48
+constexpr int kSmallNodes = 192, kSmallAtoms = 48;
+#else
+#define AGBNP_SMALL_STORE 432, 64
+constexpr int kSmallNodes = 432, kSmallAtoms = 64;
+#endif
+size_t tree_variant_lds_bytes(int variant);
+int tree_variant_node_cap(int variant);
+// workgroups of the build kernel that a CU holds: LDS granules of 1280 B (128 per CU), 32 waves, the register budget
+int tree_variant_wgs_per_cu(int variant) {
+  const size_t bytes = tree_variant_lds_bytes(variant) + 16;
+  if (bytes <= 16) return 1;
+  const int by_lds = (int)(128 / ((bytes + 1279) / 1280));
+  const int waves = kBS / 64;
+  const int by_regs = 4 * tree_waves_per_simd(tree_variant_node_cap(variant), kBS) / waves;
+  return std::max(1, std::min(std::min(by_lds, by_regs), 32 / waves));
+}
 
 size_t tree_variant_lds_bytes(int variant) {
   switch (variant) {
-    case 0: return TreeStore<432, 64>::kBytes;
+    case 0: return TreeStore<AGBNP_SMALL_STORE>::kBytes;
     case 1: return TreeStore<512, 64>::kBytes;
     case 2: return TreeStore<1024, 128>::kBytes;
     case 3: return TreeStore<2048, 256>::kBytes;
@@ -394,12 +419,12 @@ size_t tree_variant_scratch_bytes(int variant) {
   return variant == 4 ? ((TreeStore<kGlobalNodeCap, kGlobalAtomCap>::kBytes + 255) / 256) * 256 : 0;
 }
 int tree_variant_node_cap(int variant) {
-  static const int caps[5] = {432, 512, 1024, 2048, kGlobalNodeCap};
+  static const int caps[5] = {kSmallNodes, 512, 1024, 2048, kGlobalNodeCap};
   return caps[variant];
 }
 
 int tree_variant_atom_cap(int variant) {
-  static const int caps[5] = {64, 64, 128, 256, kGlobalAtomCap};
+  static const int caps[5] = {kSmallAtoms, 64, 128, 256, kGlobalAtomCap};
   return caps[variant];
 }
 
@@ -418,10 +443,10 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
   if (A.nh <= 0) return hipSuccess;
 #ifdef AGBNP_STAMPS  // diagnostic build only: time the largest subtrees alone (results are incomplete)
   if (const char* env = getenv("AGBNP_DIAG_TREE_GRID"))
-    return launch_tree(k_tree_cavity<432, 64, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<432, 64>::kBytes, A, st);
+    return launch_tree(k_tree_cavity<AGBNP_SMALL_STORE, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<AGBNP_SMALL_STORE>::kBytes, A, st);
 #endif
   switch (variant) {
-    case 0: return launch_tree(k_tree_cavity<432, 64, kBS, false>, slots, TreeStore<432, 64>::kBytes, A, st);
+    case 0: return launch_tree(k_tree_cavity<AGBNP_SMALL_STORE, kBS, false>, slots, TreeStore<AGBNP_SMALL_STORE>::kBytes, A, st);
     case 1: return launch_tree(k_tree_cavity<512, 64, kBS, false>, slots, TreeStore<512, 64>::kBytes, A, st);
     case 2: return launch_tree(k_tree_cavity<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kBytes, A, st);
     case 3: return launch_tree(k_tree_cavity<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kBytes, A, st);
@@ -433,7 +458,7 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
   if (A.nh <= 0) return hipSuccess;
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<432, 64, kBS, false>, slots, TreeStore<432, 64>::kReplayBytes, A, st);
+    case 0: return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, slots, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
     case 1: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, slots, TreeStore<512, 64>::kReplayBytes, A, st);
     case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kReplayBytes, A, st);
     case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kReplayBytes, A, st);
