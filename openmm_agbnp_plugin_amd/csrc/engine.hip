@@ -459,8 +459,8 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
 // one subtree per work slot (what a context starts with, and what an overflowed evaluation is repeated on)
 int upload_identity_packing(agbnp_hip_context* c) {
   const size_t nhp = std::max(c->nh, 1), nslots = (size_t)c->slot_cap;
-  std::vector<int> ident(4 * nhp + 8, 0);  // work items: up to four per subtree
-  for (size_t k = 0; k < nhp; k++) ident[k] = (int)k;
+  std::vector<int> ident((size_t)kMaxItems * nslots + 8, 0);  // work items: item k of slot s at kMaxItems * s + k
+  for (size_t k = 0; k < nhp; k++) ident[(size_t)kMaxItems * k] = (int)k;
   HIP_TRY(c, c->d_order.upload(ident));
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
   // [slots+3] how often a packed forest has overflowed so far (kept)
@@ -865,6 +865,42 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* c, int* indices, int
 }
 
 unsigned agbnp_hip_generation(const agbnp_hip_context* c) { return c ? c->generation : 0u; }
+
+// ---- diagnostic entry points (not part of include/agbnp_hip.h; used by scripts/ only) ---------------------------------
+// the forest packing as the device holds it: order[] (work items), forest_start[0..nforests], and the per-subtree shapes
+int agbnp_debug_get_packing(agbnp_hip_context* c, int* order, int order_cap, int* forest_start, int start_cap, int* nforests, int* sizes) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  int nf = 0;
+  HIP_TRY(c, hipMemcpy(&nf, c->d_forest.p + c->slot_cap + 1, sizeof(int), hipMemcpyDeviceToHost));
+  *nforests = nf;
+  HIP_TRY(c, hipMemcpy(forest_start, c->d_forest.p, sizeof(int) * std::min(start_cap, nf + 1), hipMemcpyDeviceToHost));
+  {  // compact form for the caller: the items of forest f at forest_start[f] .. forest_start[f+1])
+    std::vector<int> dev(c->d_order.count);
+    HIP_TRY(c, hipMemcpy(dev.data(), c->d_order.p, sizeof(int) * dev.size(), hipMemcpyDeviceToHost));
+    for (int f = 0; f < nf && f + 1 < start_cap; f++)
+      for (int k = forest_start[f]; k < forest_start[f + 1] && k < order_cap; k++) order[k] = dev[(size_t)kMaxItems * f + (k - forest_start[f])];
+  }
+  if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->d_sizes.p, sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
+  return AGBNP_HIP_OK;
+}
+// replaces the packing and (freeze != 0) stops the bookkeeping from planning new ones
+int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, const int* forest_start, int nforests, int freeze) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  if (order) {
+    std::vector<int> dev(c->d_order.count, 0);
+    for (int f = 0; f < nforests; f++)
+      for (int k = forest_start[f]; k < forest_start[f + 1] && k < norder; k++) dev[(size_t)kMaxItems * f + (k - forest_start[f])] = order[k];
+    HIP_TRY(c, hipMemcpy(c->d_order.p, dev.data(), sizeof(int) * dev.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_forest.p, forest_start, sizeof(int) * (nforests + 1), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
+  }
+  c->P.pack_enabled = freeze ? 3 : c->P.pack_enabled;  // 3: the bookkeeping keeps its statistics but writes no packing
+  return AGBNP_HIP_OK;
+}
 
 int agbnp_hip_num_particles(const agbnp_hip_context* c) { return c ? c->n : -1; }
 int agbnp_hip_version(const agbnp_hip_context* c) { return c ? c->version : -1; }

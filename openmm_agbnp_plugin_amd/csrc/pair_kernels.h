@@ -46,7 +46,7 @@ struct PairArgs {
   double *sv_vdw, *sv_large;  // [nh] self volumes (enlarged radii: diagnostic)
   double* epart;           // [2nh]
   int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
-  int* order;              // [4 nh] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation, by forest
+  int* order;              // [kMaxItems * slots] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation: item k of slot s at kMaxItems * s + k
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)

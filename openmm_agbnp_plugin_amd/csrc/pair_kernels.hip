@@ -441,6 +441,7 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
     }
     return f < nf ? nab + npair + small_start(f - nab) : nitems;
   };
+  if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
   for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
   if (t == 0) {
     P.nforests[0] = nf;
@@ -462,19 +463,20 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
         const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
         for (int part = 0; part < parts; part++) {
           const int pos = (int)(v >> 32) + part;  // position in descending weight order
-          int dst;
-          if (pos < na) {
-            dst = pos;
-          } else if (pos < nab) {
-            dst = forest_first(pos);  // leads its forest
+          int forest, place;                      // the item is number `place` of forest `forest`
+          if (pos < nab) {
+            forest = pos;  // a forest of its own, or the leader of a class-B forest
+            place = 0;
           } else if (pos >= nitems - npair) {
-            dst = forest_first(na + (nitems - 1 - pos)) + 1;  // the lightest item joins the heaviest class-B item
+            forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
+            place = 1;
           } else {
             const int k = pos - nab, r = k / fs, idx = k - r * fs;
-            const int f = (r & 1) ? fs - 1 - idx : idx;
-            dst = nab + npair + small_start(f) + r;
+            forest = nab + ((r & 1) ? fs - 1 - idx : idx);
+            place = r;
           }
-          P.order[dst] = (base + b * 256 + t) | (part << 24) | ((parts - 1) << 26);
+          // fixed stride per work slot: a tree workgroup fetches its items and its forest_start pair in ONE round trip
+          P.order[kMaxItems * forest + place] = (base + b * 256 + t) | (part << 24) | ((parts - 1) << 26);
         }
       }
     }

@@ -59,7 +59,7 @@ struct TreeArgs {
   double* hv;                  // [kHvRows][hstride]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
-  const int* order;            // [<= 4 nh] work items, by forest
+  const int* order;            // [kMaxItems * slots] work items: item k of work slot s at kMaxItems * s + k
   const int* packing;          // [slot_cap + 1] forest_start: work slot s builds order[packing[s] .. packing[s+1]);
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
                                // pair stages run), [slot_cap + 2] the copy k_tree_cavity takes for THIS evaluation
@@ -89,7 +89,7 @@ constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of 
 // A workgroup builds a FOREST: up to kMaxRoots subtrees (of different heavy atoms) side by side in one store, level
 // by level.  Every phase of the expansion and of the volume passes is bound by latency, not by work, so a forest of a
 // few hundred nodes costs little more than one subtree of a hundred.
-constexpr int kMaxRoots = 8;
+constexpr int kMaxRoots = kMaxItems;
 constexpr int kRootWords = 6 * kMaxRoots + 8;
 enum RootWord {
   kRtHeavy = 0,              // heavy index of the root
@@ -379,12 +379,40 @@ enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 
 // forest, sibling lists never mix trees.  returns BuildResult (workgroup-uniform); on success *nnodes_out /
 // *natoms_out are set.
 template <int NCAP, int ACAP, int BS>
-__device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, const int* __restrict__ roots, int m,
+__device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, int my_item, const int (&items)[kMaxRoots], int m,
                             int* nnodes_out, int* natoms_out) {
+  // my_item: work item number tid of the forest (lanes tid < m); items[]: all of them, wave-uniform (scalar registers)
   constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
   AGBNP_BUILD_STAMP_BEGIN();
+  // The neighbour-mask words of the roots are requested NOW, together with the roots' own parameters: both only need
+  // the roots' heavy indices, which arrived with the work items.  (root, block) pairs of root q: blocks
+  // (heavy_q >> 6) .. nhb-1, laid end to end; lane tid takes pair tid (further trips, if any, follow the barrier).
+  int off[kMaxRoots + 1];
+  off[0] = 0;
+#pragma unroll
+  for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? A.nhb - (work_item_root(items[q]) >> 6) : 0);
+  const int npairs = off[kMaxRoots];
+  const size_t mask_stride = (size_t)A.nhb * 64;
+  auto pair_of = [&](int c, int& q, int& J, int& hq) {  // pair c -> root, block, the root's heavy index
+    // one fused pass over the (non-decreasing) offsets.  (Looking off[q] up after the count makes the compiler index
+    // the array dynamically, i.e. put it in scratch.)
+    q = 0;
+    int o = 0;
+    hq = work_item_root(items[0]);
+#pragma unroll
+    for (int k = 1; k < kMaxRoots; k++) {
+      const bool past = k < m && c >= off[k];
+      q += past ? 1 : 0;
+      o = past ? off[k] : o;
+      hq = past ? work_item_root(items[k]) : hq;
+    }
+    J = (hq >> 6) + (c - o);
+  };
+  int q_first, J_first, hq_first;
+  pair_of(tid, q_first, J_first, hq_first);
+  const unsigned long long bits_first = tid < npairs ? A.nbmask[(size_t)J_first * mask_stride + hq_first] : 0ull;
   if (tid < m) {
-    const int item = roots[tid];
+    const int item = my_item;
     const int hi = work_item_root(item);
     const double rx = A.hvat(kHvX, hi), ry = A.hvat(kHvY, hi), rz = A.hvat(kHvZ, hi);
     const double ra = A.hvat(kHvALarge, hi), rv = A.hvat(kHvVLarge, hi), rg = A.hvat(kHvGam, hi);
@@ -441,36 +469,21 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       S.nd[6][st] = gvol;  // unswitched overlap with the root: the level-2 node's volume
     }
   };
-  {
-    // pairs of root q: blocks (heavy_q >> 6) .. nhb-1; offsets of the roots' pair ranges (m <= kMaxRoots)
-    int off[kMaxRoots + 1];
-    off[0] = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxRoots; q++) off[q + 1] = off[q] + (q < m ? A.nhb - (S.rt[kRtHeavy + q] >> 6) : 0);
-    const int npairs = off[kMaxRoots];
-    const size_t mask_stride = (size_t)A.nhb * 64;
-    for (int base = 0; base < npairs; base += BS) {
-      const int c = base + tid;
-      // root of pair c and the start of that root's range: one fused pass over the (non-decreasing) offsets.
-      // (Looking off[q] up after the count makes the compiler index the array dynamically, i.e. put it in scratch.)
-      int q = 0, o = 0;
-#pragma unroll
-      for (int k = 1; k < kMaxRoots; k++) {
-        const bool past = k < m && c >= off[k];
-        q += past ? 1 : 0;
-        o = past ? off[k] : o;
-      }
-      const int hq = S.rt[kRtHeavy + q];
-      const int J = (hq >> 6) + (c - o);
-      unsigned long long bits = c < npairs ? A.nbmask[(size_t)J * mask_stride + hq] : 0ull;
-      if (bits) {
-        int p = atomicAdd(&S.ctl[5], (int)__popcll(bits));
-        for (; bits; bits &= bits - 1, p++) {
-          if (p < kNearCap)
-            S.nd[6][NCAP - 1 - p] = __hiloint2double(0, (64 * J + __builtin_ctzll(bits)) | (q << 24));
-          else
-            S.ctl[6] = 1;  // more near candidates than staging slots (dense synthetic systems): next capacity variant
-        }
+  for (int base = 0; base < npairs; base += BS) {
+    const int c = base + tid;
+    int q = q_first, J = J_first, hq;
+    unsigned long long bits = bits_first;  // first trip: already in flight since before the barrier
+    if (base > 0) {
+      pair_of(c, q, J, hq);
+      bits = c < npairs ? A.nbmask[(size_t)J * mask_stride + hq] : 0ull;
+    }
+    if (bits) {
+      int p = atomicAdd(&S.ctl[5], (int)__popcll(bits));
+      for (; bits; bits &= bits - 1, p++) {
+        if (p < kNearCap)
+          S.nd[6][NCAP - 1 - p] = __hiloint2double(0, (64 * J + __builtin_ctzll(bits)) | (q << 24));
+        else
+          S.ctl[6] = 1;  // more near candidates than staging slots (dense synthetic systems): next capacity variant
       }
     }
   }

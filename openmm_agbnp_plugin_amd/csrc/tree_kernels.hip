@@ -117,9 +117,19 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   for (int slot = blockIdx.x; slot < nforests;) {
     int ticket = nforests;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
     do {
-    const int f0 = A.forest_start()[slot];
-    const int m = A.forest_start()[slot + 1] - f0;  // 1..kMaxRoots roots, largest forests first
-    const int* roots = A.order + f0;
+    // one round trip: lanes 0..7 of every wave fetch the slot's work items, lanes 8 and 9 its forest_start pair
+    int my_item = 0;
+    {
+      const int lane = tid & 63;
+      if (lane < kMaxRoots)
+        my_item = A.order[(size_t)kMaxRoots * slot + lane];
+      else if (lane < kMaxRoots + 2)
+        my_item = A.forest_start()[slot + lane - kMaxRoots];
+    }
+    const int m = __builtin_amdgcn_readlane(my_item, kMaxRoots + 1) - __builtin_amdgcn_readlane(my_item, kMaxRoots);  // 1..kMaxRoots
+    int items[kMaxRoots];
+#pragma unroll
+    for (int q = 0; q < kMaxRoots; q++) items[q] = __builtin_amdgcn_readlane(my_item, q);
     for (int la = tid; la < ACAP; la += BS) {
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
@@ -129,13 +139,13 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     tree_barrier<NCAP>();
     CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
-    int rc = build_forest<NCAP, ACAP, BS>(S, A, tid, roots, m, &nnodes, &natoms);
+    int rc = build_forest<NCAP, ACAP, BS>(S, A, tid, my_item, items, m, &nnodes, &natoms);
     CSTAMP(0);
     double e_sum = 0.0;
     int npairs = 0;
     // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
     // LDS variants: one atom per lane)
-    const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : work_item_root(roots[0]);
+    const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : work_item_root(items[0]);
     const double a_vdw_mine = A.hvat(kHvAVdw, hj_mine), v_vdw_mine = A.hvat(kHvVVdw, hj_mine);
     const bool want_sv1 = A.want_sv_large != 0;
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).

@@ -65,3 +65,16 @@ print("  %-22s" % "phase" + " ".join(f"xcc{x:d}".rjust(8) for x in range(8)))
 for k, nm in names.items():
     row = [log[xcc == x, 8 + k].mean() if (xcc == x).any() else 0 for x in range(8)]
     print("  %-22s" % nm + " ".join(f"{v:8.0f}" for v in row))
+# which slots share a CU?  (dispatch order -> placement)
+print("slots per CU (first 6 CUs by key):")
+for k in u[:6]:
+    sl = np.flatnonzero(key == k)
+    print(f"  key {k}: slots {sl.tolist()}  nodes {log[sl,1].astype(int).tolist()}  ends {[round(float(x),1) for x in end[sl]]}")
+per_cu_nodes = np.array([log[key == k, 1].sum() for k in u]); per_cu_life = np.array([life[key == k].mean() for k in u])
+print("per-CU nodes: min %d mean %d max %d; corr(mean life on CU, nodes on CU) = %.2f" % (per_cu_nodes.min(), per_cu_nodes.mean(), per_cu_nodes.max(), np.corrcoef(per_cu_nodes, per_cu_life)[0, 1]))
+# per-phase cost model: cycles ~ c0 + c1 nodes + c2 local atoms + c3 roots
+print("per-phase fit (cycles):            const   /node   /atom   /root   (mean)")
+for kph, nm in names.items():
+    y = log[:, 8 + kph]
+    cf, *_ = np.linalg.lstsq(A, y, rcond=None)
+    print("  %-22s %8.0f %7.1f %7.1f %7.0f   %8.0f" % (nm, cf[0], cf[1], cf[2], cf[3], y.mean()))
