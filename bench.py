@@ -145,7 +145,7 @@ def load_workload(name):
 class Replica:
     """One context + its device-resident geometries, forces and energy."""
 
-    def __init__(self, torch, system, version, device, dev_index, steps, seed0, method=None, cutoff=1.0, mode=None):
+    def __init__(self, torch, system, version, device, dev_index, steps, seed0, method=None, cutoff=1.0, mode=None, stream=None):
         self.torch, self.system, self.n = torch, system, system.n
         force = P.AGBNPForce.from_arrays(*system.params(), version=version)
         force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic if method is None else method)  # example/1dwc_benchmark.py:10
@@ -156,7 +156,7 @@ class Replica:
         self.d_pos = torch.tensor(self.geoms, dtype=torch.float64, device=device).contiguous()
         self.d_force = torch.zeros((self.n, 3), dtype=torch.float64, device=device)
         self.d_energy = torch.zeros((1,), dtype=torch.float64, device=device)
-        self.stream = torch.cuda.current_stream().cuda_stream
+        self.stream = torch.cuda.current_stream().cuda_stream if stream is None else stream.cuda_stream
         self.step_bytes = self.n * 3 * 8
 
     def run(self, first, count):
@@ -211,6 +211,33 @@ def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_
         cpu_ms, de, df = cpu_baseline_leg(system, r.geoms[warmup:], r.host_results(warmup, cpu_evals), cpu_evals, version=version, **oracle_kw)
         entry.update({"cpu_ms_per_eval": cpu_ms, "parity_on_sample": {"evals": cpu_evals, "max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df}})
     return entry
+
+
+def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, warmup):
+    """Aggregate throughput of several INDEPENDENT replicas sharing one GPU, each context on a stream of its own (multiple
+    walkers / replica exchange on one device).  The evaluation is bound by dependent latency, not by throughput, so
+    kernels of different replicas overlap; this is NOT the headline metric (one replica per GPU), it shows the headroom."""
+    system = load_workload(name)
+    streams = [torch.cuda.Stream(device=device) for _ in range(replicas)]
+    reps = []
+    for r, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            rep = Replica(torch, system, 1, device, dev_index, steps + warmup, 9000 + 977 * r, stream=st)
+            rep.settle(warmup)
+            reps.append(rep)
+    torch.cuda.synchronize()
+    for attempt in range(3):
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):  # round-robin enqueue: one evaluation of every replica per turn
+            for rep in reps:
+                rep.run(s, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if not any(rep.kernel.finish(rep.stream) for rep in reps):
+            break
+    ms = 1e3 * (t1 - t0) / steps  # per round of `replicas` evaluations
+    return {"workload": name, "replicas_on_one_gpu": replicas, "ms_per_round": ms, "ms_per_eval_aggregate": ms / replicas,
+            "aggregate_ns_day": replicas * 86.4 / ms}
 
 
 def main():
@@ -364,6 +391,7 @@ def main():
         sec.append(dict(config="4: HIV-RT stand-in = 2x2x1 lattice of 1dwc (synthetic), AGBNP1",
                         **secondary_entry(torch, "1dwc_x4", 1, device, dev_index, 40, 6, 1)))
         result["secondary"] = sec
+        result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(torch, "1dwc", device, dev_index, r, 200, 20) for r in (2, 4)]
 
     if rank == 0:
         print(json.dumps(result))
