@@ -88,7 +88,8 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_gb_items, d_db_items, d_pslot;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_fslot, d_gb_items, d_db_items, d_pslot;
+  int cus = 256;
   DevBuf<unsigned long long> d_nbmask;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
@@ -319,6 +320,10 @@ void wire_args(agbnp_hip_context* c) {
     P.nforests = c->d_forest.p + nhp1 + 1;
     P.cur_nforests = c->d_forest.p + nhp1 + 2;
     P.pack_state = c->d_forest.p + nhp1 + 3;
+    P.forest_of_slot = c->d_fslot.p;
+    P.forest_time = c->d_fslot.p + nhp1;
+    P.ncus = c->cus;
+    T.forest_of_slot = c->d_fslot.p;
     P.tree_slot_cap = c->slot_cap;
     P.tree_node_cap = tree_variant_node_cap(c->variant);
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
@@ -462,6 +467,11 @@ int upload_identity_packing(agbnp_hip_context* c) {
   std::vector<int> ident((size_t)kMaxItems * nslots + 8, 0);  // work items: item k of slot s at kMaxItems * s + k
   for (size_t k = 0; k < nhp; k++) ident[(size_t)kMaxItems * k] = (int)k;
   HIP_TRY(c, c->d_order.upload(ident));
+  {
+    std::vector<int> fslot(2 * nslots, 0);  // slot -> forest (identity), then the bookkeeping's forest times
+    for (size_t k = 0; k < nslots; k++) fslot[k] = (int)k;
+    HIP_TRY(c, c->d_fslot.upload(fslot));
+  }
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
   // [slots+3] how often a packed forest has overflowed so far (kept)
   std::vector<int> forest(nslots + 3);
@@ -594,6 +604,7 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
     // resident tree workgroups per capacity variant: what one "round" of the forest packing is
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    c->cus = cus;
     for (int v = 0; v < kGlobalVariant; v++) c->tree_slots[v] = tree_variant_wgs_per_cu(v) * cus;
     c->tree_slots[kGlobalVariant] = kGlobalGrid;
   }
@@ -897,6 +908,9 @@ int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, 
     HIP_TRY(c, hipMemcpy(c->d_order.p, dev.data(), sizeof(int) * dev.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_forest.p, forest_start, sizeof(int) * (nforests + 1), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> ident(c->slot_cap);
+    for (int k = 0; k < c->slot_cap; k++) ident[k] = k;
+    HIP_TRY(c, hipMemcpy(c->d_fslot.p, ident.data(), sizeof(int) * ident.size(), hipMemcpyHostToDevice));
   }
   c->P.pack_enabled = freeze ? 3 : c->P.pack_enabled;  // 3: the bookkeeping keeps its statistics but writes no packing
   return AGBNP_HIP_OK;

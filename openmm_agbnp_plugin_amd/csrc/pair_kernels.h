@@ -51,6 +51,10 @@ struct PairArgs {
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
   int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
+  int* forest_of_slot;     // [slots] which forest work slot s builds: slot s runs on CU s mod (number of CUs), so the
+                           // bookkeeping deals the forests, sorted by predicted time, over the CUs in serpentine order
+  int* forest_time;        // [slots] predicted time of every forest (scratch of the bookkeeping)
+  int ncus;                // CUs of the device
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
   int split_big, split_permille;  // tuning knobs: parts and node threshold (share of the capacity) for sharing on a full device

@@ -443,6 +443,8 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   };
   if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
   for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
+  for (int f = t; f < nf; f += 256) P.forest_time[f] = 0;
+  __syncthreads();  // (the barrier waits for this workgroup's stores; the adds below execute in the same L2)
   if (t == 0) {
     P.nforests[0] = nf;
     P.status[kStatForests] = nf;
@@ -477,8 +479,66 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
           }
           // fixed stride per work slot: a tree workgroup fetches its items and its forest_start pair in ONE round trip
           P.order[kMaxItems * forest + place] = (base + b * 256 + t) | (part << 24) | ((parts - 1) << 26);
+          // predicted time of the work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom,
+          // 1.6 per root; units of 0.01 us)
+          const int l2 = max(sz[b].y - 1, 0);
+          atomicAdd(&P.forest_time[forest], 9 * (1 + l2 + max(sz[b].x - 1 - l2, 0) / parts) + 34 * sz[b].y + 160);
         }
       }
+    }
+  }
+  // ---- forests -> work slots.  Work slot s runs on CU s mod ncus (observed: the dispatcher deals workgroups round-robin
+  // over the CUs), and a CU's workgroups slow each other down, so the forests are ranked by predicted time (descending,
+  // histogram sort) and dealt over the CUs in serpentine order: row 0 left to right, row 1 right to left, ...
+  __syncthreads();  // (waits for this workgroup's adds; they executed in L2, where the agent-scope loads below read)
+  for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
+  __syncthreads();
+  auto time_bin = [&](int tm) { return kBins - 1 - min(kBins - 1, tm >> 4); };
+  constexpr int kFB = 8;  // forests per thread and trip, loads in flight together
+  for (int fb = 0; fb < nf; fb += 256 * kFB) {
+    int tm[kFB];
+#pragma unroll
+    for (int b = 0; b < kFB; b++) {
+      const int f = fb + b * 256 + t;
+      tm[b] = f < nf ? __hip_atomic_load(&P.forest_time[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+#pragma unroll
+    for (int b = 0; b < kFB; b++)
+      if (tm[b] >= 0) atomicAdd(&comb[time_bin(tm[b])], 1ull);
+  }
+  __syncthreads();
+  {
+    const unsigned long long c0 = comb[2 * t], c1 = comb[2 * t + 1];
+    unsigned long long inc2 = c0 + c1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long v = __shfl_up(inc2, off, 64);
+      if ((t & 63) >= off) inc2 += v;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) part[t >> 6] = inc2;
+    __syncthreads();
+    unsigned long long before2 = 0ull;
+    for (int w = 0; w < (t >> 6); w++) before2 += part[w];
+    const unsigned long long ex2 = before2 + inc2 - (c0 + c1);
+    comb[2 * t] = ex2;
+    comb[2 * t + 1] = ex2 + c0;
+  }
+  __syncthreads();
+  const int ncu = max(P.ncus, 1), last_row = nf / ncu, last_width = nf - last_row * ncu;
+  for (int fb = 0; fb < nf; fb += 256 * kFB) {
+    int tm[kFB];
+#pragma unroll
+    for (int b = 0; b < kFB; b++) {
+      const int f = fb + b * 256 + t;
+      tm[b] = f < nf ? __hip_atomic_load(&P.forest_time[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+#pragma unroll
+    for (int b = 0; b < kFB; b++) {
+      if (tm[b] < 0) continue;
+      const int r = (int)atomicAdd(&comb[time_bin(tm[b])], 1ull);  // rank by descending predicted time
+      const int q = r / ncu, p = r - q * ncu;
+      const int width = q < last_row ? ncu : last_width;
+      P.forest_of_slot[q * ncu + ((q & 1) ? width - 1 - p : p)] = fb + b * 256 + t;
     }
   }
 }

@@ -117,14 +117,16 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   for (int slot = blockIdx.x; slot < nforests;) {
     int ticket = nforests;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
     do {
-    // one round trip: lanes 0..7 of every wave fetch the slot's work items, lanes 8 and 9 its forest_start pair
+    // which forest this slot builds (a scalar load), then one round trip: lanes 0..7 of every wave fetch the forest's
+    // work items, lanes 8 and 9 its forest_start pair
+    const int forest = A.forest_of_slot[slot];
     int my_item = 0;
     {
       const int lane = tid & 63;
       if (lane < kMaxRoots)
-        my_item = A.order[(size_t)kMaxRoots * slot + lane];
+        my_item = A.order[(size_t)kMaxRoots * forest + lane];
       else if (lane < kMaxRoots + 2)
-        my_item = A.forest_start()[slot + lane - kMaxRoots];
+        my_item = A.forest_start()[forest + lane - kMaxRoots];
     }
     const int m = __builtin_amdgcn_readlane(my_item, kMaxRoots + 1) - __builtin_amdgcn_readlane(my_item, kMaxRoots);  // 1..kMaxRoots
     int items[kMaxRoots];
