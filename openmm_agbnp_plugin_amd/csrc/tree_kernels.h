@@ -33,6 +33,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "agbnp_common.h"
 #include "device_math.h"
 
@@ -138,7 +140,11 @@ struct TreeStore {
   // (atom, node) membership pairs sorted by atom, one 16-bit word each (atom << 9 | node): the gather of a volume
   // pass walks this list instead of testing every node against every atom.  Built once per subtree after the
   // build, when the four 16-bit topology arrays are dead: the list lives in their place.
+#ifdef AGBNP_NO_PAIR_GATHER  // timing experiment: the atomics-free (atom, slice) gather for every variant
+  static constexpr bool kPairGather = false;
+#else
   static constexpr bool kPairGather = NCAP <= 512 && ACAP <= 128;
+#endif
   static constexpr int PCAP = 4 * NCAP;
   unsigned short* pairs;  // [PCAP]
   int* pcnt;              // [ACAP] per-atom counts / fill cursors while the list is built (overlays cand_vol)
@@ -303,6 +309,10 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
 }
 
 __device__ __forceinline__ void lds_add(double* p, double v) {
+#ifdef AGBNP_TIMING_PLAIN_LDS_ADD  // timing experiment only: racy, results are wrong
+  *p += v;
+  return;
+#endif
   // LDS FP64 add; with -munsafe-fp-atomics this is ds_add_f64
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -945,28 +955,57 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         if (tid + k * BS < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid + k * BS] = pair_word[k];
       tree_barrier<NCAP>();
     }
-    // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom), sums
-    // the terms of a run of the same atom in registers and adds the run to the atom's accumulators with LDS FP64
-    // atomics: work proportional to the memberships (about three per node), independent of how many local
-    // atoms the subtree has, and balanced over the lanes whatever the shape of the tree.
+    // (3) gather over the pair list.  Every lane takes an equal, contiguous piece of the list (sorted by atom) and sums
+    // the terms of every run of the same atom in registers: work proportional to the memberships (about three per
+    // node), independent of how many local atoms the subtree has, balanced whatever the shape of the tree.
+    // Combining the runs.  An LDS FP64 atomic holds the CU's LDS pipe for ~160 cycles per wave instruction, whatever
+    // the number of active lanes, and a lane-by-lane flush issued about eight of them per wave and pass (racy plain
+    // adds in their place: k_tree_cavity -4.4 us, k_tree_pseudo -2.0 us on 1dwc).  So only what really is shared goes
+    // through an atomic (this form: -0.6 / -0.35 us; the scan below costs most of what the atomics did):
+    //   * a run that begins and ends inside a lane's piece is that lane's alone: plain read-add-write;
+    //   * the lane's FIRST run, if it continues the previous lane's last run, is handed to that lane (one DPP shift);
+    //   * the lanes' LAST runs are combined inside the wave by a segmented DPP scan keyed by the atom (pieces are
+    //     contiguous and the list is sorted, so the lanes of a run are neighbours); the last lane of a segment holds the
+    //     run's sum and stores it -- plainly if the run lies inside the wave, with the atomic only if it touches the
+    //     wave's first or last lane (it may go on in the neighbouring wave), as does lane 0's first run.
+    // That leaves at most one atomic instruction per quantity, wave and pass.
     const int total = *npairs;
     const int chunk = (total + BS - 1) / BS;
     int k = tid * chunk;
     const int kend = k + chunk < total ? k + chunk : total;
-    int cur = -1;
+    const int lane = tid & 63;
+    int cur = -1, head_atom = -1;
+    bool in_first = true;
     double xa = 0.0, ya = 0.0, za = 0.0, ea = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, sv = 0.0;
-    auto flush = [&]() {
-      lds_add(&S.at[6][cur], gx);
-      lds_add(&S.at[7][cur], gy);
-      lds_add(&S.at[8][cur], gz);
-      if (with_selfvol) lds_add(&S.at[9][cur], sv);
+    double hx = 0.0, hy = 0.0, hz = 0.0, hs = 0.0;  // the piece's first run, if it ends inside the piece
+    auto plain_add = [&](int atom, double vx, double vy, double vz, double vs) {  // nobody else touches `atom` in this pass
+      S.at[6][atom] += vx;
+      S.at[7][atom] += vy;
+      S.at[8][atom] += vz;
+      if (with_selfvol) S.at[9][atom] += vs;
+    };
+    auto atomic_add = [&](int atom, double vx, double vy, double vz, double vs) {
+#ifdef AGBNP_TIMING_GATHER_PLAIN  // timing experiment only: racy across waves
+      return plain_add(atom, vx, vy, vz, vs);
+#endif
+      lds_add(&S.at[6][atom], vx);
+      lds_add(&S.at[7][atom], vy);
+      lds_add(&S.at[8][atom], vz);
+      if (with_selfvol) lds_add(&S.at[9][atom], vs);
     };
     for (; k < kend; k++) {
       const int pr = S.pairs[k];
       const int a = pr >> 9, n = pr & 511;
       const double cf = S.nd[3][n], cx = S.nd[0][n], cy = S.nd[1][n], cz = S.nd[2][n], wn = S.wrow[n];
       if (a != cur) {
-        if (cur >= 0) flush();
+        if (cur >= 0) {  // a run has ended inside the piece
+          if (in_first) {
+            head_atom = cur, hx = gx, hy = gy, hz = gz, hs = sv;
+          } else {
+            plain_add(cur, gx, gy, gz, sv);
+          }
+          in_first = false;
+        }
         cur = a;
         xa = S.at[0][a], ya = S.at[1][a], za = S.at[2][a], ea = S.at[3][a];
         gx = gy = gz = sv = 0.0;
@@ -983,7 +1022,56 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       }
       sv += wn;
     }
-    if (cur >= 0) flush();
+    // keys: the atom of the lane's last run; lanes without a piece get keys of their own (no two equal)
+    const int key = cur >= 0 ? cur : -2 - lane;
+    {
+      // first runs: continuation of the previous lane's last run -> that lane takes it; else it is a complete run
+      const int prev_key = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);       // wave_shr:1 (lane 0 keeps -1)
+      const bool head_cont = head_atom >= 0 && lane > 0 && prev_key == head_atom;
+      if (head_atom >= 0 && !head_cont) {
+        if (lane == 0)
+          atomic_add(head_atom, hx, hy, hz, hs);  // (may continue the previous wave's last run)
+        else
+          plain_add(head_atom, hx, hy, hz, hs);
+      }
+      // lane l receives lane l+1's continuing first run (wave_shl:1; lane 63 receives nothing)
+      const double sx = head_cont ? hx : 0.0, sy = head_cont ? hy : 0.0, sz = head_cont ? hz : 0.0, ss = head_cont ? hs : 0.0;
+      gx += dpp_f64<0x130, 0xf>(sx);
+      gy += dpp_f64<0x130, 0xf>(sy);
+      gz += dpp_f64<0x130, 0xf>(sz);
+      if (with_selfvol) sv += dpp_f64<0x130, 0xf>(ss);
+    }
+    // segmented inclusive scan over the lanes (4 shifts inside each row of 16 lanes, then two row broadcasts)
+    auto seg_step = [&](auto ctrl_tag, auto mask_tag) {
+      constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+      const int src_key = __builtin_amdgcn_update_dpp(-1, key, CTRL, MASK, 0xf, false);  // lanes without a source keep -1
+      const bool same = src_key == key;
+      const double ax = dpp_f64<CTRL, MASK>(gx), ay = dpp_f64<CTRL, MASK>(gy), az = dpp_f64<CTRL, MASK>(gz);
+      gx += same ? ax : 0.0;
+      gy += same ? ay : 0.0;
+      gz += same ? az : 0.0;
+      if (with_selfvol) {
+        const double as = dpp_f64<CTRL, MASK>(sv);
+        sv += same ? as : 0.0;
+      }
+    };
+    seg_step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    seg_step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    seg_step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    seg_step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+    seg_step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1, 3
+    seg_step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2, 3
+    {
+      const int next_key = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1 (lane 63 keeps -1)
+      const bool seg_end = cur >= 0 && (lane == 63 || next_key != key);
+      const int key_first = __builtin_amdgcn_readfirstlane(key), key_last = __builtin_amdgcn_readlane(key, 63);
+      if (seg_end) {
+        if (key == key_first || key == key_last)
+          atomic_add(cur, gx, gy, gz, sv);  // the run may go on in the neighbouring wave
+        else
+          plain_add(cur, gx, gy, gz, sv);
+      }
+    }
     tree_barrier<NCAP>();
     AGBNP_BUILD_STAMP(14);
     return true;

@@ -78,3 +78,8 @@ for kph, nm in names.items():
     y = log[:, 8 + kph]
     cf, *_ = np.linalg.lstsq(A, y, rcond=None)
     print("  %-22s %8.0f %7.1f %7.1f %7.0f   %8.0f" % (nm, cf[0], cf[1], cf[2], cf[3], y.mean()))
+# lifetime by dispatch row (slot // 256)
+rows = (np.arange(nf) // 256)
+for r in range(rows.max() + 1):
+    sel = rows == r
+    print(f"  row {r}: {sel.sum():4d} forests, nodes mean {log[sel,1].mean():6.1f}, start {start[sel].mean():4.1f}, life mean {life[sel].mean():5.1f} max {life[sel].max():5.1f}, end mean {end[sel].mean():5.1f} max {end[sel].max():5.1f}")
