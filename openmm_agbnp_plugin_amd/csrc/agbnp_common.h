@@ -47,7 +47,8 @@ struct SubtreeHeader {
 // workgroup sweeping all younger positions itself moved 50 MB through the L2 per evaluation of 1dwc -- the sweep
 // was bound by that, not by its arithmetic.)
 
-constexpr int kMaxItems = 8;  // work items (subtrees or parts of one) per work slot = forest; order[kMaxItems * slot + k]
+constexpr int kMaxItems = 8;  // work items (subtrees or parts of one) per work slot = forest
+constexpr int kRowStride = 16;  // a work slot's row: kMaxItems items, their number, padding -- 64 bytes, ONE load instruction
 
 // status/overflow word indices (device int array of kStatTotalWords).
 // Words [0, kStatEvalWords) belong to ONE evaluation: k_prep clears them.  The words from kStatEvalSeq on are STICKY:

@@ -88,7 +88,7 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_forest, d_fslot, d_gb_items, d_db_items, d_pslot;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_ftime, d_rows, d_forest, d_gb_items, d_db_items, d_pslot;
   int cus = 256;
   DevBuf<unsigned long long> d_nbmask;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
@@ -100,7 +100,9 @@ struct agbnp_hip_context {
   // per-evaluation device data
   DevBuf<double> d_pbox, d_abox, d_epart;
   int mode = 0;  // AGBNP_HIP_MODE_* bits
-  DevBuf<double4> d_aposq;
+  DevBuf<double4> d_aposq, d_prec, d_srec;
+  DevBuf<double> d_ys;
+  DevBuf<int> d_a2s;
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
   DevBuf<SubtreeHeader> d_hdr;
@@ -255,6 +257,10 @@ void wire_args(agbnp_hip_context* c) {
   P.hz = c->hrow(kHvZ);
   P.aposq = c->d_aposq.p;
   P.pbox = c->d_pbox.p;
+  P.a2s = c->d_a2s.p;
+  P.prec = c->d_prec.p;
+  P.srec = c->d_srec.p;
+  P.ys = c->d_ys.p;
   P.abox = c->d_abox.p;
   P.fast = (c->mode & AGBNP_HIP_MODE_FAST) ? 1 : 0;
   P.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
@@ -281,7 +287,6 @@ void wire_args(agbnp_hip_context* c) {
   P.gb_fx = c->d_gbf.p;
   P.gb_fy = c->d_gbf.p + c->n;
   P.gb_fz = c->d_gbf.p + 2 * (size_t)c->n;
-  P.gb_y = c->d_gbf.p + 3 * (size_t)c->n;
   P.gb_items = c->d_gb_items.p;
   P.gb_items_count = (int)c->d_gb_items.count;
   P.db_fx = c->d_dbf.p;
@@ -305,7 +310,9 @@ void wire_args(agbnp_hip_context* c) {
   P.sizes = c->d_sizes.p;
   T.sizes = c->d_sizes.p;
   P.order = c->d_order.p;
-  T.order = c->d_order.p;
+  P.forest_time = c->d_ftime.p;
+  P.rows = c->d_rows.p;
+  T.rows = c->d_rows.p;
   P.a_large = c->hrow(kHvALarge);
   P.v_large = c->hrow(kHvVLarge);
   P.rcut2 = c->T.rcut2;
@@ -320,10 +327,7 @@ void wire_args(agbnp_hip_context* c) {
     P.nforests = c->d_forest.p + nhp1 + 1;
     P.cur_nforests = c->d_forest.p + nhp1 + 2;
     P.pack_state = c->d_forest.p + nhp1 + 3;
-    P.forest_of_slot = c->d_fslot.p;
-    P.forest_time = c->d_fslot.p + nhp1;
     P.ncus = c->cus;
-    T.forest_of_slot = c->d_fslot.p;
     P.tree_slot_cap = c->slot_cap;
     P.tree_node_cap = tree_variant_node_cap(c->variant);
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
@@ -384,12 +388,34 @@ int allocate_work(agbnp_hip_context* c) {
       if (c->a2h[i] < 0) pslot[k++] = i;
     if (pslot.empty()) pslot.assign(64, -1);
     HIP_TRY(c, c->d_pslot.upload(pslot));
-    std::vector<int> items;
+    std::vector<int> a2s((size_t)std::max(n, 1), 0);
+    for (size_t sl = 0; sl < pslot.size(); sl++)
+      if (pslot[sl] >= 0) a2s[pslot[sl]] = (int)sl;
+    HIP_TRY(c, c->d_a2s.upload(a2s));
+    HIP_TRY(c, c->d_prec.alloc(pslot.size()));
+    HIP_TRY(c, c->d_srec.alloc(pslot.size()));
+    HIP_TRY(c, c->d_ys.alloc(pslot.size()));
+    HIP_TRY(c, hipMemset(c->d_prec.p, 0, sizeof(double4) * pslot.size()));
+    HIP_TRY(c, hipMemset(c->d_srec.p, 0, sizeof(double4) * pslot.size()));
+    HIP_TRY(c, hipMemset(c->d_ys.p, 0, sizeof(double) * pslot.size()));
+    // Work items, heaviest first: diagonal and heavy x heavy tiles (two look-ups per pair), then heavy x H.  The
+    // launch is one round (every workgroup resident at once) and workgroup b starts on CU b mod (number of CUs), so
+    // the sorted tiles are dealt over the CUs in serpentine order: every CU gets the same mix of heavy and light ones.
+    std::vector<int> sorted;
+    for (int I = 0; I < nhb; I++) sorted.push_back(I | (I << 12));
     for (int I = 0; I < nhb; I++)
-      for (int J = I + 1; J < nhb; J++) items.push_back(I | (J << 12));
+      for (int J = I + 1; J < nhb; J++) sorted.push_back(I | (J << 12));
     for (int I = 0; I < nhb; I++)
-      for (int J = nhb; J < nhb + nlb; J++) items.push_back(I | (J << 12));
-    for (int I = 0; I < nhb; I++) items.push_back(I | (I << 12));
+      for (int J = nhb; J < nhb + nlb; J++) sorted.push_back(I | (J << 12));
+    std::vector<int> items(sorted.size());
+    {
+      const size_t width = (size_t)std::max(c->cus, 1);
+      for (size_t p = 0; p < sorted.size(); p++) {
+        const size_t row = p / width, col = p % width;
+        const size_t row_len = std::min(width, sorted.size() - row * width);
+        items[row * width + ((row & 1) ? row_len - 1 - col : col)] = sorted[p];
+      }
+    }
     if (items.empty()) items.push_back(0);
     HIP_TRY(c, c->d_db_items.upload(items));
     if (nh == 0) c->d_db_items.count = 0;
@@ -419,7 +445,7 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_born_fp.alloc(n));
   HIP_TRY(c, c->d_brw.alloc(n));
   HIP_TRY(c, c->d_e_atom.alloc(n));
-  HIP_TRY(c, c->d_gbf.alloc(4 * (size_t)n));
+  HIP_TRY(c, c->d_gbf.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_dbf.alloc(4 * (size_t)n));
   HIP_TRY(c, c->d_egb_part.alloc(c->P.egb_parts));
   HIP_TRY(c, c->d_components.alloc(4));
@@ -464,14 +490,11 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
 // one subtree per work slot (what a context starts with, and what an overflowed evaluation is repeated on)
 int upload_identity_packing(agbnp_hip_context* c) {
   const size_t nhp = std::max(c->nh, 1), nslots = (size_t)c->slot_cap;
-  std::vector<int> ident((size_t)kMaxItems * nslots + 8, 0);  // work items: item k of slot s at kMaxItems * s + k
-  for (size_t k = 0; k < nhp; k++) ident[(size_t)kMaxItems * k] = (int)k;
-  HIP_TRY(c, c->d_order.upload(ident));
-  {
-    std::vector<int> fslot(2 * nslots, 0);  // slot -> forest (identity), then the bookkeeping's forest times
-    for (size_t k = 0; k < nslots; k++) fslot[k] = (int)k;
-    HIP_TRY(c, c->d_fslot.upload(fslot));
-  }
+  std::vector<int> ident((size_t)kRowStride * nslots, 0);  // slot s: its one work item (subtree s) and the number 1
+  for (size_t k = 0; k < nslots; k++) ident[(size_t)kRowStride * k] = (int)std::min(k, nhp - 1), ident[(size_t)kRowStride * k + kMaxItems] = 1;
+  HIP_TRY(c, c->d_rows.upload(ident));
+  HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
+  HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
   // [slots+3] how often a packed forest has overflowed so far (kept)
   std::vector<int> forest(nslots + 3);
@@ -878,39 +901,42 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* c, int* indices, int
 unsigned agbnp_hip_generation(const agbnp_hip_context* c) { return c ? c->generation : 0u; }
 
 // ---- diagnostic entry points (not part of include/agbnp_hip.h; used by scripts/ only) ---------------------------------
-// the forest packing as the device holds it: order[] (work items), forest_start[0..nforests], and the per-subtree shapes
+// the forest packing as the device holds it, in WORK-SLOT order: the items of slot s at forest_start[s] .. forest_start[s+1]),
+// and the per-subtree shapes
 int agbnp_debug_get_packing(agbnp_hip_context* c, int* order, int order_cap, int* forest_start, int start_cap, int* nforests, int* sizes) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   int nf = 0;
   HIP_TRY(c, hipMemcpy(&nf, c->d_forest.p + c->slot_cap + 1, sizeof(int), hipMemcpyDeviceToHost));
+  nf = std::min(nf, c->slot_cap);
   *nforests = nf;
-  HIP_TRY(c, hipMemcpy(forest_start, c->d_forest.p, sizeof(int) * std::min(start_cap, nf + 1), hipMemcpyDeviceToHost));
-  {  // compact form for the caller: the items of forest f at forest_start[f] .. forest_start[f+1])
-    std::vector<int> dev(c->d_order.count);
-    HIP_TRY(c, hipMemcpy(dev.data(), c->d_order.p, sizeof(int) * dev.size(), hipMemcpyDeviceToHost));
-    for (int f = 0; f < nf && f + 1 < start_cap; f++)
-      for (int k = forest_start[f]; k < forest_start[f + 1] && k < order_cap; k++) order[k] = dev[(size_t)kMaxItems * f + (k - forest_start[f])];
+  std::vector<int> rows(c->d_rows.count);
+  HIP_TRY(c, hipMemcpy(rows.data(), c->d_rows.p, sizeof(int) * rows.size(), hipMemcpyDeviceToHost));
+  int run = 0;
+  for (int s = 0; s < nf && s + 1 < start_cap; s++) {
+    forest_start[s] = run;
+    for (int k = 0; k < rows[(size_t)kRowStride * s + kMaxItems] && run < order_cap; k++) order[run++] = rows[(size_t)kRowStride * s + k];
+    forest_start[s + 1] = run;
   }
   if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->d_sizes.p, sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
   return AGBNP_HIP_OK;
 }
-// replaces the packing and (freeze != 0) stops the bookkeeping from planning new ones
+// replaces the packing (same form) and (freeze != 0) stops the bookkeeping from planning new ones
 int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, const int* forest_start, int nforests, int freeze) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   if (order) {
-    std::vector<int> dev(c->d_order.count, 0);
-    for (int f = 0; f < nforests; f++)
-      for (int k = forest_start[f]; k < forest_start[f + 1] && k < norder; k++) dev[(size_t)kMaxItems * f + (k - forest_start[f])] = order[k];
-    HIP_TRY(c, hipMemcpy(c->d_order.p, dev.data(), sizeof(int) * dev.size(), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_forest.p, forest_start, sizeof(int) * (nforests + 1), hipMemcpyHostToDevice));
+    if (nforests > c->slot_cap) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_debug_set_packing: more forests than work slots");
+    std::vector<int> rows(c->d_rows.count, 0);
+    for (int s = 0; s < nforests; s++) {
+      const int count = std::min(forest_start[s + 1] - forest_start[s], (int)kMaxItems);
+      rows[(size_t)kRowStride * s + kMaxItems] = count;
+      for (int k = 0; k < count && forest_start[s] + k < norder; k++) rows[(size_t)kRowStride * s + k] = order[forest_start[s] + k];
+    }
+    HIP_TRY(c, hipMemcpy(c->d_rows.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
-    std::vector<int> ident(c->slot_cap);
-    for (int k = 0; k < c->slot_cap; k++) ident[k] = k;
-    HIP_TRY(c, hipMemcpy(c->d_fslot.p, ident.data(), sizeof(int) * ident.size(), hipMemcpyHostToDevice));
   }
   c->P.pack_enabled = freeze ? 3 : c->P.pack_enabled;  // 3: the bookkeeping keeps its statistics but writes no packing
   return AGBNP_HIP_OK;

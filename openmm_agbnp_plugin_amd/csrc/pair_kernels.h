@@ -32,6 +32,12 @@ struct PairArgs {
   double4* aposq;          // [n] {x,y,z,q}
   const int* pslot;        // [nslots] pair order: heavy atoms, padding (-1) to a block of 64, hydrogens, padding
   int nslots, nhb;         // slots (multiple of 64), heavy blocks
+  const int* a2s;          // [n] slot of an atom in pair order (inverse of pslot)
+  double4* prec;           // [nslots] pair-order record written by k_prep: {x, y, z, types | validity} (low word: screened
+                           // type | screener type << 16, high word >= 0 for a real atom): what a Born / chain-rule tile
+                           // needs of a slot comes in ONE load, with no slot -> atom indirection in front of it
+  double4* srec;           // [nslots] {B, f', brw, q} by slot, published by the GB stage's diagonal tiles for the chain rule
+  double* ys;              // [nslots] the GB stage's Y sums by slot (atomic sums)
   double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
   double* abox;            // [ceil(n/64)][6] the same for the 64-atom blocks in ATOM order (GB tiles; fast mode only)
   // Pair range.  Reference semantics: the descreening stages reach as far as the tables (2 nm), GB has no limit.
@@ -46,14 +52,16 @@ struct PairArgs {
   double *sv_vdw, *sv_large;  // [nh] self volumes (enlarged radii: diagnostic)
   double* epart;           // [2nh]
   int2* sizes;             // [nh] {nodes, local atoms} per subtree, summed up by the tree kernel
-  int* order;              // [kMaxItems * slots] work items (subtree | part << 24 | (parts-1) << 26) of the NEXT evaluation: item k of slot s at kMaxItems * s + k
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
   int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
-  int* forest_of_slot;     // [slots] which forest work slot s builds: slot s runs on CU s mod (number of CUs), so the
-                           // bookkeeping deals the forests, sorted by predicted time, over the CUs in serpentine order
-  int* forest_time;        // [slots] predicted time of every forest (scratch of the bookkeeping)
+  int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k
+  int* forest_time;        // [slots + 1] predicted time of every forest (packing_role -> dealing_role), then: are they there
+  int* rows;               // [kRowStride * slots] the work items of the NEXT evaluation in WORK-SLOT order (what the tree kernel
+                           // reads: item k of slot s at kRowStride * s + k, their number at kRowStride * s + kMaxItems).  Slot s
+                           // runs on CU s mod (number of CUs), so the bookkeeping ranks the forests by predicted time and deals
+                           // them over the CUs in serpentine order
   int ncus;                // CUs of the device
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
@@ -64,7 +72,7 @@ struct PairArgs {
   // ---- pair-stage intermediates
   double* born_part;       // [n] sum_j s_j Q (atomic sums of the tiles)
   double *born, *born_fp, *brw, *e_atom;  // [n]
-  double *gb_fx, *gb_fy, *gb_fz, *gb_y;   // [n] GB direct force and Y (atomic sums of the symmetric tiles)
+  double *gb_fx, *gb_fy, *gb_fz;          // [n] GB direct force (atomic sums of the symmetric tiles); Y goes to ys
   const int* gb_items;     // [gb_items_count] tiles of k_gb_tiles: I | J<<12 (64-atom blocks, atom order, I <= J)
   int gb_items_count;
   const int* db_items;     // [db_items_count] tiles of k_born_tiles / k_dborn_tiles, same encoding over blocks of pair-order slots

@@ -29,6 +29,38 @@
 
 namespace agbnp {
 
+// Diagnostic build only (-DAGBNP_PAIR_STAMPS): wall-clock stamps (100 MHz) of every workgroup of the three pair
+// kernels: [0] entry, [1] records in LDS, [2] walk done, [3] sums handed to the atomics, [4] HW_ID, [5] XCC_ID,
+// [6] item, [7..11] finer stamps of the prologue.  Read back with agbnp_debug_pair_log (scripts/pair_timeline.py).  Never compiled into the product library.
+#ifdef AGBNP_PAIR_STAMPS
+constexpr int kPairLogSlots = 4096;
+__device__ unsigned long long g_pair_log[3][kPairLogSlots][12];
+#define PAIR_STAMP(kern, idx)                                                                                        \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[kern][blockIdx.x][idx] = wall_clock64();          \
+  } while (0)
+#define PAIR_STAMP_WAIT(kern, idx, what)                                                                            \
+  do {                                                                                                               \
+    asm volatile("s_waitcnt " what ::: "memory");                                                                    \
+    PAIR_STAMP(kern, idx);                                                                                           \
+  } while (0)
+#define PAIR_STAMP_WHERE(kern, item)                                                                                 \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) {                                                            \
+      unsigned xcc__ = 0, hw__ = 0;                                                                                  \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                                          \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                                            \
+      g_pair_log[kern][blockIdx.x][4] = hw__;                                                                        \
+      g_pair_log[kern][blockIdx.x][5] = xcc__;                                                                       \
+      g_pair_log[kern][blockIdx.x][6] = (unsigned)(item);                                                            \
+    }                                                                                                                \
+  } while (0)
+#else
+#define PAIR_STAMP(kern, idx)
+#define PAIR_STAMP_WAIT(kern, idx, what)
+#define PAIR_STAMP_WHERE(kern, item)
+#endif
+
 // ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, z_k = y2_k*dr^2/6}) -------------------
 // Natural cubic spline of the reference (AGBNPUtils.h:104-115 -> SplineFitter): on interval k, with t in [0,1),
 //   S = (1-t) y_k + t y_k+1 + ((1-t)^3 - (1-t)) z_k + (t^3 - t) z_k+1
@@ -59,6 +91,29 @@ __device__ __forceinline__ void spline_value_deriv(const double2* __restrict__ t
   const SplineCubic c = spline_cubic(tab, base, d);
   val = fma(fma(fma(c.c3, c.t, c.c2), c.t, c.c1), c.t, c.c0);
   der = fma(fma(3.0 * c.c3, c.t, 2.0 * c.c2), c.t, c.c1) * ((kI4Nodes - 1) / kI4MaxA);
+}
+
+// The I4 tables go from memory to LDS in batches of four independent loads per thread: every load of a batch is in
+// flight before the first is waited for (a plain copy loop waits for each load before it issues the next: one memory
+// round trip per 256 entries at the start of every tile).
+struct LutBatch {
+  double2 v[4];
+};
+__device__ __forceinline__ LutBatch lut_fetch(const double2* __restrict__ lut, int lut_entries, int base) {
+  LutBatch b;
+#pragma unroll
+  for (int r = 0; r < 4; r++) b.v[r] = lut[min(base + (int)threadIdx.x + 256 * r, lut_entries - 1)];
+  return b;
+}
+__device__ __forceinline__ void lut_store(double2* __restrict__ s_lut, const LutBatch& b, int lut_entries, int base) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int t = base + (int)threadIdx.x + 256 * r;
+    if (t < lut_entries) s_lut[t] = b.v[r];
+  }
+}
+__device__ __forceinline__ void lut_copy_rest(double2* __restrict__ s_lut, const double2* __restrict__ lut, int lut_entries) {
+  for (int base = 1024; base < lut_entries; base += 1024) lut_store(s_lut, lut_fetch(lut, lut_entries, base), lut_entries, base);
 }
 
 __device__ __forceinline__ void hbm_add(double* p, double v) {  // global_atomic_add_f64
@@ -129,10 +184,16 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     // bounding box of every block of 64 slots in pair order (one wave each) for the tile culling of the
     // chain-rule stage; padding slots are neutral
     const int a = P.pslot[i];
-    double lo[3], hi[3];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    int2 sm = make_int2(0, 0);
+    if (a >= 0) sx = P.pos[3 * a], sy = P.pos[3 * a + 1], sz = P.pos[3 * a + 2], sm = P.ameta[a];
+    // the slot's record for the range-limited stages (a padding slot keeps a harmless position and says so)
+    P.prec[i] = make_double4(sx, sy, sz, __hiloint2double(a >= 0 ? 0 : -1, sm.x | ((sm.y & 0x7fff) << 16)));
+    P.ys[i] = 0.0;  // GB Y sums arrive through atomics
+    double lo[3] = {sx, sy, sz}, hi[3] = {sx, sy, sz};
     for (int d = 0; d < 3; d++) {
-      lo[d] = a >= 0 ? P.pos[3 * a + d] : 1e30;
-      hi[d] = a >= 0 ? lo[d] : -1e30;
+      lo[d] = a >= 0 ? lo[d] : 1e30;
+      hi[d] = a >= 0 ? hi[d] : -1e30;
     }
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; d++) {
@@ -169,7 +230,6 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   P.gb_fx[i] = 0.0;  // GB sums arrive through atomics
   P.gb_fy[i] = 0.0;
   P.gb_fz[i] = 0.0;
-  P.gb_y[i] = 0.0;
   P.born_part[i] = 0.0;  // Born sums and chain-rule sums arrive through atomics too
   P.db_fx[i] = 0.0;
   P.db_fy[i] = 0.0;
@@ -314,14 +374,46 @@ __device__ __forceinline__ bool evaluation_overflowed(const int* __restrict__ st
 // A forest that overflows anyway (kStatPackOverflow) makes the host repeat the evaluation on the one-subtree-per-slot
 // packing written here, and every such event lowers the capacities assumed here by 15 % for good (pack_state);
 // after six of them packing stays off.
-__device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
+// The bookkeeping is serial in nature (two sorts and a packing) and sits on ONE workgroup that shares its CU with the
+// host kernel's tiles: every dependent LDS round trip costs it 0.2-0.4 us there, ~22 us in all on 1dwc, and a host kernel
+// cannot end before its role does.  So it comes in two halves that each hide underneath a launch with time to spare:
+//   packing_role  (first workgroup of the GB launch): subtree shapes -> work items -> forests (sorted by weight), the
+//                 forests' predicted times;
+//   dealing_role  (second workgroup of the chain-rule launch): forests ranked by predicted time -> work slots, every
+//                 forest's items written into its slot's row.
+// The shapes are fetched once, sixteen loads per thread in flight together, and packed into LDS; the passes are rolled
+// loops over LDS without divisions (at most four parts, at most eight places per forest).
+__device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes) {
   const int t = threadIdx.x;
-  constexpr int kBins = 512, kBatch = 8;
+  constexpr int kBins = 512, kBatch = 16;
   constexpr unsigned kUnit = 1024;
   unsigned long long* comb = reinterpret_cast<unsigned long long*>(scratch);  // [kBins] count << 32 | weight
   unsigned long long* part = comb + kBins;                                       // [4]
   int* imax = reinterpret_cast<int*>(part + 4);                                  // [24]
   static_assert(sizeof(unsigned long long) * (kBins + 4) + sizeof(int) * 24 <= kRoleScratchBytes, "role scratch");
+  // the rest of the lent LDS: [nh] subtree shapes (nodes << 9 | local atoms) if they leave room for as many times, then
+  // the predicted times of the forests
+  const int lent = (scratch_bytes - (int)kRoleScratchBytes) / (int)sizeof(int);
+  const bool shapes_in_lds = 2 * P.nh <= lent;
+  int* lds_shape = reinterpret_cast<int*>(scratch + kRoleScratchBytes);
+  int* lds_time = lds_shape + (shapes_in_lds ? P.nh : 0);
+  const int lds_forests = lent - (shapes_in_lds ? P.nh : 0);
+  if (shapes_in_lds) {
+#pragma unroll 1
+    for (int base = 0; base < P.nh; base += 256 * kBatch) {
+      int2 sz[kBatch];
+#pragma unroll
+      for (int b = 0; b < kBatch; b++) sz[b] = P.sizes[min(base + b * 256 + t, P.nh - 1)];  // (clamped, unconditional: all in flight at once)
+#pragma unroll
+      for (int b = 0; b < kBatch; b++)
+        if (base + b * 256 + t < P.nh) lds_shape[base + b * 256 + t] = (sz[b].x << 9) | sz[b].y;
+    }
+  }
+  auto shape = [&](int h) {
+    if (!shapes_in_lds) return P.sizes[h];
+    const int v = lds_shape[h];
+    return make_int2(v >> 9, v & 511);
+  };
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
   const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
   const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0);
@@ -334,36 +426,31 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   // as its slowest workgroup, and idle slots are free); with more subtrees than resident workgroups the extra items
   // crowd the forests of the others and the kernel gets slower (measured on 1dwc: 57 -> 59 us), so they stay whole.
   const bool roomy = 2 * P.nh <= P.tree_slots;
-  const int max_parts = !pack ? 1 : (roomy ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : P.split_big);
+  const int max_parts = !pack ? 1 : (roomy ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : min(P.split_big, 4));
   const int split_nodes = roomy ? 48 : (int)((float)P.split_permille * 0.001f * share * (float)P.tree_node_cap);
-  auto parts_of = [&](int2 sz) { return min(max_parts, 1 + sz.x / split_nodes); };
+  auto parts_of = [&](int2 sz) {  // min(max_parts, 1 + nodes / split_nodes), max_parts <= 4
+    return min(max_parts, 1 + (sz.x >= split_nodes ? 1 : 0) + (sz.x >= 2 * split_nodes ? 1 : 0) + (sz.x >= 3 * split_nodes ? 1 : 0));
+  };
+  auto inv_parts = [&](int parts) { return parts == 1 ? 1.0f : parts == 2 ? 0.5f : parts == 3 ? (1.0f / 3.0f) : 0.25f; };
   auto weight = [&](int2 sz, int parts) -> unsigned {  // of one work item of the subtree, 128..2047
     const int l2 = max(sz.y - 1, 0);
-    const float nodes = (float)(1 + l2) + (float)(max(sz.x - 1 - l2, 0) + parts - 1) / (float)parts;
+    const float nodes = (float)(1 + l2) + (float)(max(sz.x - 1 - l2, 0) + parts - 1) * inv_parts(parts);
     const float w = fmaxf(fmaxf(nodes * inv_tn, (float)sz.y * inv_ta), (float)(kUnit / 8));
     return (unsigned)fminf(w, 2047.0f);
   };
   __syncthreads();
   int tot = 0, mx = 0, ma = 0;
-  for (int base = 0; base < P.nh; base += 256 * kBatch) {
-    int2 sz[kBatch];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {  // independent loads first, then the (slow) LDS atomics
-      const int h = base + b * 256 + t;
-      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
-    }
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      if (sz[b].x >= 0) {
-        tot += sz[b].x;
-        mx = sz[b].x > mx ? sz[b].x : mx;
-        ma = sz[b].y > ma ? sz[b].y : ma;
-        const int parts = parts_of(sz[b]);
-        const unsigned w = weight(sz[b], parts);
-        atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
-      }
-    }
+#pragma unroll 1
+  for (int h = t; h < P.nh; h += 256) {
+    const int2 sz = shape(h);
+    tot += sz.x;
+    mx = max(mx, sz.x);
+    ma = max(ma, sz.y);
+    const int parts = parts_of(sz);
+    const unsigned w = weight(sz, parts);
+    atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
   }
+  PAIR_STAMP(1, 7);
   for (int off = 32; off > 0; off >>= 1) {
     tot += __shfl_xor(tot, off, 64);
     mx = max(mx, __shfl_xor(mx, off, 64));
@@ -441,71 +528,107 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
     }
     return f < nf ? nab + npair + small_start(f - nab) : nitems;
   };
+  PAIR_STAMP(1, 8);
   if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
+#pragma unroll 1
   for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
-  for (int f = t; f < nf; f += 256) P.forest_time[f] = 0;
-  __syncthreads();  // (the barrier waits for this workgroup's stores; the adds below execute in the same L2)
+  // (the forests are ranked by predicted time when the times fit the lent LDS: always, short of ~3000 forests)
+  const bool rank_by_time = nf <= lds_forests;
+  if (rank_by_time)
+    for (int f = t; f < nf; f += 256) lds_time[f] = 0;
+  __syncthreads();
   if (t == 0) {
     P.nforests[0] = nf;
     P.status[kStatForests] = nf;
+    P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;  // (word behind the times: are they there)
   }
+  PAIR_STAMP(1, 9);
   // sorted order -> place inside the forests
-  for (int base = 0; base < P.nh; base += 256 * kBatch) {
-    int2 sz[kBatch];
+#pragma unroll 1
+  for (int h = t; h < P.nh; h += 256) {
+    const int2 sz = shape(h);
+    const int parts = parts_of(sz);
+    const unsigned w = weight(sz, parts);
+    const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+    // predicted time of a work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom, 1.6 per
+    // root; units of 0.01 us)
+    const int l2 = max(sz.y - 1, 0);
+    const int tm = 9 * (1 + l2 + (int)((float)max(sz.x - 1 - l2, 0) * inv_parts(parts))) + 34 * sz.y + 160;
+#pragma unroll 1
+    for (int part = 0; part < parts; part++) {
+      const int pos = (int)(v >> 32) + part;  // position in descending weight order
+      int forest, place;                      // the item is number `place` of forest `forest`
+      if (pos < nab) {
+        forest = pos;  // a forest of its own, or the leader of a class-B forest
+        place = 0;
+      } else if (pos >= nitems - npair) {
+        forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
+        place = 1;
+      } else {
+        const int k = pos - nab;
+        int r = 0;  // k / fs: the serpentine round, at most kMaxItems - 1
 #pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      const int h = base + b * 256 + t;
-      sz[b] = h < P.nh ? P.sizes[h] : make_int2(-1, 0);
-    }
-#pragma unroll
-    for (int b = 0; b < kBatch; b++) {
-      if (sz[b].x >= 0) {
-        const int parts = parts_of(sz[b]);
-        const unsigned w = weight(sz[b], parts);
-        const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
-        for (int part = 0; part < parts; part++) {
-          const int pos = (int)(v >> 32) + part;  // position in descending weight order
-          int forest, place;                      // the item is number `place` of forest `forest`
-          if (pos < nab) {
-            forest = pos;  // a forest of its own, or the leader of a class-B forest
-            place = 0;
-          } else if (pos >= nitems - npair) {
-            forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
-            place = 1;
-          } else {
-            const int k = pos - nab, r = k / fs, idx = k - r * fs;
-            forest = nab + ((r & 1) ? fs - 1 - idx : idx);
-            place = r;
-          }
-          // fixed stride per work slot: a tree workgroup fetches its items and its forest_start pair in ONE round trip
-          P.order[kMaxItems * forest + place] = (base + b * 256 + t) | (part << 24) | ((parts - 1) << 26);
-          // predicted time of the work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom,
-          // 1.6 per root; units of 0.01 us)
-          const int l2 = max(sz[b].y - 1, 0);
-          atomicAdd(&P.forest_time[forest], 9 * (1 + l2 + max(sz[b].x - 1 - l2, 0) / parts) + 34 * sz[b].y + 160);
-        }
+        for (int q = 1; q < kMaxItems; q++) r += k >= q * fs ? 1 : 0;
+        const int idx = k - r * fs;
+        forest = nab + ((r & 1) ? fs - 1 - idx : idx);
+        place = r;
       }
+      P.order[kMaxItems * forest + place] = h | (part << 24) | ((parts - 1) << 26);
+      if (rank_by_time) atomicAdd(&lds_time[forest], tm);
     }
   }
-  // ---- forests -> work slots.  Work slot s runs on CU s mod ncus (observed: the dispatcher deals workgroups round-robin
-  // over the CUs), and a CU's workgroups slow each other down, so the forests are ranked by predicted time (descending,
-  // histogram sort) and dealt over the CUs in serpentine order: row 0 left to right, row 1 right to left, ...
-  __syncthreads();  // (waits for this workgroup's adds; they executed in L2, where the agent-scope loads below read)
+  PAIR_STAMP(1, 10);
+  __syncthreads();
+  if (rank_by_time)
+    for (int f = t; f < nf; f += 256) P.forest_time[f] = lds_time[f];
+}
+
+// Second half.  Work slot s runs on CU s mod ncus (observed: the dispatcher deals workgroups round-robin over the CUs),
+// and a CU's workgroups slow each other down, so the forests are ranked by predicted time (descending, histogram sort)
+// and dealt over the CUs in serpentine order: row 0 left to right, row 1 right to left, ...  A forest's items go into
+// the row of its work slot (fixed stride: a tree workgroup fetches its items and their number in ONE round trip, with
+// no slot -> forest indirection in front of it).
+__device__ void dealing_role(const PairArgs& P, char* scratch, int scratch_bytes) {
+  const int t = threadIdx.x;
+  constexpr int kBins = 512;
+  unsigned long long* comb = reinterpret_cast<unsigned long long*>(scratch);  // [kBins]
+  unsigned long long* part = comb + kBins;                                       // [4]
+  int* lds_time = reinterpret_cast<int*>(scratch + kRoleScratchBytes);          // [nf]
+  const int lent = (scratch_bytes - (int)kRoleScratchBytes) / (int)sizeof(int);
+  if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
+  const int nf = min(P.nforests[0], P.tree_slot_cap);
+  const bool ranked = P.forest_time[P.tree_slot_cap] != 0 && nf <= lent;
+  auto hand_over = [&](int f, int slot) {
+    const int2 se = make_int2(P.forest_start[f], P.forest_start[f + 1]);
+    const int4* src = reinterpret_cast<const int4*>(P.order + (size_t)kMaxItems * f);
+    const int4 lo = src[0], hi = src[1];
+    int4* dst = reinterpret_cast<int4*>(P.rows + (size_t)kRowStride * slot);
+    dst[0] = lo, dst[1] = hi;
+    dst[2] = make_int4(se.y - se.x, 0, 0, 0);
+  };
+  static_assert(kMaxItems == 8 && kRowStride >= kMaxItems + 4, "two 16-byte words of items, then the word with their number");
+  if (!ranked) {  // as they come
+#pragma unroll 1
+    for (int f = t; f < nf; f += 256) hand_over(f, f);
+    return;
+  }
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
+  {  // the times: eight loads per thread in flight together
+    constexpr int kBatch = 8;
+#pragma unroll 1
+    for (int base = 0; base < nf; base += 256 * kBatch) {
+      int tm[kBatch];
+#pragma unroll
+      for (int b = 0; b < kBatch; b++) tm[b] = P.forest_time[min(base + b * 256 + t, nf - 1)];
+#pragma unroll
+      for (int b = 0; b < kBatch; b++)
+        if (base + b * 256 + t < nf) lds_time[base + b * 256 + t] = tm[b];
+    }
+  }
   __syncthreads();
   auto time_bin = [&](int tm) { return kBins - 1 - min(kBins - 1, tm >> 4); };
-  constexpr int kFB = 8;  // forests per thread and trip, loads in flight together
-  for (int fb = 0; fb < nf; fb += 256 * kFB) {
-    int tm[kFB];
-#pragma unroll
-    for (int b = 0; b < kFB; b++) {
-      const int f = fb + b * 256 + t;
-      tm[b] = f < nf ? __hip_atomic_load(&P.forest_time[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-    }
-#pragma unroll
-    for (int b = 0; b < kFB; b++)
-      if (tm[b] >= 0) atomicAdd(&comb[time_bin(tm[b])], 1ull);
-  }
+#pragma unroll 1
+  for (int f = t; f < nf; f += 256) atomicAdd(&comb[time_bin(lds_time[f])], 1ull);
   __syncthreads();
   {
     const unsigned long long c0 = comb[2 * t], c1 = comb[2 * t + 1];
@@ -525,21 +648,12 @@ __device__ void bookkeeping_role(const PairArgs& P, char* scratch) {
   }
   __syncthreads();
   const int ncu = max(P.ncus, 1), last_row = nf / ncu, last_width = nf - last_row * ncu;
-  for (int fb = 0; fb < nf; fb += 256 * kFB) {
-    int tm[kFB];
-#pragma unroll
-    for (int b = 0; b < kFB; b++) {
-      const int f = fb + b * 256 + t;
-      tm[b] = f < nf ? __hip_atomic_load(&P.forest_time[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-    }
-#pragma unroll
-    for (int b = 0; b < kFB; b++) {
-      if (tm[b] < 0) continue;
-      const int r = (int)atomicAdd(&comb[time_bin(tm[b])], 1ull);  // rank by descending predicted time
-      const int q = r / ncu, p = r - q * ncu;
-      const int width = q < last_row ? ncu : last_width;
-      P.forest_of_slot[q * ncu + ((q & 1) ? width - 1 - p : p)] = fb + b * 256 + t;
-    }
+#pragma unroll 1
+  for (int f = t; f < nf; f += 256) {
+    const int r = (int)atomicAdd(&comb[time_bin(lds_time[f])], 1ull);  // rank by descending predicted time
+    const int q = r / ncu, p = r - q * ncu;
+    const int width = q < last_row ? ncu : last_width;
+    hand_over(f, q * ncu + ((q & 1) ? width - 1 - p : p));
   }
 }
 
@@ -595,6 +709,11 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
       return;
     }
   }
+  PAIR_STAMP_WHERE(1, I0 | (J << 12) | kGbStripFlag);
+  // the Y sums leave by pair-order slot (the chain-rule stage reads them so): the wave that will add them asks for
+  // the slots of its three blocks now
+  // (unconditional loads: a choice here would have to wait for them)
+  const int ysa = P.a2s[min(64 * I0 + lane, n - 1)], ysc = P.a2s[min(64 * I0 + 64 + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];
   if (wave < 3) {  // wave 0 prepares block J, waves 1 and 2 the two i blocks
     const int a = 64 * (wave == 0 ? J : I0 + wave - 1) + lane;
     const bool va = a < n;
@@ -614,6 +733,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
     }
   }
   __syncthreads();
+  PAIR_STAMP(1, 1);
   const int start = 16 * wave;  // the four waves take a quarter of the cyclic distances each
   const double2 axy = s_i[lane], azq = s_i[64 + lane], abc = s_i[128 + lane];
   const double2 cxy = s_i[192 + lane], czq = s_i[256 + lane], cbc = s_i[320 + lane];
@@ -665,6 +785,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   }
   const double kf = -2.0 * kDielFactor;
   __syncthreads();  // every wave is done with the records
+  PAIR_STAMP(1, 2);
   StripSums& S = *reinterpret_cast<StripSums*>(s_area);
   const int jslot = (lane + start + 16) & 63;  // whose sums the lane holds after the rotations
   S.red[wave][0][lane] = kf * fxa;
@@ -682,16 +803,17 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   e = wave_sum(e);
   if (lane == 0) s_e[wave] = e;
   __syncthreads();
-  // thread (wave q, lane l) adds quantity q of atom l of the three blocks: rows gb_fx, gb_fy, gb_fz, gb_y
+  // thread (wave q, lane l) adds quantity q of atom l of the three blocks: rows gb_fx, gb_fy, gb_fz by atom, Y by slot
   double* __restrict__ row = gb_rows + (size_t)wave * n;
   auto fold = [&](int r) { return (S.red[0][r][lane] + S.red[1][r][lane]) + (S.red[2][r][lane] + S.red[3][r][lane]); };
   const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
   const bool det = P.det != 0;  // deterministic mode: a tile's totals are rounded to the sums' quantum (device_math.h)
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (ia < n) hbm_add(&row[ia], quantize(fold(wave), qs, det));
-  if (ic < n) hbm_add(&row[ic], quantize(fold(4 + wave), qs, det));
-  if (j < n) hbm_add(&row[j], quantize(fold(8 + wave), qs, det));
+  if (ia < n) hbm_add(wave == 3 ? &P.ys[ysa] : &row[ia], quantize(fold(wave), qs, det));
+  if (ic < n) hbm_add(wave == 3 ? &P.ys[ysc] : &row[ic], quantize(fold(4 + wave), qs, det));
+  if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(fold(8 + wave), qs, det));
   if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
+  PAIR_STAMP(1, 3);
 }
 
 template <bool kCut>
@@ -705,10 +827,15 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   __shared__ __align__(16) char s_area[sizeof(StripSums)];
   static_assert(sizeof(StripSums) >= sizeof(TileSums) && sizeof(TileSums) >= kRoleScratchBytes, "the bookkeeping workgroup borrows the tile area");
   static_assert(sizeof(StripSums) >= sizeof(double2) * (3 * 128 + 6 * 64), "strip records fit the area of the sums");
-  // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): ~20 us of mostly
-  // serial work that hides underneath this launch, the longest of the pair stages
+  // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): mostly serial work that
+  // hides underneath this launch, the longest of the pair stages
   __shared__ double s_e[4];
-  if (blockIdx.x == 0) return bookkeeping_role(P, s_area);
+  if (blockIdx.x == 0) {
+    PAIR_STAMP(1, 0);
+    packing_role(P, s_area, (int)sizeof(StripSums));
+    PAIR_STAMP(1, 3);
+    return;
+  }
   static_assert(sizeof(TileSums) >= sizeof(double2) * (3 * 128 + 3 * 64), "records fit the area of the sums");
   double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over: entry m and m + 64 are atom 64 J + m
   double2* const s_zq = s_xy + 128;
@@ -719,6 +846,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
+  PAIR_STAMP(1, 0);
   if (item & kGbStripFlag) return gb_strip<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
   const bool diag = I == J;
   if (kCut && !diag) {  // fast mode: a tile whose two blocks are further apart than the cutoff has no pair to meet
@@ -732,6 +860,8 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
       return;
     }
   }
+  PAIR_STAMP_WHERE(1, item);
+  const int ysi = P.a2s[min(64 * I + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];  // (the Y sums leave by pair-order slot, see gb_strip)
   // Born radii from the finished descreening sums (every tile recomputes them for its 128 atoms: a few dozen
   // flops per atom against 4096 pair evaluations, and one kernel launch less per evaluation):
   // wave 0 prepares block J, wave 1 block I
@@ -754,14 +884,17 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
         // the diagonal tile of a block publishes the per-atom results exactly once:
         // B_i, f'_i, vdW energy + GB self energy, brw_i (ReferenceAGBNPKernels.cpp:477,513-533)
         const double bh = bra.br + kHBRadius, bh3 = bh * bh * bh, al = alpha[a];
+        const double brw_a = -(1. / (4. * kPi)) * 3. * al * bra.br * bra.br * bra.fp / (bh3 * bh);
         born[a] = bra.br;
         born_fp[a] = bra.fp;
         e_atom[a] = al / bh3 + kDielFactor * pa.w * pa.w * bra.inv_br;
-        brw[a] = -(1. / (4. * kPi)) * 3. * al * bra.br * bra.br * bra.fp / (bh3 * bh);
+        brw[a] = brw_a;
+        P.srec[ysi] = make_double4(bra.br, bra.fp, brw_a, pa.w);  // the chain-rule stage's copy, by slot (a = 64 I + lane here)
       }
     }
   }
   __syncthreads();
+  PAIR_STAMP(1, 1);
   // the four waves take a quarter of the cyclic distances each (diagonal tile: distances 1..32, 8 per wave)
   const int nsteps = diag ? 8 : 16;
   const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
@@ -808,6 +941,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   }
   const double kf = -2.0 * kDielFactor;
   __syncthreads();  // every wave is done with the records
+  PAIR_STAMP(1, 2);
   TileSums& s_sums = *reinterpret_cast<TileSums*>(s_area);
   {
     const double vi4[4] = {kf * fxi, kf * fyi, kf * fzi, yi}, vj4[4] = {kf * fxj, kf * fyj, kf * fzj, yj_acc};
@@ -816,14 +950,15 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   e = wave_sum(e);
   if (lane == 0) s_e[wave] = e;
   __syncthreads();
-  // thread (wave q, lane l) adds quantity q of atom l of block I and of block J: rows gb_fx, gb_fy, gb_fz, gb_y
+  // thread (wave q, lane l) adds quantity q of atom l of block I and of block J: rows gb_fx, gb_fy, gb_fz by atom, Y by slot
   double* __restrict__ row = gb_rows + (size_t)wave * n;
   const int i = 64 * I + lane, j = 64 * J + lane;
   const bool det = P.det != 0;
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (i < n) hbm_add(&row[i], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
-  if (j < n) hbm_add(&row[j], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
+  if (i < n) hbm_add(wave == 3 ? &P.ys[ysi] : &row[i], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
+  if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
   if (threadIdx.x == 0) egb_part[blockIdx.x - 1] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
+  PAIR_STAMP(1, 3);
 }
 
 // ---- descreening sums of the inverse Born radii, 64x64 tiles in "pair order" with range culling -------------
@@ -859,18 +994,36 @@ __device__ __forceinline__ void born_walk(double& sum_i, double& sum_j, const do
 
 __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
-                                                   const double* __restrict__ pos, const int2* __restrict__ ameta,
-                                                   const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
-                                                   const double2* __restrict__ lut, double* __restrict__ born_part, double range2, int det) {
+                                                   const double4* __restrict__ prec, const double* __restrict__ sv_vdw,
+                                                   const double* __restrict__ inv_vol_h, const double2* __restrict__ lut,
+                                                   double* __restrict__ born_part, double range2, int det) {
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
   __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
   __shared__ double s_red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PAIR_STAMP(0, 0);
   const int item = items[blockIdx.x];
+  PAIR_STAMP_WAIT(0, 7, "lgkmcnt(0)");  // kernel arguments and the item are here
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
   const bool both = J < nhb;  // heavy x heavy
+  // Everything the tile reads from memory is asked for here, before anything is waited for, so the workgroup's start
+  // is ONE round trip deep (records by slot: no slot -> atom indirection; a slot of a heavy block is the heavy atom
+  // itself, so its self volume comes straight from the tree's row).
+  const int islot = 64 * I + lane, jslot = 64 * J + lane;
+  const int ih = min(islot, nh - 1), jh = min(jslot, nh - 1);  // (clamped: the loads are unconditional, the choice comes after)
+  const double4 ri = prec[islot];
+  const double4 rj = prec[jslot];  // every wave asks; wave 0 puts block J into LDS
+  const double svi = sv_vdw[ih], ivi = inv_vol_h[ih], svj = sv_vdw[jh], ivj = inv_vol_h[jh];
+  const int a_out = pslot[wave == 0 ? islot : jslot];  // wave 0 adds the sums of block I, wave 1 those of block J: by atom
+  const LutBatch lut0 = lut_fetch(lut, lut_entries, 0);
+  PAIR_STAMP_WAIT(0, 8, "vmcnt(0)");  // everything has arrived
+  const double si = islot < nh ? svi * ivi : 0.0;
+  const double sj = jslot < nh ? svj * ivj : 0.0;
+  lut_store(s_lut, lut0, lut_entries, 0);
+  lut_copy_rest(s_lut, lut, lut_entries);
+  PAIR_STAMP_WAIT(0, 9, "vmcnt(0) lgkmcnt(0)");  // the tables are in LDS (this wave's part)
   if (!diag) {  // workgroup-uniform range test on the two bounding boxes
     double gap2 = 0.0;
     for (int d = 0; d < 3; d++) {
@@ -879,30 +1032,21 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
     }
     if (gap2 >= range2) return;
   }
-  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
-  auto scale_of = [&](int slot, bool valid) { return valid && slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0; };
+  PAIR_STAMP_WHERE(0, item);
   if (wave == 0) {
-    const int slot = 64 * J + lane;
-    const int aj = pslot[slot];
-    const bool vj = aj >= 0;
-    const int ac = vj ? aj : 0;
-    const int2 mj = ameta[ac];
-    s_xy[lane] = s_xy[lane + 64] = make_double2(pos[3 * ac], pos[3 * ac + 1]);
-    s_zs[lane] = s_zs[lane + 64] = make_double2(pos[3 * ac + 2], scale_of(slot, vj));
-    s_ty[lane] = s_ty[lane + 64] = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
+    s_xy[lane] = s_xy[lane + 64] = make_double2(rj.x, rj.y);
+    s_zs[lane] = s_zs[lane + 64] = make_double2(rj.z, sj);
+    s_ty[lane] = s_ty[lane + 64] = rj.w;
   }
   const int nsteps = diag ? 8 : 16;
   const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
-  const int islot = 64 * I + lane;
-  const int ai = pslot[islot];
-  const bool vi = ai >= 0;
-  const int aic = vi ? ai : 0;
-  const double xi = pos[3 * aic], yi = pos[3 * aic + 1], zi = pos[3 * aic + 2];
-  const double si = scale_of(islot, vi);
-  const int2 mi = ameta[aic];  // {screened type, screener type}: block I is always a heavy block
+  const bool vi = __double2hiint(ri.w) >= 0;
+  const double xi = ri.x, yi = ri.y, zi = ri.z;
+  const int2 mi = make_int2(__double2loint(ri.w) & 0xffff, __double2loint(ri.w) >> 16);  // {screened type, screener type}: block I is always a heavy block
   const int base = (lane + start) & 63;
   double sum_i = 0.0, sum_j = 0.0;
   __syncthreads();
+  PAIR_STAMP(0, 1);
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
     born_walk<true>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, mi.x * ntj, mi.y, nsteps,
@@ -912,11 +1056,13 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   s_red[wave][0][lane] = sum_i;
   s_red[wave][1][(lane + start + nsteps) & 63] = sum_j;  // whose sum the lane holds after the rotations
   __syncthreads();
+  PAIR_STAMP(0, 2);
   if (wave < 2) {  // wave 0 adds the sums of block I, wave 1 those of block J
     if (wave == 0 && !both) return;
-    const int a = wave == 0 ? ai : pslot[64 * J + lane];
+    const int a = a_out;
     if (a >= 0)
       hbm_add(&born_part[a], quantize((s_red[0][wave][lane] + s_red[1][wave][lane]) + (s_red[2][wave][lane] + s_red[3][wave][lane]), kQBorn, det != 0));
+    PAIR_STAMP(0, 3);
   }
 }
 
@@ -977,25 +1123,54 @@ __device__ __forceinline__ void dborn_walk(DbornLane& L, const double2* __restri
 
 __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, int lut_entries, const int* __restrict__ items,
                                                     const int* __restrict__ pslot, const double* __restrict__ pbox,
-                                                    const double4* __restrict__ aposq, const int2* __restrict__ ameta,
-                                                    const double* __restrict__ born, const double* __restrict__ born_fp,
-                                                    const double* __restrict__ brw, const double* __restrict__ gb_y,
-                                                    const double* __restrict__ sv_vdw, const double* __restrict__ inv_vol_h,
-                                                    int nh, const double2* __restrict__ lut, double* __restrict__ db_rows,
-                                                    PairArgs P, double* __restrict__ energy_out,
-                                                    double* __restrict__ components) {
+                                                    const double4* __restrict__ prec, const double4* __restrict__ srec,
+                                                    const double* __restrict__ ys, const double* __restrict__ sv_vdw,
+                                                    const double* __restrict__ inv_vol_h, int nh, const double2* __restrict__ lut,
+                                                    double* __restrict__ db_rows, PairArgs P, double* __restrict__ energy_out,
+                                                    double* __restrict__ components, int role_bytes) {
   // the first workgroup carries the energy sum (see above)
   extern __shared__ double2 s_lut[];
   if (blockIdx.x == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_lut));
+  if (blockIdx.x == 1) return dealing_role(P, reinterpret_cast<char*>(s_lut), role_bytes);  // second half of the bookkeeping
   // block J twice over (entry m and m + 64 are slot 64 J + m): {x, y}, {z, bw}, {s, types|validity}
   __shared__ double2 s_rec[3][128];
   // one workgroup = one tile; its four waves take a quarter of the cyclic distances each and share the j records
   // and the spline tables
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = items[blockIdx.x - 1];
+  PAIR_STAMP(2, 0);
+  const int item = items[blockIdx.x - 2];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   const bool diag = I == J;
   const bool both = J < nhb;  // heavy x heavy
+  // Everything the tile reads from memory is asked for here, before anything is waited for (see k_born_tiles): the
+  // slot's geometry and types (k_prep), {B, f', brw, q} and the finished Y sum (GB stage), the self volume (tree).
+  struct SlotData {
+    double4 r, g;
+    double y, sv, iv;
+  };
+  auto fetch = [&](int slot) {  // (unconditional loads, clamped: nothing is waited for in here)
+    SlotData d;
+    const int h = min(slot, nh - 1);
+    d.r = prec[slot];
+    d.g = srec[slot];
+    d.y = ys[slot];
+    d.sv = sv_vdw[h];
+    d.iv = inv_vol_h[h];
+    return d;
+  };
+  // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
+  // formed here from the finished GB sums instead of a per-atom kernel in between
+  auto weights = [&](const SlotData& d, bool slot_is_heavy) {
+    const double bru = -(1. / (4. * kPi)) * kDielFactor * (d.g.w * d.g.w + d.y * d.g.x) * d.g.y;
+    return make_double2(d.g.z + bru, slot_is_heavy ? d.sv * d.iv : 0.0);  // slot h of a heavy block is heavy atom h
+  };
+  const int islot = 64 * I + lane, jslot = 64 * J + lane;
+  const SlotData di = fetch(islot);
+  const SlotData dj = fetch(jslot);  // every wave asks; wave 0 puts block J into LDS
+  const int ai = pslot[islot], aj = pslot[jslot];  // the force rows are by atom
+  const LutBatch lut0 = lut_fetch(lut, lut_entries, 0);
+  lut_store(s_lut, lut0, lut_entries, 0);
+  lut_copy_rest(s_lut, lut, lut_entries);
   if (!diag) {  // workgroup-uniform range test on the two bounding boxes
     double gap2 = 0.0;
     for (int d = 0; d < 3; d++) {
@@ -1004,33 +1179,21 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
     }
     if (gap2 >= P.range2) return;
   }
-  for (int t = threadIdx.x; t < lut_entries; t += 256) s_lut[t] = lut[t];
-  // {bw, s} of an atom: bw = brw + bru with bru = -(1/4pi) k (q^2 + Y B) f' (ReferenceAGBNPKernels.cpp:534-542),
-  // formed here from the finished GB sums instead of a per-atom kernel in between
-  // (slot h of a heavy block is heavy atom h: its volume scaling factor comes straight from the tree's self volume)
-  auto weights = [&](int a, int slot, double q) {
-    const double bru = -(1. / (4. * kPi)) * kDielFactor * (q * q + gb_y[a] * born[a]) * born_fp[a];
-    return make_double2(brw[a] + bru, slot < nh ? sv_vdw[slot] * inv_vol_h[slot] : 0.0);
-  };
+  PAIR_STAMP_WHERE(2, item);
   if (wave == 0) {
-    const int aj = pslot[64 * J + lane];
-    const bool vj = aj >= 0;
-    const double4 pj = aposq[vj ? aj : 0];
-    const double2 wj = vj ? weights(aj, 64 * J + lane, pj.w) : make_double2(0.0, 0.0);
-    const int2 mj = ameta[vj ? aj : 0];
-    // low word: screened type | screener type << 16 (only read in heavy x heavy tiles); high word: >= 0 for a real atom
-    const double packed = __hiloint2double(vj ? 0 : -1, mj.x | ((mj.y & 0x7fff) << 16));
-    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(pj.x, pj.y);
-    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(pj.z, wj.x);
-    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, packed);
+    const bool vj = __double2hiint(dj.r.w) >= 0;
+    const double2 wj = vj ? weights(dj, jslot < nh) : make_double2(0.0, 0.0);
+    // .w of the record: low word screened type | screener type << 16 (only read in heavy x heavy tiles); high word >= 0 for a real atom
+    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(dj.r.x, dj.r.y);
+    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(dj.r.z, wj.x);
+    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, dj.r.w);
   }
   const int nsteps = diag ? 8 : 16;
   const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
-  const int ai = pslot[64 * I + lane];
-  const bool vi = ai >= 0;
-  const double4 pi = aposq[vi ? ai : 0];
-  const double2 wi = vi ? weights(ai, 64 * I + lane, pi.w) : make_double2(0.0, 0.0);
-  const int2 mi = ameta[vi ? ai : 0];  // {screened type, screener type}: block I is always a heavy block
+  const bool vi = __double2hiint(di.r.w) >= 0;
+  const double2 wi = vi ? weights(di, islot < nh) : make_double2(0.0, 0.0);
+  const int2 mi = make_int2(__double2loint(di.r.w) & 0xffff, __double2loint(di.r.w) >> 16);  // {screened type, screener type}: block I is always a heavy block
+  const double4 pi = di.r;
   DbornLane L;
   L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
   L.row = mi.x * ntj, L.tsr = mi.y;
@@ -1040,12 +1203,14 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   const double2* __restrict__ jzw = s_rec[1] + base;
   const double2* __restrict__ jsm = s_rec[2] + base;
   __syncthreads();
+  PAIR_STAMP(2, 1);
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
     dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj, P.range2);
   else
     dborn_walk<false>(L, s_lut, jxy, jzw, jsm, nsteps, -1, vi, true, ntj, P.range2);
   __syncthreads();  // every wave is done with the spline tables: their LDS now carries the sums of the four waves
+  PAIR_STAMP(2, 2);
   TileSums& s_sums = *reinterpret_cast<TileSums*>(s_lut);
   {
     const double vi4[4] = {L.fxi, L.fyi, L.fzi, L.wui}, vj4[4] = {L.fxj, L.fyj, L.fzj, L.wuj};
@@ -1058,8 +1223,8 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   const bool det = P.det != 0;
   const double qs = wave == 3 ? kQSum : kQGrad;
   if (vi) hbm_add(&row[wave == 3 ? 64 * I + lane : ai], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
-  const int aj = pslot[64 * J + lane];
   if (aj >= 0 && (both || wave < 3)) hbm_add(&row[wave == 3 ? 64 * J + lane : aj], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
+  PAIR_STAMP(2, 3);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1068,13 +1233,18 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
 //   block  nfb+1     bookkeeping for the NEXT evaluation: tree statistics and the largest-first subtree order
 
 __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double* __restrict__ force_out,
-                                                 double* __restrict__ energy_out, double* __restrict__ components) {
+                                                 double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
   // version 0 has no pair stages to carry the two single-workgroup roles: they are the first two workgroups here
-  extern __shared__ char s_role[];  // kRoleScratchBytes when version != 1
+  extern __shared__ char s_role[];  // role_bytes when version != 1
   int blk = blockIdx.x;
   if (version != 1) {
     if (blk == 0) return energy_role(P, version, energy_out, components, s_role);
-    if (blk == 1) return bookkeeping_role(P, s_role);
+    if (blk == 1) {  // both halves of the bookkeeping, one after the other
+      packing_role(P, s_role, role_bytes);
+      __threadfence();
+      __syncthreads();  // (the second half reads back what the first wrote)
+      return dealing_role(P, s_role, role_bytes);
+    }
     blk -= 2;
   }
   const int t = threadIdx.x;
@@ -1132,7 +1302,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
-                       (const double*)P.pbox, P.pos, P.ameta, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
+                       (const double*)P.pbox, (const double4*)P.prec, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
   if (P.fast)
@@ -1143,10 +1313,11 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
                        (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
-  // (+ 1: the energy workgroup; with no heavy atom there is no tile but the role still runs)
-  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 1), dim3(256), std::max(lds, sizeof(TileSums)), st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot, (const double*)P.pbox, (const double4*)P.aposq, P.ameta,
-                     (const double*)P.born, (const double*)P.born_fp, (const double*)P.brw, (const double*)P.gb_y,
-                     (const double*)P.sv_vdw, P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components);
+  // (+ 2: the energy workgroup and the dealing workgroup; with no heavy atom there is no tile but the roles still run)
+  const size_t db_lds = std::max(lds, sizeof(TileSums));
+  hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 2), dim3(256), db_lds, st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
+                     (const double*)P.pbox, (const double4*)P.prec, (const double4*)P.srec, (const double*)P.ys, (const double*)P.sv_vdw,
+                     P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components, (int)db_lds);
   AGBNP_CHECK_LAUNCH();
   return hipSuccess;
 }
@@ -1154,10 +1325,18 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl) {
   AGBNP_MARK(kKOutputs);
-  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), version == 1 ? 0 : kRoleScratchBytes, st, P, version, force_out, energy_out, components);
+  // (version 0: the roles' LDS, with room for the packed shapes of up to 12 k subtrees)
+  const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::min(std::max(P.nh, 1), 12288);
+  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), role_bytes, st, P, version, force_out, energy_out, components, role_bytes);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);
   return hipSuccess;
 }
 
 }  // namespace agbnp
+
+#ifdef AGBNP_PAIR_STAMPS
+extern "C" void agbnp_debug_pair_log(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(agbnp::g_pair_log), sizeof(agbnp::g_pair_log));
+}
+#endif

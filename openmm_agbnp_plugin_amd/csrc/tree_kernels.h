@@ -61,12 +61,11 @@ struct TreeArgs {
   double* hv;                  // [kHvRows][hstride]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
-  const int* order;            // [kMaxItems * slots] work items: item k of work slot s at kMaxItems * s + k
-  const int* packing;          // [slot_cap + 1] forest_start: work slot s builds order[packing[s] .. packing[s+1]);
+  const int* rows;             // [kRowStride * slots] work items: item k of work slot s at kRowStride * s + k, their number at + kMaxItems
+  const int* packing;          // [slot_cap + 1] forest_start (bookkeeping's own),
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
                                // pair stages run), [slot_cap + 2] the copy k_tree_cavity takes for THIS evaluation
   int slot_cap;
-  const int* forest_of_slot;   // [slot_cap] work slot -> forest (the bookkeeping balances the predicted time per CU)
   const unsigned long long* nbmask;  // [nhb][nhb * 64] level-2 neighbour masks from the k_prep launch (agbnp_common.h)
   int nhb;                     // blocks of 64 heavy atoms
   // pass 3 (pseudo-volume): nu_i = (W_i + U_i) / V_i (ReferenceAGBNPKernels.cpp:718-722,738-742), formed on the fly

@@ -117,18 +117,11 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   for (int slot = blockIdx.x; slot < nforests;) {
     int ticket = nforests;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
     do {
-    // which forest this slot builds (a scalar load), then one round trip: lanes 0..7 of every wave fetch the forest's
-    // work items, lanes 8 and 9 its forest_start pair
-    const int forest = A.forest_of_slot[slot];
+    // the slot's row of work items (written in slot order by the bookkeeping of the previous evaluation: no
+    // slot -> forest indirection in front of it): lanes 0..7 of every wave fetch one item each, lane 8 their number
     int my_item = 0;
-    {
-      const int lane = tid & 63;
-      if (lane < kMaxRoots)
-        my_item = A.order[(size_t)kMaxRoots * forest + lane];
-      else if (lane < kMaxRoots + 2)
-        my_item = A.forest_start()[forest + lane - kMaxRoots];
-    }
-    const int m = __builtin_amdgcn_readlane(my_item, kMaxRoots + 1) - __builtin_amdgcn_readlane(my_item, kMaxRoots);  // 1..kMaxRoots
+    if ((tid & 63) <= kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + (tid & 63)];  // (one instruction: two would be two round trips)
+    const int m = __builtin_amdgcn_readlane(my_item, kMaxRoots);  // 1..kMaxRoots
     int items[kMaxRoots];
 #pragma unroll
     for (int q = 0; q < kMaxRoots; q++) items[q] = __builtin_amdgcn_readlane(my_item, q);
