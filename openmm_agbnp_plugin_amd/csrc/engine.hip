@@ -490,7 +490,7 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
 // one subtree per work slot (what a context starts with, and what an overflowed evaluation is repeated on)
 int upload_identity_packing(agbnp_hip_context* c) {
   const size_t nhp = std::max(c->nh, 1), nslots = (size_t)c->slot_cap;
-  std::vector<int> ident((size_t)kRowStride * nslots, 0);  // slot s: its one work item (subtree s) and the number 1
+  std::vector<int> ident((size_t)kRowStride * nslots, -1);  // slot s: its one work item (subtree s), -1 = no item, and the number 1
   for (size_t k = 0; k < nslots; k++) ident[(size_t)kRowStride * k] = (int)std::min(k, nhp - 1), ident[(size_t)kRowStride * k + kMaxItems] = 1;
   HIP_TRY(c, c->d_rows.upload(ident));
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
@@ -929,7 +929,7 @@ int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, 
   HIP_TRY(c, hipDeviceSynchronize());
   if (order) {
     if (nforests > c->slot_cap) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_debug_set_packing: more forests than work slots");
-    std::vector<int> rows(c->d_rows.count, 0);
+    std::vector<int> rows(c->d_rows.count, -1);
     for (int s = 0; s < nforests; s++) {
       const int count = std::min(forest_start[s + 1] - forest_start[s], (int)kMaxItems);
       rows[(size_t)kRowStride * s + kMaxItems] = count;

@@ -601,10 +601,13 @@ __device__ void dealing_role(const PairArgs& P, char* scratch, int scratch_bytes
   auto hand_over = [&](int f, int slot) {
     const int2 se = make_int2(P.forest_start[f], P.forest_start[f + 1]);
     const int4* src = reinterpret_cast<const int4*>(P.order + (size_t)kMaxItems * f);
-    const int4 lo = src[0], hi = src[1];
+    int4 lo = src[0], hi = src[1];
+    const int m = se.y - se.x;  // -1 behind the forest's own items (the working copy may hold older ones)
+    lo.x = 0 < m ? lo.x : -1, lo.y = 1 < m ? lo.y : -1, lo.z = 2 < m ? lo.z : -1, lo.w = 3 < m ? lo.w : -1;
+    hi.x = 4 < m ? hi.x : -1, hi.y = 5 < m ? hi.y : -1, hi.z = 6 < m ? hi.z : -1, hi.w = 7 < m ? hi.w : -1;
     int4* dst = reinterpret_cast<int4*>(P.rows + (size_t)kRowStride * slot);
     dst[0] = lo, dst[1] = hi;
-    dst[2] = make_int4(se.y - se.x, 0, 0, 0);
+    dst[2] = make_int4(m, 0, 0, 0);
   };
   static_assert(kMaxItems == 8 && kRowStride >= kMaxItems + 4, "two 16-byte words of items, then the word with their number");
   if (!ranked) {  // as they come
