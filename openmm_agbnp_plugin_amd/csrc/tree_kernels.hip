@@ -100,6 +100,7 @@ __device__ __forceinline__ int next_forest(int tid, int* lds_word, int ticket) {
 // Waves per SIMD the compiler is asked to leave room for = workgroups per CU that the variant's LDS footprint allows
 // (one wave of a workgroup per SIMD): 5 for the 432-node store (<= 96 VGPRs), 4 for 512 nodes (<= 128), fewer beyond.
 constexpr int tree_waves_per_simd(int ncap, int bs) {
+  if (bs == 192) return ncap <= 512 ? 4 : 2;  // (three-wave workgroups: five per CU are 15 waves, at most four on a SIMD)
   return bs >= 256 ? (ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2)) : (ncap <= 192 ? 3 : 2);  // (one-wave workgroups: ~10 per CU for the small store)
 }
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     CSTAMP_FLUSH();
     } while (false);
     if (!queued) break;
-    slot = next_forest(tid, &s_next, ticket);
+    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
   }
 }
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     PSTAMP_FLUSH();
     } while (false);
     if (!queued) break;
-    slot = next_forest(tid, &s_next, ticket);
+    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
   }
 }
 

@@ -15,7 +15,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "openmm_agbnp_plugin_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DAGBNP_TREE_BLOCK=256", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DAGBNP_TREE_BLOCK=192", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only"]
 
 
 def demangle(names):
