@@ -269,6 +269,7 @@ void wire_args(agbnp_hip_context* c) {
   P.pslot = c->d_pslot.p;
   P.nslots = (int)c->d_pslot.count;
   P.nhb = (c->nh + 63) / 64;
+  P.cull_first = P.nslots / 64 > 96 ? 1 : 0;  // beyond ~6000 atoms most tiles are further apart than the tables reach
   P.db_items = c->d_db_items.p;
   P.db_items_count = (int)c->d_db_items.count;
   P.gx = c->hrow(kHvGx);

@@ -45,6 +45,7 @@ struct PairArgs {
   // every pair stage only meets pairs with r^2 < cutoff^2.
   double range2;           // squared reach of the Born / chain-rule stages: min(2 nm, cutoff)^2 in fast mode, else 4
   double gb_cut2;          // squared GB cutoff (fast mode) -- the GB kernel is compiled twice, this is read by the cut one
+  int cull_first;          // range-limited stages: 1 = a tile tests its bounding boxes before it asks for its data (large systems)
   int fast;                // 1 = fast mode
   int det;                 // 1 = deterministic mode (device_math.h)
   // ---- tree accumulators / outputs

@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
                                                    const int* __restrict__ pslot, const double* __restrict__ pbox,
                                                    const double4* __restrict__ prec, const double* __restrict__ sv_vdw,
                                                    const double* __restrict__ inv_vol_h, const double2* __restrict__ lut,
-                                                   double* __restrict__ born_part, double range2, int det) {
+                                                   double* __restrict__ born_part, double range2, int det, int cull_first) {
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
   __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
@@ -1014,6 +1014,18 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   // Everything the tile reads from memory is asked for here, before anything is waited for, so the workgroup's start
   // is ONE round trip deep (records by slot: no slot -> atom indirection; a slot of a heavy block is the heavy atom
   // itself, so its self volume comes straight from the tree's row).
+  auto out_of_range = [&]() {  // workgroup-uniform range test on the two bounding boxes
+    if (diag) return false;
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    return gap2 >= range2;
+  };
+  // (a large system culls most of its tiles: there the test comes first and a culled tile costs two scalar loads; a
+  // small one culls next to none: there the test waits until the tile's loads are on their way)
+  if (cull_first && out_of_range()) return;
   const int islot = 64 * I + lane, jslot = 64 * J + lane;
   const int ih = min(islot, nh - 1), jh = min(jslot, nh - 1);  // (clamped: the loads are unconditional, the choice comes after)
   const double4 ri = prec[islot];
@@ -1027,14 +1039,7 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   lut_store(s_lut, lut0, lut_entries, 0);
   lut_copy_rest(s_lut, lut, lut_entries);
   PAIR_STAMP_WAIT(0, 9, "vmcnt(0) lgkmcnt(0)");  // the tables are in LDS (this wave's part)
-  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
-    double gap2 = 0.0;
-    for (int d = 0; d < 3; d++) {
-      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
-      gap2 += g * g;
-    }
-    if (gap2 >= range2) return;
-  }
+  if (!cull_first && out_of_range()) return;
   PAIR_STAMP_WHERE(0, item);
   if (wave == 0) {
     s_xy[lane] = s_xy[lane + 64] = make_double2(rj.x, rj.y);
@@ -1167,6 +1172,16 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
     const double bru = -(1. / (4. * kPi)) * kDielFactor * (d.g.w * d.g.w + d.y * d.g.x) * d.g.y;
     return make_double2(d.g.z + bru, slot_is_heavy ? d.sv * d.iv : 0.0);  // slot h of a heavy block is heavy atom h
   };
+  auto out_of_range = [&]() {  // workgroup-uniform range test on the two bounding boxes
+    if (diag) return false;
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    return gap2 >= P.range2;
+  };
+  if (P.cull_first && out_of_range()) return;  // (see k_born_tiles)
   const int islot = 64 * I + lane, jslot = 64 * J + lane;
   const SlotData di = fetch(islot);
   const SlotData dj = fetch(jslot);  // every wave asks; wave 0 puts block J into LDS
@@ -1174,14 +1189,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   const LutBatch lut0 = lut_fetch(lut, lut_entries, 0);
   lut_store(s_lut, lut0, lut_entries, 0);
   lut_copy_rest(s_lut, lut, lut_entries);
-  if (!diag) {  // workgroup-uniform range test on the two bounding boxes
-    double gap2 = 0.0;
-    for (int d = 0; d < 3; d++) {
-      const double g = fmax(0.0, fmax(pbox[6 * J + d] - pbox[6 * I + 3 + d], pbox[6 * I + d] - pbox[6 * J + 3 + d]));
-      gap2 += g * g;
-    }
-    if (gap2 >= P.range2) return;
-  }
+  if (!P.cull_first && out_of_range()) return;
   PAIR_STAMP_WHERE(2, item);
   if (wave == 0) {
     const bool vj = __double2hiint(dj.r.w) >= 0;
@@ -1305,7 +1313,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)
     hipLaunchKernelGGL(k_born_tiles, dim3(P.db_items_count), dim3(256), lds, st, P.nh, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
-                       (const double*)P.pbox, (const double4*)P.prec, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det);
+                       (const double*)P.pbox, (const double4*)P.prec, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det, P.cull_first);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
   if (P.fast)
