@@ -111,8 +111,16 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;  // hand-off word of the work queue (in LDS for every variant)
   const int tid = threadIdx.x;
+  // the row of the workgroup's own work slot is requested before anything is waited for (blockIdx.x < slot_cap: the
+  // row exists whether or not the slot is in use)
+  int first_item = -1;
+  if ((tid & 63) < kMaxRoots) first_item = A.rows[(size_t)kRowStride * blockIdx.x + (tid & 63)];
   const int nforests = min(A.nforests()[0], A.slot_cap);  // (never above the slots the per-slot arrays hold)
   if (blockIdx.x == 0 && tid == 0) A.cur_nforests()[0] = nforests;
+  if ((int)blockIdx.x >= nforests && tid == 0) {  // an idle work slot: k_tree_pseudo's workgroup of the same slot finds nothing to replay
+    A.hdr[blockIdx.x].nnodes = 0;
+    A.hdr[blockIdx.x].natoms = 0;
+  }
 
   const bool queued = nforests > (int)gridDim.x;  // otherwise every forest has a workgroup of its own
   for (int slot = blockIdx.x; slot < nforests;) {
@@ -122,8 +130,11 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     // slot -> forest indirection in front of it): lanes 0..7 of every wave fetch one item each
     // (-1 = no item.  Counting the items with a ballot instead of reading the row's count word out of lane 8 makes
     // k_tree_cavity 1.6 us faster on 1dwc, A/B on one box -- same spill counts, different register allocation.)
-    int my_item = -1;
-    if ((tid & 63) < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + (tid & 63)];
+    int my_item = first_item;
+    if (slot != (int)blockIdx.x) {  // (a forest from the queue)
+      my_item = -1;
+      if ((tid & 63) < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + (tid & 63)];
+    }
     const int m = __popcll(__ballot(my_item >= 0));  // 1..kMaxRoots
     int items[kMaxRoots];
 #pragma unroll
@@ -270,10 +281,11 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;
   const int tid = threadIdx.x;
-  const int nforests = A.cur_nforests()[0];
-  const bool queued = nforests > (int)gridDim.x;
-  for (int slot = blockIdx.x; slot < nforests;) {
-    int ticket = nforests;
+  const int nforests = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
+  // The workgroup's own work slot needs no test: k_tree_cavity leaves "nothing to replay" in the header of an idle slot,
+  // so the forest's topology is requested straight away.
+  for (int slot = blockIdx.x;;) {
+    int ticket = 0x3fffffff;  // (a forest that asks for no successor ends the workgroup's run)
     do {
     PSTAMP_BEGIN();
     // One round trip to the stored topology: the paths, the membership list and the local atom list are requested
@@ -301,7 +313,8 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     }
     const int nnodes = H->nnodes, natoms = H->natoms, m = H->nroots;
     int npairs = H->npairs;
-    if (nnodes <= m) {  // not built (capacity overflow: the host repeats the evaluation) or lone atoms only
+    const bool queued = nforests > (int)gridDim.x;
+    if (nnodes <= m) {  // not built (capacity overflow: the host repeats the evaluation), lone atoms only, or an idle slot
       if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
       break;
     }
@@ -356,8 +369,9 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     PSTAMP(2);
     PSTAMP_FLUSH();
     } while (false);
-    if (!queued) break;
+    if (nforests <= (int)gridDim.x) break;  // every forest has a workgroup of its own
     slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
+    if (slot >= nforests) break;
   }
 }
 
