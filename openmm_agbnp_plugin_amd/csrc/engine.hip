@@ -334,7 +334,7 @@ void wire_args(agbnp_hip_context* c) {
     P.tree_atom_cap = tree_variant_atom_cap(c->variant);
     const bool no_pack = getenv("AGBNP_HIP_NO_PACK") != nullptr;  // tuning knob: one subtree per work slot
     P.pack_enabled = no_pack ? 0 : (getenv("AGBNP_HIP_ITEMS_ALONE") ? 2 : 1);
-    const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 969;
+    const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 1000;
     P.round_permille = std::max(100, round_permille);
     const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 3;
     const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 550;

@@ -67,7 +67,7 @@ struct PairArgs {
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
   int split_big, split_permille;  // tuning knobs: parts and node threshold (share of the capacity) for sharing on a full device
-  int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 969)
+  int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 1000: every resident slot)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
   int* status;
   // ---- pair-stage intermediates
