@@ -1003,6 +1003,8 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   extern __shared__ double2 s_lut[];
   __shared__ double2 s_xy[128], s_zs[128];  // block J twice over: {x, y}, {z, s}
   __shared__ double s_ty[128];               // low word: types, high word: >= 0 for a real atom
+  __shared__ double2 s_ixy[64], s_izs[64];   // block I, on its way from memory to the lanes' registers
+  __shared__ double s_ity[64];
   __shared__ double s_red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   PAIR_STAMP(0, 0);
@@ -1026,35 +1028,46 @@ __global__ __launch_bounds__(256) void k_born_tiles(int nh, int nhb, int ntj, in
   // (a large system culls most of its tiles: there the test comes first and a culled tile costs two scalar loads; a
   // small one culls next to none: there the test waits until the tile's loads are on their way)
   if (cull_first && out_of_range()) return;
+  // Every slot of the tile is fetched ONCE (the start of a launch is a burst of every workgroup's loads at the same
+  // time: it is their volume that the first microseconds wait for): lanes 0..15 of wave w take slots 16w.. of block I,
+  // lanes 16..31 those of block J (the upper half of the wave repeats the same addresses), and block I reaches the
+  // lanes' registers through LDS.
   const int islot = 64 * I + lane, jslot = 64 * J + lane;
-  const int ih = min(islot, nh - 1), jh = min(jslot, nh - 1);  // (clamped: the loads are unconditional, the choice comes after)
-  const double4 ri = prec[islot];
-  const double4 rj = prec[jslot];  // every wave asks; wave 0 puts block J into LDS
-  const double svi = sv_vdw[ih], ivi = inv_vol_h[ih], svj = sv_vdw[jh], ivj = inv_vol_h[jh];
+  const int fpart = (lane >> 4) & 1, fidx = 16 * wave + (lane & 15);
+  const int fslot = 64 * (fpart ? J : I) + fidx, fh = min(fslot, nh - 1);  // (clamped: the loads are unconditional, the choice comes after)
+  const double4 fr = prec[fslot];
+  const double fsv = sv_vdw[fh], fiv = inv_vol_h[fh];
   const int a_out = pslot[wave == 0 ? islot : jslot];  // wave 0 adds the sums of block I, wave 1 those of block J: by atom
   const LutBatch lut0 = lut_fetch(lut, lut_entries, 0);
   PAIR_STAMP_WAIT(0, 8, "vmcnt(0)");  // everything has arrived
-  const double si = islot < nh ? svi * ivi : 0.0;
-  const double sj = jslot < nh ? svj * ivj : 0.0;
+  const double fs = fslot < nh ? fsv * fiv : 0.0;
   lut_store(s_lut, lut0, lut_entries, 0);
   lut_copy_rest(s_lut, lut, lut_entries);
   PAIR_STAMP_WAIT(0, 9, "vmcnt(0) lgkmcnt(0)");  // the tables are in LDS (this wave's part)
   if (!cull_first && out_of_range()) return;
   PAIR_STAMP_WHERE(0, item);
-  if (wave == 0) {
-    s_xy[lane] = s_xy[lane + 64] = make_double2(rj.x, rj.y);
-    s_zs[lane] = s_zs[lane + 64] = make_double2(rj.z, sj);
-    s_ty[lane] = s_ty[lane + 64] = rj.w;
+  if (lane < 32) {
+    if (fpart) {
+      s_xy[fidx] = s_xy[fidx + 64] = make_double2(fr.x, fr.y);
+      s_zs[fidx] = s_zs[fidx + 64] = make_double2(fr.z, fs);
+      s_ty[fidx] = s_ty[fidx + 64] = fr.w;
+    } else {
+      s_ixy[fidx] = make_double2(fr.x, fr.y);
+      s_izs[fidx] = make_double2(fr.z, fs);
+      s_ity[fidx] = fr.w;
+    }
   }
-  const int nsteps = diag ? 8 : 16;
-  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
-  const bool vi = __double2hiint(ri.w) >= 0;
-  const double xi = ri.x, yi = ri.y, zi = ri.z;
-  const int2 mi = make_int2(__double2loint(ri.w) & 0xffff, __double2loint(ri.w) >> 16);  // {screened type, screener type}: block I is always a heavy block
-  const int base = (lane + start) & 63;
-  double sum_i = 0.0, sum_j = 0.0;
   __syncthreads();
   PAIR_STAMP(0, 1);
+  const double2 ixy = s_ixy[lane], izs = s_izs[lane];
+  const double ity = s_ity[lane];
+  const int nsteps = diag ? 8 : 16;
+  const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
+  const bool vi = __double2hiint(ity) >= 0;
+  const double xi = ixy.x, yi = ixy.y, zi = izs.x, si = izs.y;
+  const int2 mi = make_int2(__double2loint(ity) & 0xffff, __double2loint(ity) >> 16);  // {screened type, screener type}: block I is always a heavy block
+  const int base = (lane + start) & 63;
+  double sum_i = 0.0, sum_j = 0.0;
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
     born_walk<true>(sum_i, sum_j, s_lut, s_xy + base, s_zs + base, s_ty + base, xi, yi, zi, si, mi.x * ntj, mi.y, nsteps,
@@ -1182,39 +1195,48 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
     return gap2 >= P.range2;
   };
   if (P.cull_first && out_of_range()) return;  // (see k_born_tiles)
+  // every slot of the tile is fetched once, block I reaches the lanes' registers through LDS (see k_born_tiles)
   const int islot = 64 * I + lane, jslot = 64 * J + lane;
-  const SlotData di = fetch(islot);
-  const SlotData dj = fetch(jslot);  // every wave asks; wave 0 puts block J into LDS
+  const int fpart = (lane >> 4) & 1, fidx = 16 * wave + (lane & 15);
+  const int fslot = 64 * (fpart ? J : I) + fidx;
+  const SlotData fd = fetch(fslot);
   const int ai = pslot[islot], aj = pslot[jslot];  // the force rows are by atom
   const LutBatch lut0 = lut_fetch(lut, lut_entries, 0);
   lut_store(s_lut, lut0, lut_entries, 0);
   lut_copy_rest(s_lut, lut, lut_entries);
   if (!P.cull_first && out_of_range()) return;
   PAIR_STAMP_WHERE(2, item);
-  if (wave == 0) {
-    const bool vj = __double2hiint(dj.r.w) >= 0;
-    const double2 wj = vj ? weights(dj, jslot < nh) : make_double2(0.0, 0.0);
+  double2* const s_irec = s_lut + lut_entries;  // [3][64] block I, behind the tables (the launch sizes the area for both)
+  if (lane < 32) {
+    const bool vf = __double2hiint(fd.r.w) >= 0;
+    const double2 wf = vf ? weights(fd, fslot < nh) : make_double2(0.0, 0.0);
     // .w of the record: low word screened type | screener type << 16 (only read in heavy x heavy tiles); high word >= 0 for a real atom
-    s_rec[0][lane] = s_rec[0][lane + 64] = make_double2(dj.r.x, dj.r.y);
-    s_rec[1][lane] = s_rec[1][lane + 64] = make_double2(dj.r.z, wj.x);
-    s_rec[2][lane] = s_rec[2][lane + 64] = make_double2(wj.y, dj.r.w);
+    const double2 r0 = make_double2(fd.r.x, fd.r.y), r1 = make_double2(fd.r.z, wf.x), r2 = make_double2(wf.y, fd.r.w);
+    if (fpart) {
+      s_rec[0][fidx] = s_rec[0][fidx + 64] = r0;
+      s_rec[1][fidx] = s_rec[1][fidx + 64] = r1;
+      s_rec[2][fidx] = s_rec[2][fidx + 64] = r2;
+    } else {
+      s_irec[fidx] = r0;
+      s_irec[64 + fidx] = r1;
+      s_irec[128 + fidx] = r2;
+    }
   }
   const int nsteps = diag ? 8 : 16;
   const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
-  const bool vi = __double2hiint(di.r.w) >= 0;
-  const double2 wi = vi ? weights(di, islot < nh) : make_double2(0.0, 0.0);
-  const int2 mi = make_int2(__double2loint(di.r.w) & 0xffff, __double2loint(di.r.w) >> 16);  // {screened type, screener type}: block I is always a heavy block
-  const double4 pi = di.r;
+  __syncthreads();
+  PAIR_STAMP(2, 1);
+  const double2 i0 = s_irec[lane], i1 = s_irec[64 + lane], i2 = s_irec[128 + lane];
+  const bool vi = __double2hiint(i2.y) >= 0;
+  const int2 mi = make_int2(__double2loint(i2.y) & 0xffff, __double2loint(i2.y) >> 16);  // {screened type, screener type}: block I is always a heavy block
   DbornLane L;
-  L.x = pi.x, L.y = pi.y, L.z = pi.z, L.bw = wi.x, L.s = wi.y;
+  L.x = i0.x, L.y = i0.y, L.z = i1.x, L.bw = i1.y, L.s = i2.x;
   L.row = mi.x * ntj, L.tsr = mi.y;
   L.fxi = L.fyi = L.fzi = L.wui = L.fxj = L.fyj = L.fzj = L.wuj = 0.0;
   const int base = (lane + start) & 63;
   const double2* __restrict__ jxy = s_rec[0] + base;
   const double2* __restrict__ jzw = s_rec[1] + base;
   const double2* __restrict__ jsm = s_rec[2] + base;
-  __syncthreads();
-  PAIR_STAMP(2, 1);
   // diagonal tile, cyclic distance 32 (the last step of the last wave): one end only
   if (both)
     dborn_walk<true>(L, s_lut, jxy, jzw, jsm, nsteps, diag ? 32 - start : -1, vi, lane < 32, ntj, P.range2);
@@ -1307,7 +1329,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_born_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 3 * 64 * sizeof(double2)));
     if (e != hipSuccess) return e;
   }
   AGBNP_MARK(kKBornTiles);
@@ -1325,7 +1347,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
   // (+ 2: the energy workgroup and the dealing workgroup; with no heavy atom there is no tile but the roles still run)
-  const size_t db_lds = std::max(lds, sizeof(TileSums));
+  const size_t db_lds = std::max(lds + 3 * 64 * sizeof(double2), sizeof(TileSums));  // tables + block I's records; later the sums
   hipLaunchKernelGGL(k_dborn_tiles, dim3(P.db_items_count + 2), dim3(256), db_lds, st, P.n, P.nhb, P.ntj, P.lut_entries, P.db_items, P.pslot,
                      (const double*)P.pbox, (const double4*)P.prec, (const double4*)P.srec, (const double*)P.ys, (const double*)P.sv_vdw,
                      P.inv_vol_h, P.nh, P.lut, P.db_fx, P, energy_out, components, (int)db_lds);
