@@ -1358,8 +1358,8 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl) {
   AGBNP_MARK(kKOutputs);
-  // (version 0: the roles' LDS, with room for the packed shapes of up to 12 k subtrees)
-  const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::min(std::max(P.nh, 1), 12288);
+  // (version 0: the roles' LDS, with room for the packed shapes and as many forest times of up to 6 k subtrees)
+  const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::min(2 * std::max(P.nh, 1) + 64, 12288);
   hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), role_bytes, st, P, version, force_out, energy_out, components, role_bytes);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);
