@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
                                                   double* __restrict__ egb_part, PairArgs P) {
   // one LDS area, two lives: the atom records during the walk, the sums of the four waves after it
   __shared__ __align__(16) char s_area[sizeof(StripSums)];
-  static_assert(sizeof(StripSums) >= sizeof(TileSums) && sizeof(TileSums) >= kRoleScratchBytes, "the bookkeeping workgroup borrows the tile area");
+  static_assert(sizeof(StripSums) >= sizeof(TileSums) && sizeof(TileSums) >= kRoleScratchBytes, "the packing workgroup borrows the tile area");
   static_assert(sizeof(StripSums) >= sizeof(double2) * (3 * 128 + 6 * 64), "strip records fit the area of the sums");
   // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): mostly serial work that
   // hides underneath this launch, the longest of the pair stages

@@ -1,6 +1,7 @@
 // GaussVol overlap-tree kernels for gfx950 (MI355X).
 //
-// One workgroup (BS = 256 lanes) owns a FOREST -- the complete overlap subtrees rooted at up to eight heavy atoms
+// One workgroup (BS = 192 lanes: five of them on a CU are at most four waves per SIMD, so the build keeps its ~124
+// vector registers without spilling) owns a FOREST -- the complete overlap subtrees rooted at up to eight heavy atoms
 // (or one residue class of the level-2 branches of a big subtree) -- and keeps it in LDS for its whole life: build
 // (large radii) -> volume pass 1 on the build's Gaussians -> topology out -> vdW radii -> volume pass 2, all inside
 // one launch.  Only per-atom sums (gradients, self volumes), one energy pair per forest and the stored topology
@@ -1075,7 +1076,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
     AGBNP_BUILD_STAMP(14);
     return true;
   }
-  // (3) atom-owned gather (variants too large for 16-bit pair words).  The 256 lanes form (atom, slice) pairs:
+  // (3) atom-owned gather (variants too large for 16-bit pair words).  The BS lanes form (atom, slice) pairs:
   // A = 16/32/64 atoms per round (the smallest
   {
     const int A = natoms <= 16 ? 16 : (natoms <= 32 ? 32 : 64);

@@ -75,9 +75,9 @@ __device__ unsigned long long g_wg_log[kWgLogSlots][24];
 #endif
 
 // Build + cavity passes of one forest = the subtrees of up to kMaxRoots heavy atoms (reference steps A-D of
-// platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).  Work slot s holds the
-// roots order[forest_start[s] .. forest_start[s+1]); the packing comes from the previous evaluation's subtree sizes
-// (the bookkeeping workgroup).
+// platforms/reference/src/ReferenceAGBNPKernels.cpp:293-384, restated in oracle run_cavity()).  Work slot s builds the
+// work items of its row rows[kRowStride * s ..]; the packing comes from the previous evaluation's subtree sizes
+// (packing_role / dealing_role in pair_kernels.hip).
 //
 // Scheduling: the launch holds as many workgroups as the device keeps resident (or fewer, if there are fewer forests);
 // a workgroup starts on forest blockIdx.x and then takes forests from a device-wide queue until it is empty: one
