@@ -123,8 +123,14 @@ unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
  * between runs.  In this mode every term that enters an order-dependent sum is first rounded to a fixed quantum
  * (2^-34 kJ/mol/nm for forces, 2^-52 nm^3 for self volumes, 2^-44 / 2^-40 for the pair-stage sums, 2^-36 kJ/mol for
  * energies): sums of such terms are exact in FP64, hence independent of their order.  Results stay within 1e-8 of the
- * default mode's (far inside the 1e-4 parity bar). */
-enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1, AGBNP_HIP_MODE_DETERMINISTIC = 2 };
+ * default mode's (far inside the 1e-4 parity bar).
+ *
+ * AGBNP_HIP_MODE_SINGLE (only together with AGBNP_HIP_MODE_FAST): the GB pair stage -- the dominant pair stage -- computes
+ * its pair terms in single precision (packed FP32, hardware exp2 / rsqrt; positions relative to a block-local origin),
+ * as the reference's OpenCL platform does in its default precision; Born radii, the range-limited stages, the trees and
+ * every sum across tiles stay FP64.  Forces differ from the FP64 fast mode by ~1e-3 kJ/mol/nm, the energy by ~1e-2
+ * kJ/mol on a 4000-atom protein.  Rejected without AGBNP_HIP_MODE_FAST: the Reference semantics are FP64. */
+enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1, AGBNP_HIP_MODE_DETERMINISTIC = 2, AGBNP_HIP_MODE_SINGLE = 4 };
 int agbnp_hip_set_mode(agbnp_hip_context* ctx, int mode);
 int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
 

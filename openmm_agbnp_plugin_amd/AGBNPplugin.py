@@ -139,7 +139,7 @@ class HipCalcAGBNPForceKernel:
     def Name():
         return "CalcAGBNPForce"
 
-    MODES = {"reference": 0, "fast": 1, "deterministic": 2, "fast+deterministic": 3}
+    MODES = {"reference": 0, "fast": 1, "deterministic": 2, "fast+deterministic": 3, "fast+single": 5}
 
     def __init__(self, device=0, mode="reference"):
         """mode "reference" (default): the Reference platform's semantics, the parity target.  mode "fast": the

@@ -263,6 +263,7 @@ void wire_args(agbnp_hip_context* c) {
   P.ys = c->d_ys.p;
   P.abox = c->d_abox.p;
   P.fast = (c->mode & AGBNP_HIP_MODE_FAST) ? 1 : 0;
+  P.single = (c->mode & AGBNP_HIP_MODE_FAST) && (c->mode & AGBNP_HIP_MODE_SINGLE) ? 1 : 0;
   P.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
   P.range2 = P.fast ? std::min(kI4MaxA * kI4MaxA, c->cutoff * c->cutoff) : kI4MaxA * kI4MaxA;
   P.gb_cut2 = P.fast ? c->cutoff * c->cutoff : 1e300;
@@ -823,8 +824,10 @@ int agbnp_hip_get_tables(agbnp_hip_context* c, double* y, double* y2, int* type_
 
 int agbnp_hip_set_mode(agbnp_hip_context* c, int mode) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
-  if (mode & ~(AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_DETERMINISTIC))
+  if (mode & ~(AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_DETERMINISTIC | AGBNP_HIP_MODE_SINGLE))
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: unknown mode bits");
+  if ((mode & AGBNP_HIP_MODE_SINGLE) && !(mode & AGBNP_HIP_MODE_FAST))
+    return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: single precision is an option of the fast mode (the Reference semantics are FP64)");
   if ((mode & AGBNP_HIP_MODE_FAST) && !(c->cutoff > 0.0))
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: the fast mode needs a positive cutoff distance");
   HIP_TRY(c, hipSetDevice(c->device));

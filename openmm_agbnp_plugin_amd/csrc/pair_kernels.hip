@@ -441,14 +441,20 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   __syncthreads();
   int tot = 0, mx = 0, ma = 0;
 #pragma unroll 1
-  for (int h = t; h < P.nh; h += 256) {
-    const int2 sz = shape(h);
-    tot += sz.x;
-    mx = max(mx, sz.x);
-    ma = max(ma, sz.y);
-    const int parts = parts_of(sz);
-    const unsigned w = weight(sz, parts);
-    atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+  for (int h0 = t; h0 < P.nh; h0 += 256 * 4) {  // (four LDS reads in flight)
+    int2 sz[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) sz[c] = shape(min(h0 + 256 * c, P.nh - 1));
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (h0 + 256 * c >= P.nh) continue;
+      tot += sz[c].x;
+      mx = max(mx, sz[c].x);
+      ma = max(ma, sz[c].y);
+      const int parts = parts_of(sz[c]);
+      const unsigned w = weight(sz[c], parts);
+      atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+    }
   }
   PAIR_STAMP(1, 7);
   for (int off = 32; off > 0; off >>= 1) {
@@ -543,38 +549,53 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;  // (word behind the times: are they there)
   }
   PAIR_STAMP(1, 9);
-  // sorted order -> place inside the forests
+  // sorted order -> place inside the forests.  Four subtrees per thread and trip, their LDS round trips (shape, then the
+  // ranked add) in flight together: the role's time is its chain of dependent LDS latencies.
+  constexpr int kChains = 4;
 #pragma unroll 1
-  for (int h = t; h < P.nh; h += 256) {
-    const int2 sz = shape(h);
-    const int parts = parts_of(sz);
-    const unsigned w = weight(sz, parts);
-    const unsigned long long v = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
-    // predicted time of a work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom, 1.6 per
-    // root; units of 0.01 us)
-    const int l2 = max(sz.y - 1, 0);
-    const int tm = 9 * (1 + l2 + (int)((float)max(sz.x - 1 - l2, 0) * inv_parts(parts))) + 34 * sz.y + 160;
-#pragma unroll 1
-    for (int part = 0; part < parts; part++) {
-      const int pos = (int)(v >> 32) + part;  // position in descending weight order
-      int forest, place;                      // the item is number `place` of forest `forest`
-      if (pos < nab) {
-        forest = pos;  // a forest of its own, or the leader of a class-B forest
-        place = 0;
-      } else if (pos >= nitems - npair) {
-        forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
-        place = 1;
-      } else {
-        const int k = pos - nab;
-        int r = 0;  // k / fs: the serpentine round, at most kMaxItems - 1
+  for (int h0 = t; h0 < P.nh; h0 += 256 * kChains) {
+    int2 sz[kChains];
+    int parts[kChains];
+    unsigned long long v[kChains];
 #pragma unroll
-        for (int q = 1; q < kMaxItems; q++) r += k >= q * fs ? 1 : 0;
-        const int idx = k - r * fs;
-        forest = nab + ((r & 1) ? fs - 1 - idx : idx);
-        place = r;
+    for (int c = 0; c < kChains; c++) sz[c] = shape(min(h0 + 256 * c, P.nh - 1));
+#pragma unroll
+    for (int c = 0; c < kChains; c++) {
+      parts[c] = parts_of(sz[c]);
+      const unsigned w = weight(sz[c], parts[c]);
+      v[c] = 0ull;
+      if (h0 + 256 * c < P.nh) v[c] = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts[c] << 32) | (w * (unsigned)parts[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < kChains; c++) {
+      const int h = h0 + 256 * c;
+      if (h >= P.nh) continue;
+      // predicted time of a work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom, 1.6 per
+      // root; units of 0.01 us)
+      const int l2 = max(sz[c].y - 1, 0);
+      const int tm = 9 * (1 + l2 + (int)((float)max(sz[c].x - 1 - l2, 0) * inv_parts(parts[c]))) + 34 * sz[c].y + 160;
+#pragma unroll 1
+      for (int part = 0; part < parts[c]; part++) {
+        const int pos = (int)(v[c] >> 32) + part;  // position in descending weight order
+        int forest, place;                         // the item is number `place` of forest `forest`
+        if (pos < nab) {
+          forest = pos;  // a forest of its own, or the leader of a class-B forest
+          place = 0;
+        } else if (pos >= nitems - npair) {
+          forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
+          place = 1;
+        } else {
+          const int k = pos - nab;
+          int r = 0;  // k / fs: the serpentine round, at most kMaxItems - 1
+#pragma unroll
+          for (int q = 1; q < kMaxItems; q++) r += k >= q * fs ? 1 : 0;
+          const int idx = k - r * fs;
+          forest = nab + ((r & 1) ? fs - 1 - idx : idx);
+          place = r;
+        }
+        P.order[kMaxItems * forest + place] = h | (part << 24) | ((parts[c] - 1) << 26);
+        if (rank_by_time) atomicAdd(&lds_time[forest], tm);
       }
-      P.order[kMaxItems * forest + place] = h | (part << 24) | ((parts - 1) << 26);
-      if (rank_by_time) atomicAdd(&lds_time[forest], tm);
     }
   }
   PAIR_STAMP(1, 10);
@@ -819,7 +840,128 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   PAIR_STAMP(1, 3);
 }
 
+// ---- GB strips in packed single precision (fast mode + AGBNP_HIP_MODE_SINGLE) -----------------------------------------
+// The reference's GPU platform computes its pair terms in single precision; this is the strip of above with the two
+// i atoms of a lane as the two halves of a packed FP32 operand (v_pk_fma_f32 & co: two pairs per instruction), the
+// hardware's exp2 / rsqrt, positions taken relative to the first atom of block J before they are rounded to FP32, the
+// j sums travelling by ONE DPP move each.  Born radii and everything outside the pair loop stay FP64; a strip's
+// totals leave in FP64 exactly like the FP64 strip's.  ~50 instructions per two pairs against 130.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rot1f(float v) {  // lane l <- lane l+1 (mod 64)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134, 0xf, 0xf, true));
+}
 template <bool kCut>
+__device__ __forceinline__ void gb_strip_f32(int n, int I0, int J, const double4* __restrict__ aposq, const double* __restrict__ born_part,
+                                             const double* __restrict__ inv_rvdw, double* __restrict__ gb_rows, double* __restrict__ egb_out,
+                                             const PairArgs& P, char* s_area, double* s_e) {
+  float4* const s_jr = reinterpret_cast<float4*>(s_area);         // block J twice over: {x, y, z, q}
+  float2* const s_jb = reinterpret_cast<float2*>(s_jr + 128);     // ... {B, 1/B}
+  float4* const s_ir = reinterpret_cast<float4*>(s_jb + 128);     // blocks I0, I0 + 1: [block][64] {x, y, z, q}
+  float2* const s_ib = reinterpret_cast<float2*>(s_ir + 128);     // ... {B, -log2(e)/(4 B)}
+  static_assert(sizeof(StripSums) >= 128 * 16 + 128 * 8 + 128 * 16 + 128 * 8, "single-precision records fit the area of the sums");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (kCut) {  // both tiles of the strip beyond the cutoff
+    double gmin = 1e300;
+    for (int b = 0; b < 2; b++) {
+      double gap2 = 0.0;
+      for (int d = 0; d < 3; d++) {
+        const double g = fmax(0.0, fmax(P.abox[6 * J + d] - P.abox[6 * (I0 + b) + 3 + d], P.abox[6 * (I0 + b) + d] - P.abox[6 * J + 3 + d]));
+        gap2 += g * g;
+      }
+      gmin = fmin(gmin, gap2);
+    }
+    if (gmin >= P.gb_cut2) {
+      if (threadIdx.x == 0) egb_out[0] = 0.0;
+      return;
+    }
+  }
+  const int ysa = P.a2s[min(64 * I0 + lane, n - 1)], ysc = P.a2s[min(64 * I0 + 64 + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];
+  const double4 origin = aposq[min(64 * J, n - 1)];  // (uniform address: a scalar load)
+  if (wave < 3) {  // wave 0 prepares block J, waves 1 and 2 the two i blocks
+    const int a = 64 * (wave == 0 ? J : I0 + wave - 1) + lane;
+    const bool va = a < n;
+    const int ac = va ? a : n - 1;
+    const double4 pa = aposq[ac];
+    const BornRadius bra = born_radius(inv_rvdw[ac], born_part[ac]);
+    const float4 rec = make_float4((float)(pa.x - origin.x), (float)(pa.y - origin.y), (float)(pa.z - origin.z), va ? (float)pa.w : 0.0f);
+    if (wave == 0) {
+      s_jr[lane] = s_jr[lane + 64] = rec;
+      s_jb[lane] = s_jb[lane + 64] = make_float2((float)bra.br, (float)bra.inv_br);
+    } else {
+      s_ir[(wave - 1) * 64 + lane] = rec;
+      s_ib[(wave - 1) * 64 + lane] = make_float2((float)bra.br, (float)((-0.25 * 1.4426950408889634074) * bra.inv_br));
+    }
+  }
+  __syncthreads();
+  const int start = 16 * wave;  // the four waves take a quarter of the cyclic distances each
+  const float4 ra = s_ir[lane], rc = s_ir[64 + lane];
+  const float2 ba = s_ib[lane], bc = s_ib[64 + lane];
+  const v2f xi = {ra.x, rc.x}, yi = {ra.y, rc.y}, zi = {ra.z, rc.z}, qi = {ra.w, rc.w}, bi = {ba.x, bc.x}, ci = {ba.y, bc.y};
+  const int base = (lane + start) & 63;
+  const float4* __restrict__ jr = s_jr + base;
+  const float2* __restrict__ jb = s_jb + base;
+  const float cut2 = (float)P.gb_cut2;
+  v2f fx = {0.f, 0.f}, fy = {0.f, 0.f}, fz = {0.f, 0.f}, ys = {0.f, 0.f}, e2 = {0.f, 0.f};
+  float fxj = 0.f, fyj = 0.f, fzj = 0.f, yj = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < 16; k++) {
+    const float4 rj = jr[k];
+    const float2 bj = jb[k];
+    const v2f dx = rj.x - xi, dy = rj.y - yi, dz = rj.z - zi;
+    const v2f d2 = dz * dz + (dy * dy + dx * dx);
+    const v2f bb = bi * bj.x;
+    const v2f arg = d2 * (ci * bj.y);
+    const v2f et = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};  // exp(-d^2 / (4 B_i B_j))
+    const v2f den = bb * et + d2;
+    const v2f f = {__builtin_amdgcn_rsqf(den.x), __builtin_amdgcn_rsqf(den.y)};
+    v2f qq = qi * rj.w;
+    if (kCut) qq = {d2.x < cut2 ? qq.x : 0.f, d2.y < cut2 ? qq.y : 0.f};
+    const v2f s1 = qq * f;
+    const v2f s3 = s1 * (f * f);
+    const v2f mw = (1.0f - 0.25f * et) * s3;
+    const v2f yt = (0.25f * d2 + bb) * (et * s3);
+    e2 += s1;
+    fx += dx * mw;
+    fy += dy * mw;
+    fz += dz * mw;
+    ys += yt;
+    const v2f gx = dx * mw, gy = dy * mw, gz = dz * mw;
+    fxj = rot1f(fxj - (gx.x + gx.y));
+    fyj = rot1f(fyj - (gy.x + gy.y));
+    fzj = rot1f(fzj - (gz.x + gz.y));
+    yj = rot1f(yj + (yt.x + yt.y));
+  }
+  const double kf = -2.0 * kDielFactor;
+  __syncthreads();  // every wave is done with the records
+  StripSums& S = *reinterpret_cast<StripSums*>(s_area);
+  const int jslot = (lane + start + 16) & 63;  // whose sums the lane holds after the rotations
+  S.red[wave][0][lane] = kf * (double)fx.x;
+  S.red[wave][1][lane] = kf * (double)fy.x;
+  S.red[wave][2][lane] = kf * (double)fz.x;
+  S.red[wave][3][lane] = (double)ys.x;
+  S.red[wave][4][lane] = kf * (double)fx.y;
+  S.red[wave][5][lane] = kf * (double)fy.y;
+  S.red[wave][6][lane] = kf * (double)fz.y;
+  S.red[wave][7][lane] = (double)ys.y;
+  S.red[wave][8][jslot] = kf * (double)fxj;
+  S.red[wave][9][jslot] = kf * (double)fyj;
+  S.red[wave][10][jslot] = kf * (double)fzj;
+  S.red[wave][11][jslot] = (double)yj;
+  const double e = wave_sum((double)e2.x + (double)e2.y);
+  if (lane == 0) s_e[wave] = e;
+  __syncthreads();
+  double* __restrict__ row = gb_rows + (size_t)wave * n;
+  auto fold = [&](int r) { return (S.red[0][r][lane] + S.red[1][r][lane]) + (S.red[2][r][lane] + S.red[3][r][lane]); };
+  const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
+  const bool det = P.det != 0;
+  const double qs = wave == 3 ? kQSum : kQGrad;
+  if (ia < n) hbm_add(wave == 3 ? &P.ys[ysa] : &row[ia], quantize(fold(wave), qs, det));
+  if (ic < n) hbm_add(wave == 3 ? &P.ys[ysc] : &row[ic], quantize(fold(4 + wave), qs, det));
+  if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(fold(8 + wave), qs, det));
+  if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
+}
+
+template <bool kCut, bool kSingle>
 __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                   const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
                                                   const double* __restrict__ alpha, double* __restrict__ born,
@@ -850,7 +992,10 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   PAIR_STAMP(1, 0);
-  if (item & kGbStripFlag) return gb_strip<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
+  if (item & kGbStripFlag) {
+    if (kSingle) return gb_strip_f32<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
+    return gb_strip<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
+  }
   const bool diag = I == J;
   if (kCut && !diag) {  // fast mode: a tile whose two blocks are further apart than the cutoff has no pair to meet
     double gap2 = 0.0;
@@ -1338,12 +1483,9 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
                        (const double*)P.pbox, (const double4*)P.prec, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det, P.cull_first);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
-  if (P.fast)
-    hipLaunchKernelGGL(k_gb_tiles<true>, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
-  else
-    hipLaunchKernelGGL(k_gb_tiles<false>, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+  auto gb = P.fast ? (P.single ? k_gb_tiles<true, true> : k_gb_tiles<true, false>) : k_gb_tiles<false, false>;
+  hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                     (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);
   // (+ 2: the energy workgroup and the dealing workgroup; with no heavy atom there is no tile but the roles still run)

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import openmm_agbnp_plugin_amd as P
+from openmm_agbnp_plugin_amd import _lib
 from oracle import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -112,6 +113,30 @@ def test_fast_mode_with_a_huge_cutoff_is_the_reference_mode(gpu_required, system
     e = k.execute(s.pos, f)
     eo, fo = Oracle(*s.params(), version=1).execute(s.pos)
     assert_close(e, f, eo, fo)
+
+
+def test_fast_mode_single_precision_gb(gpu_required, systems):
+    """AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_SINGLE: GB pair terms in packed FP32 (the precision of the reference's OpenCL
+    platform).  Stays within single-precision distance of the FP64 fast mode -- 1e-6 relative in the energy, 2e-2
+    kJ/mol/nm in the forces -- and is NOT bit-equal to it; the bit is rejected without the fast mode."""
+    s = systems("1dwc")
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    force.setCutoffDistance(1.0)
+    k64 = P.HipCalcAGBNPForceKernel(mode="fast")
+    k64.initialize(force)
+    k32 = P.HipCalcAGBNPForceKernel(mode="fast+single")
+    k32.initialize(force)
+    for pos in (s.pos, s.jittered(3, sigma=0.004)):
+        f64, f32 = np.zeros((s.n, 3)), np.zeros((s.n, 3))
+        e64, e32 = k64.execute(pos, f64), k32.execute(pos, f32)
+        assert e32 != e64
+        assert abs(e32 - e64) < 1e-6 * abs(e64) + 1e-2
+        assert np.abs(f32 - f64).max() < 2e-2
+        assert np.abs(f32 - f64).max() < 1e-4 * np.abs(f64).max()
+    lib = _lib.load()
+    assert lib.agbnp_hip_set_mode(k32._h, 4) != _lib.OK  # single precision without the fast mode
+    assert lib.agbnp_hip_get_mode(k32._h) == 5
 
 
 # ---- deterministic mode ----------------------------------------------------------------------------------------------
