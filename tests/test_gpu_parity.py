@@ -139,6 +139,27 @@ def test_fast_mode_single_precision_gb(gpu_required, systems):
     assert lib.agbnp_hip_get_mode(k32._h) == 5
 
 
+@pytest.mark.parametrize("name,evaluations,checked,sigma", [("trpcage", 200, 30, 0.01), ("1dwc", 80, 10, 0.006)])
+@pytest.mark.parametrize("version", [0, 1])
+def test_soak_with_kicks_follows_the_oracle(gpu_required, systems, name, evaluations, checked, sigma, version):
+    """A long sequence of evaluations on ONE context (the forest packing, the work-slot rows and the capacity variant are
+    carried from evaluation to evaluation), geometries jittered with a larger kick every 37 steps so that the packing has
+    to follow trees that change shape; a random subset is compared with the oracle."""
+    s = systems(name)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=version))
+    oracle = Oracle(*s.params(), version=version)
+    rng = np.random.default_rng(7 + version)
+    check = set(rng.choice(evaluations, checked, replace=False).tolist())
+    for i in range(evaluations):
+        pos = s.jittered(i, sigma=sigma * (3.0 if i % 37 == 0 else 1.0))
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        if i in check:
+            eo, fo = oracle.execute(pos)
+            assert_close(e, f, eo, fo)
+
+
 # ---- deterministic mode ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["1dwc", "trpcage"])
 def test_deterministic_mode_is_bit_reproducible(gpu_required, systems, name):
