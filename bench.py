@@ -11,8 +11,9 @@ multi-GPU      : replicas only (the force evaluation does not shard; DESIGN.md s
                  GPU, independent geometries, no data-path collective; RCCL carries only the timing
                  reduction (MAX of the elapsed time) and the gather of the per-rank records.
 secondary      : on one GPU the same JSON line also carries BASELINE.json's other configurations (trpcage
-                 GaussVol, trpcage AGBNP1 with CutoffNonPeriodic 1.2 nm, the 16 608-atom HIV-RT stand-in) and the
-                 OpenCL-semantics fast mode, each with its own parity-on-sample figure.  --secondary 0 skips them.
+                 GaussVol, trpcage AGBNP1 with CutoffNonPeriodic 1.2 nm, the 16 608-atom HIV-RT stand-in),
+                 each with its own parity-on-sample figure, and under "other_modes" the timings of the fast
+                 (OpenCL-semantics), fast+single and deterministic modes on the headline workload.  --secondary 0 skips them.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -393,6 +394,9 @@ def main():
         sec.append(dict(config="4: HIV-RT stand-in = 2x2x1 lattice of 1dwc (synthetic), AGBNP1",
                         **secondary_entry(torch, "1dwc_x4", 1, device, dev_index, 40, 6, 1)))
         result["secondary"] = sec
+        # the other evaluation modes on the headline workload (each has a line of its own with --mode; here for the record)
+        result["other_modes"] = [dict(mode=m, **secondary_entry(torch, "1dwc", 1, device, dev_index, 200, 20, 0, cutoff=1.0, mode=m))
+                                 for m in ("fast", "fast+single", "deterministic")]
         result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(torch, "1dwc", device, dev_index, r, 200, 20) for r in (2, 4)]
 
     if rank == 0:
