@@ -38,10 +38,17 @@ class DeviceMD:
         self.noise = torch.empty_like(self.x)
         self.c1 = float(np.exp(-self.gamma * self.dt))
         self.c2 = torch.sqrt((1.0 - self.c1 * self.c1) * KB * self.T / self.mass)
-        # per-step log written inside the graph: [potential, kinetic] at index `counter`
-        self.log = torch.zeros((log_capacity, 2), **f64)
+        # per-step log written inside the graph: potential and kinetic energy at index `counter`
+        self.log_pe = torch.zeros(log_capacity, **f64)
+        self.log_ke = torch.zeros(log_capacity, **f64)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.one = torch.ones(1, dtype=torch.int64, device=self.dev)
+        # Every torch op below is one tiny launch (~2 us each inside the replayed graph), so the step is written with as
+        # few of them as the arithmetic allows: fused multiply-adds, preallocated outputs, dot products for the sums.
+        self.hdt_m = (0.5 * self.dt) / self.mass  # dt / 2m
+        self.d = torch.zeros_like(self.x)           # x - x0
+        self.mv = torch.zeros_like(self.x)          # m v
+        self.ke = torch.zeros(1, **f64)
         self.graphs = {}
         self.generation = None
         self.steps_done = 0
@@ -49,32 +56,34 @@ class DeviceMD:
     # ---- force field: tethers + AGBNP (added on the device by the engine)
     def forces(self):
         torch = self.torch
-        d = self.x - self.x0
-        self.frc.copy_(-self.k * d)
-        self.ene.copy_((0.5 * self.k) * (d * d).sum().reshape(1))
+        torch.sub(self.x, self.x0, out=self.d)
+        torch.mul(self.d, -self.k, out=self.frc)
+        torch.mul(torch.dot(self.d.view(-1), self.d.view(-1)).reshape(1), 0.5 * self.k, out=self.ene)
         self.kernel.execute_device(self.x.data_ptr(), self.frc.data_ptr(), self.ene.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     def _record(self):
-        ke = 0.5 * (self.mass * self.v * self.v).sum().reshape(1)
-        row = torch_cat(self.torch, self.ene, ke).reshape(1, 2)
-        self.log.index_copy_(0, self.counter, row)
+        torch = self.torch
+        torch.mul(self.v, self.mass, out=self.mv)
+        torch.mul(torch.dot(self.mv.view(-1), self.v.view(-1)).reshape(1), 0.5, out=self.ke)
+        self.log_pe.index_copy_(0, self.counter, self.ene)
+        self.log_ke.index_copy_(0, self.counter, self.ke)
         self.counter.add_(self.one)
 
     def step_verlet(self):  # velocity Verlet (the reference's NVE check uses OpenMM's VerletIntegrator, test_agbnp.py:57)
-        self.v.add_(self.frc / self.mass, alpha=0.5 * self.dt)
+        self.v.addcmul_(self.frc, self.hdt_m)
         self.x.add_(self.v, alpha=self.dt)
         self.forces()
-        self.v.add_(self.frc / self.mass, alpha=0.5 * self.dt)
+        self.v.addcmul_(self.frc, self.hdt_m)
         self._record()
 
     def step_langevin(self):  # BAOAB (the reference uses LangevinIntegrator(300 K, 1/ps), test_agbnp.py:37, 1dwc_benchmark.py:20)
-        self.v.add_(self.frc / self.mass, alpha=0.5 * self.dt)
+        self.v.addcmul_(self.frc, self.hdt_m)
         self.x.add_(self.v, alpha=0.5 * self.dt)
         self.noise.normal_(generator=None)
-        self.v.mul_(self.c1).add_(self.c2 * self.noise)
+        self.v.mul_(self.c1).addcmul_(self.c2, self.noise)
         self.x.add_(self.v, alpha=0.5 * self.dt)
         self.forces()
-        self.v.add_(self.frc / self.mass, alpha=0.5 * self.dt)
+        self.v.addcmul_(self.frc, self.hdt_m)
         self._record()
 
     def step_descent(self, gain=2.0e-6):  # crude minimiser: a capped move along the force
@@ -145,15 +154,12 @@ class DeviceMD:
     def energies(self, last=None):
         """(potential, kinetic) per recorded step as numpy arrays."""
         n = int(self.counter.item())
-        rows = self.log[:n].cpu().numpy()
+        pe, ke = self.log_pe[:n].cpu().numpy(), self.log_ke[:n].cpu().numpy()
         if last:
-            rows = rows[-last:]
-        return rows[:, 0], rows[:, 1]
+            pe, ke = pe[-last:], ke[-last:]
+        return pe, ke
 
     def temperature(self):
         ke = 0.5 * float((self.mass * self.v * self.v).sum())
         return 2.0 * ke / (3 * self.system.n * KB)
 
-
-def torch_cat(torch, a, b):
-    return torch.cat((a, b))
