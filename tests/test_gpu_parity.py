@@ -160,6 +160,40 @@ def test_soak_with_kicks_follows_the_oracle(gpu_required, systems, name, evaluat
             assert_close(e, f, eo, fo)
 
 
+@pytest.mark.parametrize("name", ["trpcage", "1dwc", "2clr"])
+def test_work_slot_rows_hold_every_subtree_exactly_once(gpu_required, systems, name):
+    """What the bookkeeping (packing in the GB launch, dealing in the chain-rule launch) hands to the next evaluation's
+    tree kernel, read back through the diagnostic accessor: every work slot holds 1..8 work items, every subtree appears
+    with all of its parts exactly once (a shared subtree as `parts` items, part numbers 0..parts-1), and the number of
+    rows is the forest count the engine reports."""
+    s = systems(name)
+    ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    lib = _lib.load()
+    lib.agbnp_debug_get_packing.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for step in range(4):
+        ctx.setPositions(s.jittered(step, sigma=0.004))
+        ctx.getState()
+        cap = 8 * s.nheavy + 64
+        order, start, nf = (C.c_int * cap)(), (C.c_int * cap)(), C.c_int(0)
+        assert lib.agbnp_debug_get_packing(ctx.kernel._h, order, cap, start, cap, C.byref(nf), None) == _lib.OK
+        nf = nf.value
+        start = np.array(start[:nf + 1])
+        items = np.array(order[:start[nf]])
+        counts = np.diff(start)
+        assert nf >= 1 and counts.min() >= 1 and counts.max() <= 8
+        subtree, part, parts = items & 0xFFFFFF, (items >> 24) & 3, ((items >> 26) & 3) + 1
+        assert part.max() < parts.max() + 1 and (part < parts).all()
+        assert sorted(set(subtree.tolist())) == list(range(s.nheavy))   # every subtree is somebody's work
+        seen = {}
+        for h, p, n in zip(subtree.tolist(), part.tolist(), parts.tolist()):
+            seen.setdefault(h, []).append((p, n))
+        for h, lst in seen.items():
+            n = lst[0][1]
+            assert all(x[1] == n for x in lst) and sorted(x[0] for x in lst) == list(range(n)), (h, lst)
+        if step > 0:  # (the first evaluation runs one subtree per slot)
+            assert nf == int(ctx.kernel.scalar("forests"))
+
+
 # ---- deterministic mode ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["1dwc", "trpcage"])
 def test_deterministic_mode_is_bit_reproducible(gpu_required, systems, name):
