@@ -337,6 +337,7 @@ void wire_args(agbnp_hip_context* c) {
     P.pack_enabled = no_pack ? 0 : (getenv("AGBNP_HIP_ITEMS_ALONE") ? 2 : 1);
     const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 1000;
     P.round_permille = std::max(100, round_permille);
+    P.replan_every = std::max(1, getenv("AGBNP_HIP_REPLAN_EVERY") ? atoi(getenv("AGBNP_HIP_REPLAN_EVERY")) : 4);
     const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 3;
     const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 550;
     // a full device has slot_cap = 2 x subtrees work slots: more parts per subtree than that could plan more work items
@@ -498,16 +499,20 @@ int upload_identity_packing(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
   HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
-  // [slots+3] how often a packed forest has overflowed so far (kept)
+  // [slots+3] how often a packed forest has overflowed so far (kept), [slots+4] the age of the packing in evaluations
+  // (huge: this one is no plan, the next evaluation's bookkeeping plans at once)
   std::vector<int> forest(nslots + 3);
   for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
   forest[nslots + 1] = c->nh;
   forest[nslots + 2] = c->nh;
+  const int no_plan = 1 << 20;
   if (c->d_forest.p == nullptr) {
     forest.push_back(0);
+    forest.push_back(no_plan);
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_forest.p + nslots + 4, &no_plan, sizeof(int), hipMemcpyHostToDevice));
   return AGBNP_HIP_OK;
 }
 

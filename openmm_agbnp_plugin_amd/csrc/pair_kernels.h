@@ -57,7 +57,9 @@ struct PairArgs {
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
-  int* pack_state;         // [1] persistent: how often a packed forest has overflowed (tightens the packing)
+  int* pack_state;         // [2] persistent: how often a packed forest has overflowed (tightens the packing); evaluations since
+                           // the packing in use was planned (huge = it is no plan: one subtree per slot)
+  int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 4)
   int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k
   int* forest_time;        // [slots + 1] predicted time of every forest (packing_role -> dealing_role), then: are they there
   int* rows;               // [kRowStride * slots] the work items of the NEXT evaluation in WORK-SLOT order (what the tree kernel

@@ -468,12 +468,25 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     imax[8 + (t >> 6)] = tot;
   }
   __syncthreads();
+  // The tree statistics are taken at every evaluation.  The PACKING is planned anew when the one in use is not a plan at
+  // all (a fresh context, or the one-subtree-per-slot fallback after an overflow: its age says so), when this evaluation
+  // overflowed, and otherwise at every replan_every-th evaluation: geometries change little between MD steps, a
+  // misprediction is caught by the overflow protocol whatever its age, and everything below this point is latency that
+  // small systems and version 0 (whose k_outputs launch lasts as long as this role) cannot hide.
+  const int age = P.pack_state[1];
+  const bool plan = overflow || age + 1 >= P.replan_every;
   if (t == 0) {
     P.status[kStatTotalNodes] = (imax[8] + imax[9]) + (imax[10] + imax[11]);
     P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
     P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
     P.pack_state[0] = level;
+    if (P.pack_enabled != 3) P.pack_state[1] = plan ? 0 : age + 1;
+    if (!plan) {
+      P.status[kStatForests] = P.nforests[0];       // (the packing stays)
+      P.forest_time[P.tree_slot_cap] = 2;           // tells dealing_role that there is nothing to deal
+    }
   }
+  if (!plan) return;
   // exclusive scan of the (count, weight) histogram (bins are in descending weight order): thread t owns bins 2t, 2t+1
   const unsigned long long h0 = comb[2 * t], h1 = comb[2 * t + 1];
   unsigned long long incl = h0 + h1;
@@ -618,7 +631,9 @@ __device__ void dealing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const int lent = (scratch_bytes - (int)kRoleScratchBytes) / (int)sizeof(int);
   if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
   const int nf = min(P.nforests[0], P.tree_slot_cap);
-  const bool ranked = P.forest_time[P.tree_slot_cap] != 0 && nf <= lent;
+  const int told = P.forest_time[P.tree_slot_cap];  // packing_role's word: 0 = forests without times, 1 = with times, 2 = no new packing
+  if (told == 2) return;
+  const bool ranked = told == 1 && nf <= lent;
   auto hand_over = [&](int f, int slot) {
     const int2 se = make_int2(P.forest_start[f], P.forest_start[f + 1]);
     const int4* src = reinterpret_cast<const int4*>(P.order + (size_t)kMaxItems * f);
