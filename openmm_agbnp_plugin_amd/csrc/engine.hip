@@ -88,7 +88,7 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_ftime, d_rows, d_forest, d_gb_items, d_db_items, d_pslot;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_ftime, d_rows, d_forest, d_gb_items, d_db_items, d_pslot, d_ctx_slot;
   int cus = 256;
   DevBuf<unsigned long long> d_nbmask;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
@@ -459,6 +459,8 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_hdr.alloc(nslots));
   HIP_TRY(c, hipMemset(c->d_hdr.p, 0, sizeof(SubtreeHeader) * nslots));
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
+  HIP_TRY(c, c->d_ctx_slot.alloc(std::max(n, 1)));
+  HIP_TRY(c, hipMemset(c->d_ctx_slot.p, 0, sizeof(int) * std::max(n, 1)));
   HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
   HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * 3 * (size_t)n));
@@ -710,12 +712,18 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   // the staging buffers start as zeros (allocation) and every output adapter hands them back as zeros
-  HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, st));
-  int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, st);
-  if (rc != AGBNP_HIP_OK) return rc;
-  HIP_TRY(c, launch_adapt_outputs(c->n, padded_num_atoms, d_atom_index, c->d_force_tmp.p, c->d_energy_tmp.p,
-                                  reinterpret_cast<unsigned long long*>(d_force_buffer), d_energy_buffer, energy_is_double, energy_slot, st));
-  return AGBNP_HIP_OK;
+  HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, c->d_ctx_slot.p, st));
+  // the output side is the engine's own last kernel: forces as fixed point at the context's slots, energy into its
+  // accumulator (the kernel arguments are captured by value at launch, so the targets are set for this evaluation only)
+  c->P.omm.force_fixed = reinterpret_cast<unsigned long long*>(d_force_buffer);
+  c->P.omm.padded = padded_num_atoms;
+  c->P.omm.ctx_slot = c->d_ctx_slot.p;
+  c->P.omm.energy_buffer = d_energy_buffer;
+  c->P.omm.energy_is_double = energy_is_double;
+  c->P.omm.energy_slot = energy_slot;
+  const int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, st);
+  c->P.omm = OpenmmTargets();
+  return rc;
 }
 
 int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {

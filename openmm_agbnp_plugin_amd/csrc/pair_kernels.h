@@ -8,7 +8,19 @@
 
 namespace agbnp {
 
+// Where an evaluation's results go when the caller is an OpenMM GPU context (agbnp_hip_execute_openmm): 2^32 fixed-point
+// force planes in the context's atom order and one slot of its energy accumulator.  force_fixed == nullptr: the plain
+// FP64 buffers of agbnp_hip_execute_device.
+struct OpenmmTargets {
+  unsigned long long* force_fixed = nullptr;  // [3 * padded] planes x | y | z
+  int padded = 0;
+  const int* ctx_slot = nullptr;              // [n] particle -> slot of the context's atom order (written by k_adapt_positions)
+  void* energy_buffer = nullptr;
+  int energy_is_double = 1, energy_slot = 0;
+};
+
 struct PairArgs {
+  OpenmmTargets omm;
   int n, nh;
   // ---- per-evaluation input
   const double* pos;  // [3n] caller's positions (nm), atom order

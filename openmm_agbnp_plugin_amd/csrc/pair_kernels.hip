@@ -345,7 +345,13 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         // role runs exactly once per evaluation, after the tree stage.
         const int node = P.status[kStatNodeOverflow], atom = P.status[kStatAtomOverflow], pack = P.status[kStatPackOverflow];
         if ((node | atom | pack) == 0) {
-          energy_out[0] += o0 + o1 + o2 + o3;
+          const double e = o0 + o1 + o2 + o3;
+          if (P.omm.force_fixed == nullptr)
+            energy_out[0] += e;
+          else if (P.omm.energy_buffer && P.omm.energy_is_double)  // an OpenMM context's accumulator (GVolReduceTree.cl:112)
+            static_cast<double*>(P.omm.energy_buffer)[P.omm.energy_slot] += e;
+          else if (P.omm.energy_buffer)
+            static_cast<float*>(P.omm.energy_buffer)[P.omm.energy_slot] += (float)e;
         } else {
           const int seq = P.status[kStatEvalSeq] - 1;  // k_prep counted this evaluation in
           P.status[kStatBadCount] += 1;
@@ -1445,6 +1451,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   if (i >= P.n) return;
   double fx = 0, fy = 0, fz = 0;
   const int h = P.a2h[i];
+  const int ctx_slot = P.omm.force_fixed ? P.omm.ctx_slot[i] : 0;  // (asked for with the rest, used at the end)
   if (h >= 0) {  // cavity + pseudo-volume gradients -> force
     fx = -P.gx[h];
     fy = -P.gy[h];
@@ -1456,6 +1463,15 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     fz += P.gb_fz[i] + P.db_fz[i];
   }
   if (evaluation_overflowed(P.status)) return;  // incomplete evaluation: withheld (see energy_role), the caller repeats it
+  if (P.omm.force_fixed) {
+    // an OpenMM context's force buffer: 64-bit fixed point, value * 2^32 rounded to nearest, three planes over the
+    // padded atom count in the context's atom order, integer atomics (GVolReduceTree.cl:117-119)
+    auto to_fixed = [](double f) { return (unsigned long long)(long long)rint(f * 4294967296.0); };
+    atomicAdd(&P.omm.force_fixed[ctx_slot], to_fixed(fx));
+    atomicAdd(&P.omm.force_fixed[ctx_slot + P.omm.padded], to_fixed(fy));
+    atomicAdd(&P.omm.force_fixed[ctx_slot + 2 * P.omm.padded], to_fixed(fz));
+    return;
+  }
   force_out[3 * i] += fx;
   force_out[3 * i + 1] += fy;
   force_out[3 * i + 2] += fz;
