@@ -138,6 +138,8 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  * prints at verbose_level > 0, ReferenceAGBNPKernels.cpp:333-352,459-462,519).
  * scalars: 0 E_vol1  1 E_vol2  2 E_atom (vdW + GB self)  3 E_GB pair  4 max subtree nodes
  *          5 total tree nodes  6 kernel variant  7 max local atoms  8 work slots (forests) planned for the next evaluation
+ *          9 1 if the range-limited pair stages run in row form (neighbour rows with a skin, rebuilt on the device when an
+ *            atom has moved more than half the skin; Reference mode, version 1)  10 builds of those rows so far
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii)
  *          4 / 5 nodes / local atoms of the overlap subtree rooted at the atom (tree shape, capacity planning) */

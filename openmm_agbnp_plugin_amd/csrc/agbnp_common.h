@@ -61,7 +61,7 @@ enum StatusWord {
   kStatMaxNodes = 3,       // max nodes of any subtree (diagnostic)
   kStatMaxAtoms = 4,       // max local atoms of any subtree (diagnostic)
   kStatCavityQueue = 5,    // work queue of k_tree_cavity (same)
-  kStatUnused6 = 6,
+  kStatRowOverflow = 6,    // a neighbour row of the row-form pair stages outgrew its stride (the host falls back to the tiles)
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
@@ -71,6 +71,7 @@ enum StatusWord {
   kStatStickyNode = 12,    // OR of the per-evaluation overflow words over those evaluations
   kStatStickyAtom = 13,
   kStatStickyPack = 14,
+  kStatStickyRow = 15,
   kStatWords = 16,
   kStatBadBitmap = 16,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
@@ -79,7 +80,9 @@ enum StatusWord {
 
 // kernel ids of one evaluation, in launch order (bench/profiling support)
 enum KernelId {
-  kKPrep = 0, kKTreeCavity, kKBornTiles, kKGbTiles, kKDbornTiles, kKTreePseudo, kKOutputs, kKernelCount
+  kKPrep = 0, kKTreeCavity, kKBornTiles, kKGbTiles, kKDbornTiles, kKTreePseudo, kKOutputs,
+  kKBornRows, kKDbornRows,  // row form of the two range-limited stages (take the place of the two tile kernels)
+  kKernelCount
 };
 
 }  // namespace agbnp

@@ -103,6 +103,16 @@ struct agbnp_hip_context {
   DevBuf<double4> d_aposq, d_prec, d_srec;
   DevBuf<double> d_ys;
   DevBuf<int> d_a2s;
+  // row form of the range-limited stages (pair_kernels.hip, k_rows)
+  DevBuf<unsigned> d_hperm, d_aperm, d_nlh, d_nla, d_bslice, d_cslice;
+  DevBuf<int> d_nlh_count, d_nla_count, d_nl_flag;
+  DevBuf<double> d_nl_ref, d_bw;
+  DevBuf<double4> d_rec_h, d_hrow, d_grec;
+  DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
+  bool rows_capable = false;   // the buffers above exist
+  bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
+  double skin = 0.1;           // nm; AGBNP_HIP_SKIN
+  int nlh_stride = 0, nla_stride = 0;  // entries reserved per list part
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
   DevBuf<SubtreeHeader> d_hdr;
@@ -126,6 +136,7 @@ struct agbnp_hip_context {
   int tree_slots[5] = {1280, 1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
+  int last_rows[2] = {0, 0};   // {stale flag, builds so far} of the row-form neighbour rows, as of the last harvest
   bool have_results = false;
   bool diagnostics = false;
 
@@ -296,6 +307,38 @@ void wire_args(agbnp_hip_context* c) {
   P.db_fz = c->d_dbf.p + 2 * row;
   P.db_wu = c->d_dbf.p + 3 * row;
   P.egb_part = c->d_egb_part.p;
+  {
+    // Row form (reference mode only: the fast mode cuts every stage at the cutoff and the deterministic mode fixes the
+    // order of its sums through the tiles' quantized totals)
+    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 &&
+                !(c->mode & (AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_DETERMINISTIC)) ? 1 : 0;
+    const double reach = kI4MaxA + c->skin;
+    P.nl_build2 = reach * reach;
+    P.nl_move2 = 0.25 * c->skin * c->skin;
+    P.nl_flag = c->d_nl_flag.p;
+    P.nl_ref = c->d_nl_ref.p;
+    P.hperm = c->d_hperm.p;
+    P.aperm = c->d_aperm.p;
+    P.hperm_n = (int)c->d_hperm.count;
+    P.aperm_n = (int)c->d_aperm.count;
+    P.nlh = c->d_nlh.p;
+    P.nla = c->d_nla.p;
+    P.nlh_count = c->d_nlh_count.p;
+    P.nla_count = c->d_nla_count.p;
+    P.nlh_stride = c->nlh_stride;
+    P.nla_stride = c->nla_stride;
+    P.bslice = c->d_bslice.p;
+    P.cslice = c->d_cslice.p;
+    P.rec_h = c->d_rec_h.p;
+    P.hrow = c->d_hrow.p;
+    P.bw = c->d_bw.p;
+    P.grec = c->d_grec.p;
+    const size_t tab = (size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1);
+    P.pw_a = c->d_pw.p;
+    P.pw_b = c->d_pw.p ? c->d_pw.p + tab : nullptr;
+    P.pwt_a = c->d_pw.p ? c->d_pw.p + 2 * tab : nullptr;
+    P.pwt_b = c->d_pw.p ? c->d_pw.p + 3 * tab : nullptr;
+  }
 
   TreeArgs& T = c->T;
   T.nh = c->nh;
@@ -354,6 +397,87 @@ void wire_args(agbnp_hip_context* c) {
 }
 
 int upload_identity_packing(agbnp_hip_context* c);
+
+// Buffers of the row form of the range-limited stages (k_rows): candidate orders sorted by type, neighbour rows at a fixed
+// stride, the power-form spline coefficients.  Systems it does not take (version 0, more radius types than the per-wave
+// table slices hold, more particles than the row buffers are sized for) simply keep the tile kernels.
+int allocate_rows(agbnp_hip_context* c) {
+  const int n = c->n, nh = c->nh;
+  constexpr int kRowCap = 3072;      // entries per row (part): no protein holds that many heavy atoms within 2.1 nm of one point
+  constexpr int kMaxTypes = 255;     // a row's type is one byte of its group's slice word
+  constexpr size_t kMaxTableBytes = 40 * 1024;  // the power-form table lives in LDS whole (1dwc: 8 x 6 types, 23 KB)
+  constexpr int kMaxParticles = 65536;
+  // (round 3, work in progress: the row form is exact and tested but not yet faster than the tiles on 1dwc -- every
+  // workgroup pays for its own copy of the table -- so it is opt-in until its persistent form is in)
+  const char* want = getenv("AGBNP_HIP_ROWS");
+  if (c->version != 1 || nh == 0 || n > kMaxParticles || want == nullptr || atoi(want) == 0) return AGBNP_HIP_OK;
+  if (c->lut.nscreened > kMaxTypes || c->lut.nscreener > kMaxTypes) return AGBNP_HIP_OK;
+  if ((size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1) * 2 * sizeof(double2) > kMaxTableBytes) return AGBNP_HIP_OK;
+  if (getenv("AGBNP_HIP_SKIN")) c->skin = std::min(1.0, std::max(0.0, atof(getenv("AGBNP_HIP_SKIN"))));
+  auto sorted_by_type = [&](int count, auto type_of) {
+    std::vector<unsigned> v;
+    for (int k = 0; k < count; k++) v.push_back((unsigned)k | ((unsigned)type_of(k) << 24));
+    std::stable_sort(v.begin(), v.end(), [](unsigned a, unsigned b) { return (a >> 24) < (b >> 24); });
+    while (v.size() % 64 != 0) v.push_back(~0u);
+    return v;
+  };
+  const std::vector<unsigned> hperm = sorted_by_type(nh, [&](int h) { return c->lut.type_screener[c->h2a[h]]; });
+  const std::vector<unsigned> aperm = sorted_by_type(n, [&](int a) { return c->lut.type_screened[a]; });
+  HIP_TRY(c, c->d_hperm.upload(hperm));
+  HIP_TRY(c, c->d_aperm.upload(aperm));
+  // a list part takes every kBornParts-th (kChainParts-th) chunk of 64 candidates: it can hold all of them, up to the cap
+  auto part_stride = [&](size_t candidates, int parts) { return std::max(128, std::min(64 * (int)((candidates / 64 + parts - 1) / parts), kRowCap)); };
+  c->nlh_stride = part_stride(hperm.size(), kBornParts);
+  c->nla_stride = part_stride(aperm.size(), kChainParts);
+  if (getenv("AGBNP_HIP_ROW_STRIDE")) c->nlh_stride = c->nla_stride = std::max(128, atoi(getenv("AGBNP_HIP_ROW_STRIDE")));  // (tests: force an overflow)
+  const size_t born_lists = (size_t)((n + kRowGroup - 1) / kRowGroup) * kBornParts, chain_lists = (size_t)((nh + kRowGroup - 1) / kRowGroup) * kChainParts;
+  HIP_TRY(c, c->d_nlh.alloc(born_lists * c->nlh_stride));
+  HIP_TRY(c, c->d_nla.alloc(chain_lists * c->nla_stride));
+  HIP_TRY(c, hipMemset(c->d_nlh.p, 0, sizeof(unsigned) * born_lists * c->nlh_stride));  // (entries beyond a list's length are read: valid indices)
+  HIP_TRY(c, hipMemset(c->d_nla.p, 0, sizeof(unsigned) * chain_lists * c->nla_stride));
+  {
+    std::vector<unsigned> bs((n + kRowGroup - 1) / kRowGroup, 0u), cs((nh + kRowGroup - 1) / kRowGroup, 0u);
+    for (int a = 0; a < n; a++) bs[a / kRowGroup] |= (unsigned)c->lut.type_screened[a] << (8 * (a % kRowGroup));
+    for (int h = 0; h < nh; h++) cs[h / kRowGroup] |= (unsigned)c->lut.type_screener[c->h2a[h]] << (8 * (h % kRowGroup));
+    HIP_TRY(c, c->d_bslice.upload(bs));
+    HIP_TRY(c, c->d_cslice.upload(cs));
+  }
+  HIP_TRY(c, c->d_nlh_count.alloc(born_lists));
+  HIP_TRY(c, c->d_nla_count.alloc(chain_lists));
+  HIP_TRY(c, hipMemset(c->d_nlh_count.p, 0, sizeof(int) * born_lists));
+  HIP_TRY(c, hipMemset(c->d_nla_count.p, 0, sizeof(int) * chain_lists));
+  const std::vector<int> flag = {1, 0};  // stale: the first evaluation builds the rows
+  HIP_TRY(c, c->d_nl_flag.upload(flag));
+  HIP_TRY(c, c->d_nl_ref.alloc(3 * (size_t)n));
+  HIP_TRY(c, hipMemset(c->d_nl_ref.p, 0xff, sizeof(double) * 3 * (size_t)n));  // NaN: every atom has "moved"
+  HIP_TRY(c, c->d_bw.alloc(n));
+  HIP_TRY(c, c->d_rec_h.alloc(nh));
+  HIP_TRY(c, c->d_hrow.alloc(nh));
+  HIP_TRY(c, c->d_grec.alloc(n));
+  HIP_TRY(c, hipMemset(c->d_bw.p, 0, sizeof(double) * n));
+  HIP_TRY(c, hipMemset(c->d_grec.p, 0, sizeof(double4) * n));
+  // Power form of the natural cubic spline on interval k (t in [0, 1)): S = c0 + c1 t + c2 t^2 + c3 t^3 with the same
+  // operations the tile kernels use on the knots {y, z = y2 dr^2 / 6} (spline_cubic in pair_kernels.hip)
+  const int nti = c->lut.nscreened, ntj = c->lut.nscreener, ni = kI4Nodes - 1;
+  const size_t tab = (size_t)nti * ntj * ni;
+  const double dr = kI4MaxA / (kI4Nodes - 1);
+  std::vector<double2> pw(4 * tab);
+  for (int ti = 0; ti < nti; ti++)
+    for (int tj = 0; tj < ntj; tj++)
+      for (int k = 0; k < ni; k++) {
+        const size_t o = ((size_t)ti * ntj + tj) * kI4Nodes + k;
+        const double y0 = c->lut.y[o], y1 = c->lut.y[o + 1], z0 = c->lut.y2[o] * dr * dr / 6.0, z1 = c->lut.y2[o + 1] * dr * dr / 6.0;
+        const double2 ca = make_double2(y0, (y1 - y0) - std::fma(2.0, z0, z1)), cb = make_double2(3.0 * z0, z1 - z0);
+        const size_t by_screened = ((size_t)ti * ntj + tj) * ni + k, by_screener = ((size_t)tj * nti + ti) * ni + k;
+        pw[by_screened] = ca;
+        pw[tab + by_screened] = cb;
+        pw[2 * tab + by_screener] = ca;
+        pw[3 * tab + by_screener] = cb;
+      }
+  HIP_TRY(c, c->d_pw.upload(pw));
+  c->rows_capable = true;
+  return AGBNP_HIP_OK;
+}
 
 int allocate_work(agbnp_hip_context* c) {
   const int n = c->n, nh = c->nh;
@@ -424,6 +548,10 @@ int allocate_work(agbnp_hip_context* c) {
     if (nh == 0) c->d_db_items.count = 0;
   }
 
+  {
+    int rc = allocate_rows(c);
+    if (rc != AGBNP_HIP_OK) return rc;
+  }
   HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
   {
@@ -535,6 +663,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   tl.used = 0;
   HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
+  if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
@@ -550,6 +679,13 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last) ...
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
+  if (s[kStatStickyRow] && !c->rows_disabled) {
+    // a neighbour row of the row-form pair stages outgrew its stride: the tile kernels from here on (other launches:
+    // a captured graph of this context is stale)
+    c->rows_disabled = true;
+    wire_args(c);
+    c->generation++;
+  }
   if (s[kStatStickyNode] || s[kStatStickyAtom]) {
     // ... and, if a single subtree outgrew the store, on the next larger capacity variant
     if (c->variant >= kGlobalVariant)
@@ -775,6 +911,8 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 6: *value = c->variant; break;
     case 7: *value = c->last_status[kStatMaxAtoms]; break;
     case 8: *value = c->last_status[kStatForests]; break;
+    case 9: *value = c->P.rows_on; break;        // 1: the range-limited pair stages run in row form
+    case 10: *value = c->last_rows[1]; break;    // builds of the neighbour rows so far
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;
@@ -874,8 +1012,8 @@ int agbnp_hip_set_profiling(agbnp_hip_context* c, int enabled) {
 int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
-  static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_born_tiles", "k_gb_tiles",
-                                            "k_dborn_tiles", "k_tree_pseudo", "k_outputs"};
+  static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_born_tiles", "k_gb_tiles", "k_dborn_tiles",
+                                            "k_tree_pseudo", "k_outputs",     "k_born_rows",  "k_dborn_rows"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 

@@ -96,7 +96,36 @@ struct PairArgs {
   double *db_fx, *db_fy, *db_fz, *db_wu;  // [n] chain-rule force by atom, W+U by heavy index (atomic sums)
   double* egb_part;        // [egb_parts]
   int egb_parts;
+  // ---- row form of the range-limited stages (k_rows, pair_kernels.hip): one wave gathers over the neighbour row of one
+  //      atom -- no pair is met that is out of reach, no sum leaves through an atomic.  Reference mode only; the tile
+  //      kernels stay for the fast and deterministic modes, for more radius types than the per-wave table slices hold,
+  //      and as the fallback when a neighbour row outgrows its stride.
+  int rows_on;             // 1: Born sums and chain rule in row form
+  double nl_build2;        // squared list radius: (reach + skin)^2
+  double nl_move2;         // (skin / 2)^2: an atom further than this from where it was when the rows were built makes them stale
+  int* nl_flag;            // [0] != 0: the rows are stale for THIS evaluation (k_prep sets, k_outputs clears; 1 on a fresh context)
+                           // [1] how often the rows have been built so far (diagnostic)
+  double* nl_ref;          // [3n] positions at the last build (NaN on a fresh context)
+  const unsigned* hperm;   // [hperm_n] heavy index | screener type << 24, sorted by (type, index), padded with ~0u to whole chunks of 64
+  const unsigned* aperm;   // [aperm_n] atom | screened type << 24, sorted by (type, index), same padding
+  int hperm_n, aperm_n;
+  unsigned* nlh;           // [groups of 4 atoms x kBornParts][nlh_stride] heavy neighbours of the group, entries as in hperm
+  int* nlh_count;          // [groups x kBornParts]
+  int nlh_stride;
+  unsigned* nla;           // [groups of 4 heavy atoms x kChainParts][nla_stride] neighbours of any kind, entries as in aperm
+  int* nla_count;          // [groups x kChainParts]
+  int nla_stride;
+  double4* rec_h;          // [nh] {x, y, z, 1 / V_vdw} by heavy index (k_prep): what a Born row gathers of a neighbour (+ its self volume)
+  double4* hrow;           // [nh] {x, y, z, atom | screener type << 24} by heavy index (k_prep): a chain-rule row's own record
+  double* bw;              // [n] brw + bru by atom: the GB stage adds alpha_i (diagonal tile) + beta_i * (Y of the tile) with atomics
+  double4* grec;           // [n] {G_x, G_y, G_z, -} of the Born rows: G_i = sum_j (r_j - r_i) s_j Q'_ij / d
+  const unsigned *bslice, *cslice;  // [groups] the table slices (= types) of a group's four row atoms, one byte each (Born / chain-rule groups)
+  const double2 *pw_a, *pw_b;    // power-form spline coefficients {c0, c1}, {c2, c3} by [screened][screener][15 intervals]
+  const double2 *pwt_a, *pwt_b;  // the same by [screener][screened][15]
 };
+constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
+constexpr int kChainParts = 4;  // waves (list parts) per group of chain-rule rows
+constexpr int kBornParts = 4;   // ... per group of Born rows
 
 // Optional per-kernel timing: an event is recorded on the evaluation's stream in front of every kernel
 // (and one after the last); durations are read back after the stream has been synchronised.

@@ -224,9 +224,20 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
         P.abox[6 * (i >> 6) + 3 + d] = hi[d];
       }
   }
+  if (P.rows_on) {
+    // Row form of the range-limited stages: its neighbour rows were built with a skin; they stay exact as long as no atom
+    // is further than half the skin from where it was then.  (NaN reference positions -- a fresh context -- fail the test.)
+    bool moved = false;
+    if (i < P.n) {
+      const double rx = P.pos[3 * i] - P.nl_ref[3 * i], ry = P.pos[3 * i + 1] - P.nl_ref[3 * i + 1], rz = P.pos[3 * i + 2] - P.nl_ref[3 * i + 2];
+      moved = !(fma(rz, rz, fma(ry, ry, rx * rx)) <= P.nl_move2);
+    }
+    if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&P.nl_flag[0], 1);
+  }
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
+  if (P.rows_on) P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
   P.gb_fx[i] = 0.0;  // GB sums arrive through atomics
   P.gb_fy[i] = 0.0;
   P.gb_fz[i] = 0.0;
@@ -246,6 +257,10 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.sv_vdw[h] = 0.0;
     P.sv_large[h] = 0.0;
     P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
+    if (P.rows_on) {
+      P.rec_h[h] = make_double4(x, y, z, P.inv_vol_h[h]);
+      P.hrow[h] = make_double4(x, y, z, __hiloint2double(0, i | (P.ameta[i].y << 24)));
+    }
   }
 }
 
@@ -268,6 +283,11 @@ __device__ __forceinline__ BornRadius born_radius(double inv_rvdw, double qsum) 
   r.br = 1. / r.inv_br;
   return r;
 }
+// bw_i = brw_i + bru_i with bru_i = -(1/4pi) k (q_i^2 + Y_i B_i) f'_i (ReferenceAGBNPKernels.cpp:524-542) is linear in the GB
+// stage's Y sum: bw_i = alpha_i + beta_i Y_i.  With the row form of the chain rule the GB tiles add alpha_i (once, the
+// diagonal tile) and beta_i * (their share of Y_i) straight into bw_i, so that a chain-rule row gathers ONE word per neighbour.
+__device__ __forceinline__ double bw_beta(const BornRadius& r) { return -(1. / (4. * kPi)) * kDielFactor * r.br * r.fp; }
+__device__ __forceinline__ double bw_alpha(const BornRadius& r, double brw, double q) { return brw - (1. / (4. * kPi)) * kDielFactor * (q * q) * r.fp; }
 
 // ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
 // A workgroup of four waves owns one tile (I <= J).  In every wave lane l keeps atom i = 64 I + l and its sums in
@@ -344,7 +364,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         // queued or graph-replayed evaluations cannot lose an overflow to the next evaluation's k_prep.  This
         // role runs exactly once per evaluation, after the tree stage.
         const int node = P.status[kStatNodeOverflow], atom = P.status[kStatAtomOverflow], pack = P.status[kStatPackOverflow];
-        if ((node | atom | pack) == 0) {
+        const int rowo = P.status[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
+        if ((node | atom | pack | rowo) == 0) {
           const double e = o0 + o1 + o2 + o3;
           if (P.omm.force_fixed == nullptr)
             energy_out[0] += e;
@@ -358,13 +379,14 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyNode] |= node;
           P.status[kStatStickyAtom] |= atom;
           P.status[kStatStickyPack] |= pack;
+          P.status[kStatStickyRow] |= rowo;
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
       }
 }
 
 __device__ __forceinline__ bool evaluation_overflowed(const int* __restrict__ status) {
-  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow]) != 0;
+  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow]) != 0;
 }
 
 // Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes
@@ -759,6 +781,14 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   // the slots of its three blocks now
   // (unconditional loads: a choice here would have to wait for them)
   const int ysa = P.a2s[min(64 * I0 + lane, n - 1)], ysc = P.a2s[min(64 * I0 + 64 + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];
+  double beta_a = 0.0, beta_c = 0.0, beta_j = 0.0;  // row form of the chain rule: wave 3 (idle here) turns its Y totals into bw shares
+  if (!kCut && P.rows_on && wave == 3) {
+    const int ka = min(64 * I0 + lane, n - 1), kc = min(64 * I0 + 64 + lane, n - 1), kj = min(64 * J + lane, n - 1);
+    const double ra = inv_rvdw[ka], rc = inv_rvdw[kc], rj = inv_rvdw[kj], pa = born_part[ka], pc = born_part[kc], pj = born_part[kj];
+    beta_a = bw_beta(born_radius(ra, pa));
+    beta_c = bw_beta(born_radius(rc, pc));
+    beta_j = bw_beta(born_radius(rj, pj));
+  }
   if (wave < 3) {  // wave 0 prepares block J, waves 1 and 2 the two i blocks
     const int a = 64 * (wave == 0 ? J : I0 + wave - 1) + lane;
     const bool va = a < n;
@@ -854,9 +884,15 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
   const bool det = P.det != 0;  // deterministic mode: a tile's totals are rounded to the sums' quantum (device_math.h)
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (ia < n) hbm_add(wave == 3 ? &P.ys[ysa] : &row[ia], quantize(fold(wave), qs, det));
-  if (ic < n) hbm_add(wave == 3 ? &P.ys[ysc] : &row[ic], quantize(fold(4 + wave), qs, det));
-  if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(fold(8 + wave), qs, det));
+  if (!kCut && P.rows_on && wave == 3) {  // (the row form never runs in the deterministic mode)
+    if (ia < n) hbm_add(&P.bw[ia], beta_a * fold(3));
+    if (ic < n) hbm_add(&P.bw[ic], beta_c * fold(7));
+    if (j < n) hbm_add(&P.bw[j], beta_j * fold(11));
+  } else {
+    if (ia < n) hbm_add(wave == 3 ? &P.ys[ysa] : &row[ia], quantize(fold(wave), qs, det));
+    if (ic < n) hbm_add(wave == 3 ? &P.ys[ysc] : &row[ic], quantize(fold(4 + wave), qs, det));
+    if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(fold(8 + wave), qs, det));
+  }
   if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
   PAIR_STAMP(1, 3);
 }
@@ -1031,6 +1067,13 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   }
   PAIR_STAMP_WHERE(1, item);
   const int ysi = P.a2s[min(64 * I + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];  // (the Y sums leave by pair-order slot, see gb_strip)
+  double beta_i = 0.0, beta_j = 0.0;  // row form of the chain rule: see gb_strip
+  if (!kCut && P.rows_on && wave == 3) {
+    const int ki = min(64 * I + lane, n - 1), kj = min(64 * J + lane, n - 1);
+    const double ri = inv_rvdw[ki], rj = inv_rvdw[kj], pi = born_part[ki], pj = born_part[kj];
+    beta_i = bw_beta(born_radius(ri, pi));
+    beta_j = bw_beta(born_radius(rj, pj));
+  }
   // Born radii from the finished descreening sums (every tile recomputes them for its 128 atoms: a few dozen
   // flops per atom against 4096 pair evaluations, and one kernel launch less per evaluation):
   // wave 0 prepares block J, wave 1 block I
@@ -1059,6 +1102,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
         e_atom[a] = al / bh3 + kDielFactor * pa.w * pa.w * bra.inv_br;
         brw[a] = brw_a;
         P.srec[ysi] = make_double4(bra.br, bra.fp, brw_a, pa.w);  // the chain-rule stage's copy, by slot (a = 64 I + lane here)
+        if (!kCut && P.rows_on) hbm_add(&P.bw[a], bw_alpha(bra, brw_a, pa.w));
       }
     }
   }
@@ -1124,8 +1168,13 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int i = 64 * I + lane, j = 64 * J + lane;
   const bool det = P.det != 0;
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (i < n) hbm_add(wave == 3 ? &P.ys[ysi] : &row[i], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
-  if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
+  if (!kCut && P.rows_on && wave == 3) {
+    if (i < n) hbm_add(&P.bw[i], beta_i * tile_sums_fold(s_sums, 3, lane));
+    if (j < n) hbm_add(&P.bw[j], beta_j * tile_sums_fold(s_sums, 7, lane));
+  } else {
+    if (i < n) hbm_add(wave == 3 ? &P.ys[ysi] : &row[i], quantize(tile_sums_fold(s_sums, wave, lane), qs, det));
+    if (j < n) hbm_add(wave == 3 ? &P.ys[ysj] : &row[j], quantize(tile_sums_fold(s_sums, 4 + wave, lane), qs, det));
+  }
   if (threadIdx.x == 0) egb_part[blockIdx.x - 1] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
   PAIR_STAMP(1, 3);
 }
@@ -1426,6 +1475,298 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   PAIR_STAMP(2, 3);
 }
 
+// ---- row form of the two range-limited stages ------------------------------------------------------------------------
+// The tile kernels above meet every pair of two 64-atom blocks; on a protein of a few thousand atoms a third of those pairs
+// lie inside the tables' 2 nm reach, and a wave pays for all of them.  The row form meets (almost) only pairs in reach and
+// needs no atomics and no second look-up per pair:
+//
+//   Born row of atom a (every atom):      beta-sum_a = sum_b s_b Q_{t(a) t'(b)}(d)          b heavy, b != a, d < 2 nm
+//                                          G_a       = sum_b (r_b - r_a) s_b Q'_{t(a) t'(b)}(d) / d
+//   chain-rule row of heavy atom a:       (W+U)_a    = sum_b bw_b Q_{t(b) t'(a)}(d)           b of any kind, b != a, d < 2 nm
+//                                          H_a       = sum_b (r_b - r_a) bw_b Q'_{t(b) t'(a)}(d) / d
+//   chain-rule force:                      F_a      += bw_a G_a + s_a H_a                     (H_a = 0 for a hydrogen)
+//
+// which is the reference's loop (ReferenceAGBNPKernels.cpp:435-449,555-586) with its two force updates sorted by the atom
+// they land on: force[i] += w with w = dist bw_i s_j Q'/d sums up to bw_i G_i, force[j] -= w to s_j H_j.  G does not depend
+// on bw, so it rides in the Born rows, where the same table entry is being looked up anyway: each stage looks a pair up
+// once, as the symmetric tiles do.
+//
+// A GROUP = kRowGroup consecutive row atoms (bonded neighbours, a fraction of a nm apart) shares one neighbour list: a lane
+// gathers ONE neighbour record per step (list entry -> {x, y, z, .} and weight from memory: the vector-memory pipe is what
+// a one-row-per-wave form is bound by) and meets it with the group's row atoms, which are wave-uniform and live in scalar
+// registers.  The list of a group is cut into parts, one wave each (the parts take the 64-candidate chunks of the
+// candidate order in turn); the sums of a wave meet in a transposing butterfly, those of the parts in LDS, and leave
+// through plain stores.  Spline entries in 32-byte power form come from the slices of the group's row types in LDS.
+//
+// Neighbour lists: entries (index | type << 24) of every candidate within reach + skin of ANY row atom of the group, in
+// the order of a static candidate list sorted by type -- the lanes of a step then mostly read consecutive entries of one
+// table row: distinct LDS banks.  The lists are rebuilt, on the device and by the waves that own them, in the evaluation
+// whose k_prep found an atom further than skin / 2 from where it was at the last build (the lists of both kinds in the
+// Born launch, so both see the same positions and an overflowing list is known before the energy is added up);
+// d < 2 nm is still tested per pair, so the sums hold exactly the reference's pairs.
+constexpr int kRowIntervals = kI4Nodes - 1;
+
+// a value every lane holds alike, moved to scalar registers (the row atoms of a group: VALU operands, no vector registers)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int kCtrl>
+__device__ __forceinline__ double dpp_move(double v) {  // lane <- the lane that the DPP control names (bound_ctrl: no "old" operand)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_move<0xB1>(v); }                   // quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_move<0x4E>(v); }                   // quad_perm [2, 3, 0, 1]
+__device__ __forceinline__ double lane_xor4(double v) { return dpp_move<0x1B>(dpp_move<0x141>(v)); }  // row_half_mirror, then quad_perm [3, 2, 1, 0]
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_move<0x128>(v); }                  // row_ror:8
+
+struct RowAtoms {  // wave-uniform (scalar registers): the row atoms of a group
+  double x[kRowGroup], y[kRowGroup], z[kRowGroup];
+  int self[kRowGroup];   // index of the row atom in the candidates' numbering (never met: -1 for a row that is no candidate)
+  int rows;              // valid rows (the last group may be short)
+};
+
+template <bool kChain>
+__device__ __forceinline__ RowAtoms row_atoms(const PairArgs& P, int group) {
+  RowAtoms A;
+  const int nrows = kChain ? P.nh : P.n;
+  A.rows = min(kRowGroup, nrows - kRowGroup * group);
+  const double4* __restrict__ pos = kChain ? static_cast<const double4*>(P.hrow) : static_cast<const double4*>(P.aposq);
+  double4 pr[kRowGroup];
+  int self[kRowGroup];
+#pragma unroll
+  for (int r = 0; r < kRowGroup; r++) {  // (all in flight together)
+    const int row = min(kRowGroup * group + r, nrows - 1);
+    pr[r] = pos[row];
+    self[r] = kChain ? 0 : P.a2h[row];  // (-1 for a hydrogen: no candidate has that index)
+  }
+#pragma unroll
+  for (int r = 0; r < kRowGroup; r++) {
+    const bool there = r < A.rows;
+    A.x[r] = uniform(there ? pr[r].x : 1e30);  // a row that does not exist is out of everybody's reach
+    A.y[r] = uniform(pr[r].y);
+    A.z[r] = uniform(pr[r].z);
+    A.self[r] = uniform(!there ? -1 : kChain ? (__double2loint(pr[r].w) & 0xffffff) : self[r]);
+  }
+  return A;
+}
+
+// builds one part of a group's list: the candidates perm[64 c + lane] of chunks c = part, part + parts, ... (index |
+// type << 24, ~0u = padding), their records rec[index] = {x, y, z, .}; returns the number of entries (may exceed stride)
+__device__ __forceinline__ int row_build(const RowAtoms& A, const unsigned* __restrict__ perm, int np, int part, int parts,
+                                         const double4* __restrict__ rec, double build2, unsigned* __restrict__ list, int stride, int lane) {
+  int cnt = 0;
+  for (int base = 64 * part; base < np; base += 64 * parts) {
+    const unsigned e = perm[base + lane];
+    const double4 r = rec[e != ~0u ? (int)(e & 0xffffffu) : 0];
+    double dmin = 1e300;
+#pragma unroll
+    for (int q = 0; q < kRowGroup; q++) {
+      const double dx = r.x - A.x[q], dy = r.y - A.y[q], dz = r.z - A.z[q];
+      dmin = fmin(dmin, fma(dz, dz, fma(dy, dy, dx * dx)));
+    }
+    const bool ok = e != ~0u && dmin < build2;
+    const unsigned long long m = __ballot(ok);
+    const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (ok && at < stride) list[at] = e;
+    cnt += __popcll(m);
+  }
+  return cnt;
+}
+
+template <bool kChain>
+__global__ __launch_bounds__(256) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
+  constexpr int R = kRowGroup, NP = kChain ? kChainParts : kBornParts, G = 4 / NP;  // G groups of NP waves per workgroup
+  static_assert(4 % NP == 0 && R == 4, "a workgroup of four waves holds whole groups; the butterfly below folds 16 sums");
+  extern __shared__ double2 s_dyn[];
+  __shared__ double s_comb[4][4][4 * R];  // [wave][16-lane row of the wave][sum]
+  int blk = blockIdx.x;
+  if (kChain) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles)
+    if (blk == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
+    if (blk == 1) return dealing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
+    blk -= 2;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int born_groups = (P.n + R - 1) / R, chain_groups = (P.nh + R - 1) / R;
+  const int born_blocks = (born_groups * kBornParts + 3) >> 2, chain_blocks = (chain_groups * kChainParts + 3) >> 2;
+  const int stale = P.nl_flag[0];
+  if (!kChain && blk >= born_blocks) {
+    // The chain-rule lists are built here, in the Born launch, by workgroups that exit at once in an evaluation whose
+    // lists are still good.
+    if (!stale) return;
+    const int sub = (blk - born_blocks) * 4 + wave;
+    if (sub >= chain_groups * kChainParts) return;
+    const int g = sub / kChainParts, part = sub - g * kChainParts;
+    const RowAtoms A = row_atoms<true>(P, g);
+    const int cnt = row_build(A, P.aperm, P.aperm_n, part, kChainParts, static_cast<const double4*>(P.aposq), P.nl_build2,
+                              P.nla + (size_t)sub * P.nla_stride, P.nla_stride, lane);
+    if (lane == 0) {
+      P.nla_count[sub] = min(cnt, P.nla_stride);
+      if (cnt > P.nla_stride) P.status[kStatRowOverflow] = 1;
+    }
+    return;
+  }
+  if (kChain && blk >= chain_blocks) {  // hydrogens screen nobody: their chain-rule force is bw_a G_a
+    const int a = (blk - chain_blocks) * 256 + (int)threadIdx.x;
+    if (a < P.n && P.a2h[a] < 0) {
+      const double4 g = P.grec[a];
+      const double bwa = P.bw[a];
+      P.db_fx[a] = bwa * g.x;
+      P.db_fy[a] = bwa * g.y;
+      P.db_fz[a] = bwa * g.z;
+    }
+    return;
+  }
+  PAIR_STAMP((kChain ? 2 : 0), 0);
+  const int sub = blk * 4 + wave;  // (group, part)
+  const int ngroups = kChain ? chain_groups : born_groups;
+  const bool active = sub / NP < ngroups;
+  const int group = min(sub / NP, ngroups - 1), part = sub % NP;
+  const int stride = kChain ? P.nla_stride : P.nlh_stride;
+  const unsigned* list = (kChain ? P.nla : P.nlh) + (size_t)(active ? sub : 0) * stride;  // (not restrict: a build rewrites it)
+  // Everything that does not depend on anything is asked for at once: the row atoms, the types of their table slices, the
+  // length of the list and its first two steps (the lists start out zeroed: an entry beyond the length is a valid index).
+  const int listed = active ? (kChain ? P.nla_count : P.nlh_count)[sub] : 0;
+  const unsigned slices = (kChain ? P.cslice : P.bslice)[group];  // one byte per row
+  unsigned e1 = list[lane], e2 = list[64 + lane];
+  // the whole table goes to LDS ({c0, c1} of every entry, then {c2, c3}): which slices the group needs is not waited for
+  const int ne = (kChain ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice
+  const int tab = P.nti * P.ntj * kRowIntervals;            // ... of the table
+  double2* const s_tab = s_dyn;
+  {
+    const double2* __restrict__ ga = kChain ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
+    for (int base = 0; base < 2 * tab; base += 256 * 4) {
+      double2 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = ga[min(base + 256 * q + (int)threadIdx.x, 2 * tab - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (base + 256 * q + (int)threadIdx.x < 2 * tab) s_tab[base + 256 * q + threadIdx.x] = v[q];
+    }
+  }
+  const RowAtoms A = row_atoms<kChain>(P, group);
+  PAIR_STAMP_WAIT((kChain ? 2 : 0), 7, "vmcnt(0) lgkmcnt(0)");  // the row atoms are here
+  int slice_at[R];  // first entry of the row's slice
+#pragma unroll
+  for (int r = 0; r < R; r++) slice_at[r] = uniform((int)((slices >> (8 * r)) & 0xffu) * ne);
+  int count = listed;
+  if (!kChain && stale) {
+    count = active ? row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2,
+                               P.nlh + (size_t)sub * stride, stride, lane) : 0;
+    if (active && lane == 0) {
+      P.nlh_count[sub] = min(count, stride);
+      if (count > stride) P.status[kStatRowOverflow] = 1;
+      if (sub == 0) P.nl_flag[1] += 1;  // (builds so far: agbnp_hip_get_scalar)
+    }
+    if (active && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
+      const int a = kRowGroup * group + lane;
+      P.nl_ref[3 * a] = P.pos[3 * a], P.nl_ref[3 * a + 1] = P.pos[3 * a + 1], P.nl_ref[3 * a + 2] = P.pos[3 * a + 2];
+    }
+    count = min(count, stride);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
+    e1 = list[lane], e2 = list[64 + lane];
+  }
+  const double4* __restrict__ rec = kChain ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
+  const double* __restrict__ wsrc = kChain ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
+  const int nsteps = (count + 63) >> 6;
+  // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
+  // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
+  double4 r1 = rec[e1 & 0xffffffu];
+  double w1 = wsrc[e1 & 0xffffffu];
+  __syncthreads();  // the slices are in LDS
+  PAIR_STAMP((kChain ? 2 : 0), 8);
+  double acc[4 * R];
+#pragma unroll
+  for (int q = 0; q < 4 * R; q++) acc[q] = 0.0;
+  PAIR_STAMP_WAIT((kChain ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
+#ifdef AGBNP_PAIR_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(kChain ? 2 : 0)][blockIdx.x][6] = (unsigned)count, g_pair_log[(kChain ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
+#endif
+  const int last = stride - 1;
+  constexpr double kPerNode = (kI4Nodes - 1) / kI4MaxA;
+  for (int k = 0; k < nsteps; k++) {
+    const unsigned e = e1;
+    const double4 rb = r1;
+    const double wb = w1;
+    e1 = e2;
+    r1 = rec[e1 & 0xffffffu];
+    w1 = wsrc[e1 & 0xffffffu];
+    e2 = list[min(64 * (k + 2) + lane, last)];
+    const int b = (int)(e & 0xffffffu);
+    const int tent = (int)(e >> 24) * kRowIntervals;
+    const double w = (kChain ? wb : wb * rb.w) * kPerNode;  // bw_b, or s_b = selfvol_b / V_b (times the table's d(t)/d(d))
+    const double range2 = 64 * k + lane < count ? P.range2 : -1.0;  // (a lane beyond the list meets nobody)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
+      const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+      if (d2 < range2 && b != A.self[r]) {
+        const double rinv = rsqrt_pos(d2);
+        const double u = (d2 * rinv) * kPerNode;
+        const int ent = slice_at[r] + tent + (int)u;
+        const double t = __builtin_amdgcn_fract(u);
+        const double2 ca = s_tab[ent], cb = s_tab[ent + tab];
+        // value and derivative of c0 + c1 t + c2 t^2 + c3 t^3 in five operations
+        const double b2 = fma(cb.y, t, cb.x), b1 = fma(b2, t, ca.y);
+        const double val = fma(b1, t, ca.x), der = fma(fma(cb.y, t, b2), t, b1);
+        acc[4 * r] = fma(w, val, acc[4 * r]);
+        const double g = w * der * rinv;
+        acc[4 * r + 1] = fma(dx, g, acc[4 * r + 1]);
+        acc[4 * r + 2] = fma(dy, g, acc[4 * r + 2]);
+        acc[4 * r + 3] = fma(dz, g, acc[4 * r + 3]);
+      }
+    }
+  }
+  PAIR_STAMP((kChain ? 2 : 0), 2);
+  // 16 sums per lane -> one per lane and 16-lane row: four transposing butterfly stages (a lane keeps the half of the sums
+  // that its bit of the stage selects and adds its partner's copy of them; DPP moves, no LDS)
+  {
+    const bool u0 = lane & 1, u1 = lane & 2, u2 = lane & 4, u3 = lane & 8;
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = (u0 ? acc[q + 8] : acc[q]) + lane_xor1(u0 ? acc[q] : acc[q + 8]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = (u1 ? acc[q + 4] : acc[q]) + lane_xor2(u1 ? acc[q] : acc[q + 4]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) acc[q] = (u2 ? acc[q + 2] : acc[q]) + lane_xor4(u2 ? acc[q] : acc[q + 2]);
+    acc[0] = (u3 ? acc[1] : acc[0]) + lane_xor8(u3 ? acc[0] : acc[1]);
+    // bit s of the lane chose the halves of stage s: the lane's sum is number bit-reversed(lane & 15); the unit of the
+    // value sums goes back in (w carried the table's d(t)/d(d) for the derivatives)
+    const int q = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+    s_comb[wave][lane >> 4][q] = (q & 3) == 0 ? acc[0] * (1.0 / kPerNode) : acc[0];
+  }
+  __syncthreads();
+  PAIR_STAMP((kChain ? 2 : 0), 10);
+  // one thread per row of the workgroup: the sums of the parts and of their 16-lane rows, then the row's results
+  const int t = threadIdx.x;
+  if (t >= G * R) return;
+  const int gw = t / R, r = t % R;                 // group of the workgroup, row of the group
+  const int tgroup = (blk * 4 + gw * NP) / NP;
+  const int nrows = kChain ? P.nh : P.n;
+  const int row = R * tgroup + r;
+  if (tgroup >= ngroups || row >= nrows) return;
+  double sv = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int p = 0; p < NP; p++)
+    for (int lr = 0; lr < 4; lr++) {
+      const double* c = s_comb[gw * NP + p][lr] + 4 * r;
+      sv += c[0], sx += c[1], sy += c[2], sz += c[3];
+    }
+  if (!kChain) {
+    P.born_part[row] = sv;
+    P.grec[row] = make_double4(sx, sy, sz, 0.0);
+  } else {
+    const int atom = __double2loint(static_cast<const double4*>(P.hrow)[row].w) & 0xffffff;
+    const double sa = P.sv_vdw[row] * P.inv_vol_h[row], bwa = P.bw[atom];
+    const double4 g = P.grec[atom];
+    P.db_wu[row] = sv;
+    P.db_fx[atom] = fma(bwa, g.x, sa * sx);
+    P.db_fy[atom] = fma(bwa, g.y, sa * sy);
+    P.db_fz[atom] = fma(bwa, g.z, sa * sz);
+  }
+  PAIR_STAMP((kChain ? 2 : 0), 3);
+}
+
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
 //   blocks [0, nfb)  forces: F = -grad(tree) + sum of the pair partial rows, ADDED to the caller's buffer
 //   block  nfb       energy: fixed-order sum of every energy partial, ADDED to the caller's scalar
@@ -1448,6 +1789,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   }
   const int t = threadIdx.x;
   const int i = blk * 256 + t;
+  if (P.rows_on && i == 0) P.nl_flag[0] = 0;  // this evaluation's neighbour rows are up to date (k_prep of the next one tests again)
   if (i >= P.n) return;
   double fx = 0, fy = 0, fz = 0;
   const int h = P.a2h[i];
@@ -1507,6 +1849,24 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 3 * 64 * sizeof(double2)));
     if (e != hipSuccess) return e;
+  }
+  if (P.rows_on) {  // row form of the two range-limited stages
+    auto gb = k_gb_tiles<false, false>;
+    const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
+    const int born_blocks = (born_groups * kBornParts + 3) / 4, chain_blocks = (chain_groups * kChainParts + 3) / 4;
+    const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
+    const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
+    AGBNP_MARK(kKBornRows);
+    hipLaunchKernelGGL(k_rows<false>, dim3(born_blocks + chain_blocks), dim3(256), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    AGBNP_CHECK_LAUNCH();
+    AGBNP_MARK(kKGbTiles);
+    hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+    AGBNP_CHECK_LAUNCH();
+    AGBNP_MARK(kKDbornRows);
+    hipLaunchKernelGGL(k_rows<true>, dim3(2 + chain_blocks + (P.n + 255) / 256), dim3(256), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    AGBNP_CHECK_LAUNCH();
+    return hipSuccess;
   }
   AGBNP_MARK(kKBornTiles);
   if (P.db_items_count > 0)

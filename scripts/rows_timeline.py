@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box, -DAGBNP_PAIR_STAMPS build): per-workgroup timeline of the two row-form kernels (k_rows) of one
+evaluation.  Usage: AGBNP_HIP_LIBRARY=build/diag/libagbnp_hip_pstamps.so python scripts/rows_timeline.py [system]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import openmm_agbnp_plugin_amd as P
+from openmm_agbnp_plugin_amd import _lib
+
+name = sys.argv[1] if len(sys.argv) > 1 else "1dwc"
+s = P.load_system(name)
+ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+lib = _lib.load()
+for k in range(6):
+    ctx.setPositions(s.jittered(k)); ctx.getState()
+SLOTS = 4096
+buf = (C.c_ulonglong * (3 * SLOTS * 12))()
+lib.agbnp_debug_pair_log(buf)
+log = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(3, SLOTS, 12)
+for kern, nm in ((0, "k_rows<born>"), (2, "k_rows<chain>")):
+    L = log[kern]
+    ok = (L[:, 0] > 0) & (L[:, 3] >= L[:, 0])
+    latest = L[ok, 0].max()
+    ok &= L[:, 0] > latest - 20000
+    W = L[ok]
+    t0 = W[:, 0].min()
+    us = lambda v: (v - t0) / 100.0
+    print(f"== {nm}: {int(ok.sum())} working workgroups; entries from 0 to {us(W[:, 0]).max():.2f} us; last end {us(W[:, 3]).max():.2f} us")
+    phases = (("entry -> row atoms", W[:, 7] - W[:, 0]), ("-> slices in LDS (barrier)", W[:, 8] - W[:, 7]), ("-> first records", W[:, 1] - W[:, 8]),
+              ("loop", W[:, 2] - W[:, 1]), ("butterfly + barrier", W[:, 10] - W[:, 2]), ("results", W[:, 3] - W[:, 10]), ("lifetime", W[:, 3] - W[:, 0]))
+    for pn, v in phases:
+        v = v / 100.0
+        print(f"   {pn:28s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
+    steps = W[:, 9]
+    loop = (W[:, 2] - W[:, 1]) / 100.0
+    print(f"   entries per part: mean {W[:, 6].mean():.0f} max {W[:, 6].max():.0f}; steps mean {steps.mean():.1f}; us per step {np.median(loop / np.maximum(steps, 1)):.3f}")
+    end = us(W[:, 3])
+    print(f"   ends: p10 {np.percentile(end, 10):.2f} p50 {np.median(end):.2f} p90 {np.percentile(end, 90):.2f} max {end.max():.2f}")

@@ -838,3 +838,71 @@ def test_absurd_density_is_a_clean_capacity_error(gpu_required):
     sysm = P.AGBNPSystem("blob", pos, np.full(n, 0.2), np.full(n, 48.9), np.full(n, -1.0), np.zeros(n), np.zeros(n, dtype=np.int32))
     with pytest.raises(P.OpenMMException, match="exceeds the largest supported capacity"):
         gpu_eval(sysm, 0)
+
+
+# ---- row form of the range-limited pair stages (neighbour rows with a skin) ------------------------------------------
+def test_neighbour_rows_follow_moving_atoms(gpu_required, systems, monkeypatch):
+    """Reference mode runs the Born sums and the chain rule over neighbour rows built with a skin (default 0.1 nm) and
+    rebuilt on the device once an atom is further than half of it from where it was at the last build.  A walk whose
+    steps are small (no rebuild for a while), then larger than the skin (rebuild at once), then small again must match
+    the oracle at every step, and the rows must have been rebuilt when -- and only when -- an atom had moved too far."""
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    rng = np.random.default_rng(11)
+    pos = s.pos.copy()
+    builds = []
+    for step, sigma in enumerate([0.0, 0.003, 0.003, 0.003, 0.08, 0.002, 0.002, 0.03, 0.03, 0.001]):
+        pos = pos + rng.normal(0.0, sigma, pos.shape) if sigma > 0 else pos
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+        assert k.scalar("rows_on") == 1
+        builds.append(int(k.scalar("row_builds")))
+    # sigma 0.003 nm never carries an atom 0.05 nm away in three steps; sigma 0.08 nm does at once; the drift of two
+    # steps of 0.03 nm does too
+    assert builds[0] == 1 and builds[3] == 1, builds
+    assert builds[4] == 2 and builds[6] == 2, builds
+    assert builds[-1] >= 3, builds
+
+
+def test_neighbour_row_overflow_falls_back_to_the_tiles(gpu_required, systems, monkeypatch):
+    """A neighbour row that outgrows its stride (forced here: 128 entries) withholds the evaluation like any other
+    capacity overflow; the host repeats it on the tile kernels and stays there."""
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_ROW_STRIDE", "128")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    monkeypatch.delenv("AGBNP_HIP_ROW_STRIDE")
+    oracle = Oracle(*s.params(), version=1)
+    for step in range(3):
+        pos = s.jittered(step)
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+        assert k.scalar("rows_on") == 0
+
+
+@pytest.mark.parametrize("skin", ["0.0", "0.02", "0.3"])
+def test_neighbour_rows_are_exact_for_any_skin(gpu_required, systems, monkeypatch, skin):
+    """The skin only decides how often the rows are rebuilt (0: at every new geometry), never which pairs are summed."""
+    s = systems("fixture264")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_SKIN", skin)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    for step in range(4):
+        pos = s.jittered(step, sigma=0.004)
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+    assert k.scalar("rows_on") == 1
+    builds = int(k.scalar("row_builds"))  # (jitter of 0.004 nm: 0.01 nm = half of 0.02 is exceeded by some atom, 0.15 nm never)
+    assert builds == 4 if skin == "0.0" else 1 <= builds <= 4 if skin == "0.02" else builds == 1
