@@ -36,14 +36,41 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 SIMDS = 1024           # 256 CUs x 4
 CLOCK_GHZ = 2.4        # max clock; the chip holds ~2.3 GHz in these kernels (profiles/r02/wg_timeline.txt)
 
-# Vector instructions of one pair step of one wave (64 pairs), read off the gfx950 assembly of the shipped kernels
-# (scripts/resource_table.py --keep-asm; loop bodies of k_gb_tiles / k_born_tiles / k_dborn_tiles): total VALU
-# and the FP64 ones among them.  {kernel: {tile kind: (valu, f64)}}
+# Fallback only (no counter summary under profiles/): vector instructions of one pair step of one wave (64 pairs), read
+# off the gfx950 assembly of the shipped kernels: total VALU and the FP64 ones among them.  {kernel: {tile kind: (valu, f64)}}
+# tests/test_host_api.py holds this table to within 3 % of the counters of the newest profiles/rNN/pmc_utilization.csv.
 PAIR_STEP_VALU = {
-    "k_gb_tiles": {"all": (65, 48.5)},
-    "k_born_tiles": {"hh": (47, 35), "hl": (34, 26)},
-    "k_dborn_tiles": {"hh": (74, 56), "hl": (52, 40)},
+    "k_gb_tiles": {"all": (59, 44)},
+    "k_born_tiles": {"hh": (49.6, 35), "hl": (35.9, 26)},   # (loop body + the tile's prologue / epilogue spread over its steps)
+    "k_dborn_tiles": {"hh": (75, 56), "hl": (52.7, 40)},
 }
+ISSUE_BOUND_KERNELS = ("k_gb_tiles", "k_born_tiles", "k_dborn_tiles", "k_born_rows", "k_dborn_rows")
+
+
+def newest_profile_dir():
+    root = os.path.join(ROOT, "profiles")
+    tags = sorted(d for d in os.listdir(root) if d.startswith("r") and d[1:].isdigit() and os.path.isdir(os.path.join(root, d))) if os.path.isdir(root) else []
+    return os.path.join(root, tags[-1]) if tags else None
+
+
+def counter_valu_instructions(system_name):
+    """Vector wave-instructions per launch of every kernel as the SQ counters saw them (SQ_INSTS_VALU of the newest
+    profiles/rNN/pmc_utilization.csv, taken on this workload with scripts/profile_round.sh).  None when there is none."""
+    d = newest_profile_dir()
+    if d is None or system_name != "1dwc":
+        return None, None
+    path = os.path.join(d, "pmc_utilization.csv")
+    if not os.path.exists(path):
+        return None, None
+    import csv
+    out = {}
+    for row in csv.DictReader(open(path)):
+        try:
+            out[row["kernel"]] = {"valu": float(row["SQ_INSTS_VALU"]), "lds_conflict_share": float(row["lds_bank_conflict_share"]),
+                                  "valu_share_of_wave_cycles": float(row["valu_share_of_wave_cycles"])}
+        except (KeyError, ValueError):
+            continue
+    return out, os.path.relpath(path, ROOT)
 
 
 def algorithmic_bytes(n_atoms, slots):
@@ -165,17 +192,38 @@ class Replica:
         for s in range(first, first + count):
             self.kernel.execute_device(base + s * self.step_bytes, self.d_force.data_ptr(), self.d_energy.data_ptr(), self.stream)
 
-    def settle(self, count):
-        """Warm-up: also settles the tree-capacity variant (repeat until no evaluation of the batch was withheld)."""
+    def settle(self, count, agree=None):
+        """Warm-up: also settles the tree-capacity variant (repeat until no evaluation of the batch was withheld -- on ANY
+        rank: `agree` turns the local count into the job's, so every rank repeats or none does)."""
+        agree = agree or (lambda withheld: withheld)
         for _ in range(8):
             self.run(0, max(count, 1))
-            if not self.kernel.finish(self.stream):
-                return
-        raise SystemExit("bench: tree capacity did not settle")
+            if not agree(self.kernel.finish(self.stream)):
+                return True
+        return False
 
-    def timed(self, first, count, barrier=lambda: None):
+    def preheat(self, seconds, batch):
+        """Evaluations until the device has been busy for `seconds`: the first milliseconds after an idle period run at a
+        lower clock (the driver's 20-step / 5-warm-up invocation measured 0.1216 ms where 200 steps measured 0.1147).
+        Untimed; returns the number of evaluations."""
+        torch, done = self.torch, 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            self.run(0, max(batch, 1))
+            torch.cuda.synchronize()
+            done += max(batch, 1)
+        self.kernel.finish(self.stream)  # (a withheld one here is caught by the timed pass's own check)
+        return done
+
+    def timed(self, first, count, barrier=lambda: None, agree=None):
+        """Seconds for `count` evaluations, or None if they would not settle.  `agree` (multi-rank runs): the MAX over the
+        ranks of the withheld count, a collective that EVERY rank enters after every try -- a rank whose own evaluations were
+        all complete repeats with the others instead of walking on to the next collective alone."""
         torch = self.torch
+        agree = agree or (lambda withheld: withheld)
+        self.tries = 0
         for _ in range(3):
+            self.tries += 1
             self.d_force.zero_()
             self.d_energy.zero_()
             torch.cuda.synchronize()
@@ -188,9 +236,9 @@ class Replica:
             t1 = time.perf_counter()
             # finish() reads the device's sticky overflow log: EVERY one of the timed evaluations is accounted for, not
             # just the last.  Non-zero = some were withheld (capacity negotiation still under way): time the run again.
-            if not self.kernel.finish(self.stream):
+            if not agree(self.kernel.finish(self.stream)):
                 return t1 - t0
-        raise SystemExit("bench: tree capacity did not settle")
+        return None
 
     def host_results(self, first, count):
         out = []
@@ -205,8 +253,12 @@ def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_
     """ms/eval, ns/day and parity-on-sample of another configuration (rank 0, one GPU)."""
     system = load_workload(name)
     r = Replica(torch, system, version, device, dev_index, steps + warmup, 7000, method=method, cutoff=cutoff, mode=mode)
-    r.settle(warmup)
-    ms = 1e3 * r.timed(warmup, steps) / steps
+    if not r.settle(warmup):
+        raise SystemExit(f"bench: tree capacity did not settle ({name})")
+    seconds = r.timed(warmup, steps)
+    if seconds is None:
+        raise SystemExit(f"bench: tree capacity did not settle ({name})")
+    ms = 1e3 * seconds / steps
     entry = {"workload": name, "atoms": system.n, "version": version, "ms_per_eval": ms, "ns_day": 86.4 / ms}
     if cpu_evals > 0:
         cpu_ms, de, df = cpu_baseline_leg(system, r.geoms[warmup:], r.host_results(warmup, cpu_evals), cpu_evals, version=version, **oracle_kw)
@@ -224,7 +276,8 @@ def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, w
     for r, st in enumerate(streams):
         with torch.cuda.stream(st):
             rep = Replica(torch, system, 1, device, dev_index, steps + warmup, 9000 + 977 * r, stream=st)
-            rep.settle(warmup)
+            if not rep.settle(warmup):
+                raise SystemExit("bench: tree capacity did not settle (concurrent replicas)")
             reps.append(rep)
     torch.cuda.synchronize()
     for attempt in range(3):
@@ -234,11 +287,84 @@ def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, w
                 rep.run(s, 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        if not any(rep.kernel.finish(rep.stream) for rep in reps):
+        if not any([rep.kernel.finish(rep.stream) for rep in reps]):  # (a list: every replica's log is read and reset)
             break
+    else:
+        raise SystemExit("bench: the concurrent replicas' third attempt still held withheld evaluations")
     ms = 1e3 * (t1 - t0) / steps  # per round of `replicas` evaluations
     return {"workload": name, "replicas_on_one_gpu": replicas, "ms_per_round": ms, "ms_per_eval_aggregate": ms / replicas,
             "aggregate_ns_day": replicas * 86.4 / ms}
+
+
+def job_max(dist, value, device):
+    """MAX over the ranks of a small non-negative integer (1 rank: the value itself).  THE collective behind every decision
+    that must be the same on all ranks: repeat a timed pass, give up, go on."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t[0])
+
+
+class Phases:
+    """Multi-rank discipline: the ranks run different geometries, so anything can go wrong on one rank alone (an evaluation
+    withheld, a capacity that does not settle, a HIP error).  Every phase runs under `run`, which catches the local failure;
+    `agree_all_ok` is entered by EVERY rank at the same point of the program and returns the job-wide verdict, so either all
+    ranks go on or all leave through `abort` -- no rank is left waiting in a collective that the others never enter."""
+
+    def __init__(self, dist, device, rank):
+        self.dist, self.device, self.rank, self.error = dist, device, rank, None
+
+    def run(self, fn, *a, **kw):
+        if self.error is not None:
+            return None
+        try:
+            return fn(*a, **kw)
+        except (SystemExit, Exception) as exc:  # noqa: BLE001 -- the failure is reported, then every rank leaves together
+            self.error = f"{type(exc).__name__}: {exc}"
+            return None
+
+    def agree_all_ok(self, what):
+        failed = job_max(self.dist, 0 if self.error is None else 1, self.device)
+        if failed:
+            self.abort(what)
+        return True
+
+    def abort(self, what):
+        if self.rank == 0 or self.error is not None:
+            print(f"bench: rank {self.rank}: {what} failed" + (f" here: {self.error}" if self.error else " on another rank"), file=sys.stderr)
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+        raise SystemExit(1)
+
+
+def headline_pass(rep, dist, device, W, K, preheat_seconds, phases):
+    """Settle, pre-heat and time the K steps of this rank's replica; every repeat decision is the job's (job_max), so all
+    ranks make the same number of tries.  Returns (seconds of this rank, evaluations spent on the pre-heat)."""
+    agree = lambda withheld: job_max(dist, 1 if withheld else 0, device)  # noqa: E731
+
+    def barrier():
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+
+    def settle():
+        if not rep.settle(W, agree):
+            raise SystemExit("tree capacity did not settle in the warm-up")
+        return rep.preheat(preheat_seconds, max(W, 5))
+
+    warm = phases.run(settle)
+    phases.agree_all_ok("warm-up")
+
+    def timed():
+        seconds = rep.timed(W, K, barrier, agree)
+        if seconds is None:
+            raise SystemExit("tree capacity did not settle in the timed pass")
+        return seconds
+
+    seconds = phases.run(timed)
+    phases.agree_all_ok("timed pass")
+    return seconds, warm
 
 
 def main():
@@ -252,6 +378,10 @@ def main():
     ap.add_argument("--mode", default="reference", choices=["reference", "fast", "fast+single", "deterministic"],
                     help="fast = the OpenCL platform's semantics (cutoff on every pair stage); deterministic = bit-reproducible "
                          "sums (Reference semantics); each printed as its own line")
+    ap.add_argument("--preheat-ms", type=float, default=150.0,
+                    help="untimed evaluations before the timed region until the device has been busy this long (clock ramp)")
+    ap.add_argument("--replicas-per-gpu", type=int, default=1,
+                    help="also report the aggregate of R concurrent replicas per GPU (streams of one process); the headline stays 1")
     args = ap.parse_args()
 
     import torch
@@ -275,28 +405,36 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     world = dist.get_world_size() if dist.is_initialized() else 1  # what took part, not what the environment promised
+    mdist = dist if world > 1 else None
+    phases = Phases(mdist, coll_device, rank)
 
     K, W = args.steps, args.warmup
-    system = load_workload(args.system)
-    n = system.n
     mode = None if args.mode == "reference" else args.mode
-    rep = Replica(torch, system, 1, device, dev_index, K + W, 1000 * rank, mode=mode)
+    system = phases.run(load_workload, args.system)
+    rep = phases.run(lambda: Replica(torch, system, 1, device, dev_index, K + W, 1000 * rank, mode=mode))
+    phases.agree_all_ok("context creation")
+    n = system.n
     kernel = rep.kernel
-    rep.settle(W)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    elapsed_local = rep.timed(W, K, barrier)
-    elapsed = max_over_ranks(dist if world > 1 else None, elapsed_local, coll_device)
+    elapsed_local, warm_evals = headline_pass(rep, mdist, coll_device, W, K, args.preheat_ms * 1e-3, phases)
+    elapsed = max_over_ranks(mdist, elapsed_local, coll_device)
     ms_per_step = 1e3 * elapsed / K
     props = torch.cuda.get_device_properties(dev_index)
     record = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
               "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)),
-              "ms_per_eval": 1e3 * elapsed_local / K, "ns_day": 86.4 / (1e3 * elapsed_local / K), "pid": os.getpid()}
-    per_rank = gather_records(dist if world > 1 else None, record, coll_device)
+              "ms_per_eval": 1e3 * elapsed_local / K, "ns_day": 86.4 / (1e3 * elapsed_local / K), "pid": os.getpid(),
+              "timed_tries": rep.tries, "clock_warm_evals": warm_evals}
+    per_rank = gather_records(mdist, record, coll_device)
     value = world * 86.4 / ms_per_step  # whole job: all replicas' steps / max-over-ranks time
+
+    # ---- secondary aggregate: R concurrent replicas per GPU (every rank, same R; the job's time is the slowest rank's)
+    per_gpu = None
+    if args.replicas_per_gpu > 1:
+        local = phases.run(concurrent_replicas_entry, torch, args.system, device, dev_index, args.replicas_per_gpu, K, W)
+        phases.agree_all_ok("concurrent replicas per GPU")
+        ms_round = max_over_ranks(mdist, local["ms_per_round"], coll_device)
+        per_gpu = {"replicas_per_gpu": args.replicas_per_gpu, "ms_per_round_max_over_ranks": ms_round,
+                   "aggregate_ns_day": world * args.replicas_per_gpu * 86.4 / ms_round,
+                   "note": "R independent contexts per GPU on R streams of one process; NOT the headline (one replica per GPU)"}
 
     result = None
     if rank == 0:
@@ -314,13 +452,21 @@ def main():
             "config": {"workload": f"{args.system} (thrombin, {n} atoms, {system.nheavy} heavy) AGBNP1 version=1, "
                                    f"CutoffNonPeriodic 1.0 nm ({semantics}), one jittered geometry per step "
                                    "(sigma 0.002 nm), positions/forces/energy resident in HBM",
-                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode},
+                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode,
+                       "pair_stage_form": "rows" if int(kernel.scalar("rows_on")) else "tiles"},
+            "clock_warm_evals": warm_evals,
             "per_replica_ns_day": [round(r["ns_day"], 4) for r in per_rank],
             "ranks": per_rank,
             "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in per_rank}),
             "algorithmic_bytes_per_eval": b_eval,
             "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
         }
+        if per_gpu is not None:
+            result["replicas_per_gpu"] = per_gpu
+        if int(kernel.scalar("rows_on")):
+            result["neighbour_rows"] = {"builds_so_far": int(kernel.scalar("row_builds")),
+                                        "note": "rows built with a skin and rebuilt on the device when an atom has moved more than half of it; "
+                                                "the jittered geometries of this protocol stay within it"}
 
     # ---- per-kernel durations: same K steps again with a hipEvent in front of every kernel (separate pass so
     #      that the events do not sit inside the timed region above)
@@ -328,7 +474,7 @@ def main():
         kernel.set_profiling(True)
         rep.run(W, K)
         if kernel.finish(rep.stream):
-            raise SystemExit("bench: an evaluation of the profiling pass overflowed after the timed pass had settled")
+            print("bench: an evaluation of the profiling pass overflowed after the timed pass had settled", file=sys.stderr)
         times = kernel.kernel_times()
         kernel.set_profiling(False)
         raw_us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in times.items() if v[1] > 0}
@@ -339,35 +485,55 @@ def main():
         event_overhead_us = max(0.0, (sum(raw_us.values()) - 1e3 * ms_per_step) / max(len(raw_us), 1))
         avg_us = {k: max(v - event_overhead_us, 0.0) for k, v in raw_us.items()}
         dominant = max(avg_us, key=avg_us.get)
-        traffic = None
+        traffic, eval_traffic = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_pmc.json")
         if os.path.exists(tfile):
             try:
                 rec = json.load(open(tfile))
-                if rec.get("kernel") == dominant and rec.get("system") == args.system:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                if rec.get("system") == args.system:
+                    eval_traffic = rec.get("all_kernels_bytes_per_eval")
+                    if rec.get("kernel") == dominant:
+                        traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         achieved = b_kernel.get(dominant, 0) / (avg_us[dominant] * 1e-6) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
-        # the roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave
-        # holds its SIMD for 4 cycles at FP64 rate), measured against the wave-steps this geometry makes them execute
+        if eval_traffic:  # what really crosses the HBM interface, by the PMC counters of the committed profile
+            result["eval_hbm_fraction_counter_bytes"] = (eval_traffic / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9)
+            if traffic:
+                result["roofline"]["frac_counter_bytes"] = traffic / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        # The roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave holds
+        # its SIMD for 4 cycles at FP64 rate).  Instruction counts: SQ_INSTS_VALU of the committed counter pass where there
+        # is one for this workload, else the hand-read table x the wave-steps this geometry makes the kernels execute.
+        counters, counter_file = counter_valu_instructions(args.system)
         steps_by_kernel = pair_wave_steps(system, rep.geoms[W])
         issue = []
-        for kname, kinds in PAIR_STEP_VALU.items():
+        for kname in ISSUE_BOUND_KERNELS:
             if kname not in avg_us:
                 continue
-            valu = sum(steps_by_kernel[kname][kind] * v for kind, (v, _) in kinds.items())
-            f64 = sum(steps_by_kernel[kname][kind] * f for kind, (_, f) in kinds.items())
+            if counters and kname in counters:
+                valu, source = counters[kname]["valu"], counter_file + ": SQ_INSTS_VALU"
+            elif kname in PAIR_STEP_VALU:
+                valu = sum(steps_by_kernel[kname][kind] * v for kind, (v, _) in PAIR_STEP_VALU[kname].items())
+                source = "hand-read instruction table x wave-steps of this geometry"
+            else:
+                continue
             bound_us = valu * 4 / SIMDS / (CLOCK_GHZ * 1e3)
-            issue.append({"bound": "fp64_issue", "kernel": kname, "wave_steps": int(sum(steps_by_kernel[kname].values())),
-                          "valu_instructions": int(valu), "fp64_instructions": int(f64), "cycles_per_instruction": 4,
-                          "bound_us": round(bound_us, 2), "avg_launch_us": round(avg_us[kname], 2),
-                          "frac": round(bound_us / avg_us[kname], 3) if avg_us[kname] > 0 else None,
-                          "achieved": round(2 * f64 * 64 / (avg_us[kname] * 1e-6) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s (FP64 FMA = 2)"})
+            entry = {"bound": "fp64_issue", "kernel": kname, "valu_instructions": int(valu), "source": source, "cycles_per_instruction": 4,
+                     "bound_us": round(bound_us, 2), "avg_launch_us": round(avg_us[kname], 2),
+                     "frac": round(bound_us / avg_us[kname], 3) if avg_us[kname] > 0 else None}
+            if counters and kname in counters:
+                entry["lds_bank_conflict_share"] = counters[kname]["lds_conflict_share"]
+            issue.append(entry)
         result["rooflines_issue"] = issue
+        # speed of light of the evaluation as launched: per kernel the roof that binds it -- vector issue for the pair
+        # kernels, the modelled bytes at the HBM peak for the rest (tree kernels: latency-bound far above that)
+        issue_by_kernel = {e["kernel"]: e["bound_us"] for e in issue}
+        sol = {k: issue_by_kernel.get(k, b_kernel.get(k, 0) / (HBM_PEAK_GBS * 1e9) * 1e6) for k in avg_us}
+        result["speed_of_light_us"] = {"sum": round(sum(sol.values()), 2), "per_kernel": {k: round(v, 2) for k, v in sol.items()},
+                                       "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3)}
         result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
         result["kernel_sum_us"] = round(sum(avg_us.values()), 2)
         result["kernel_event_us"] = {k: round(v, 2) for k, v in raw_us.items()}

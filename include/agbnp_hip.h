@@ -113,10 +113,14 @@ unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
  * 2 nm, GB meets ALL pairs, nonbonded method and cutoff are inert -- parity target of this engine).
  * AGBNP_HIP_MODE_FAST = the semantics of the reference's GPU (OpenCL) platform: every pair stage of AGBNP1 -- Born-radius
  * descreening sums, GB pair energy / direct forces / Y sums, chain-rule W/U sums and forces -- only meets pairs with
- * r^2 < cutoff_distance^2 (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186; that
- * platform applies the cutoff for every nonbonded method, OpenCLAGBNPKernels.cpp:490,1155), tiles beyond it are culled.
+ * r^2 < cutoff_distance^2 (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186).  As on
+ * that platform the cutoff only exists for a nonbonded method other than NoCutoff (USE_CUTOFF, OpenCLAGBNPKernels.cpp:487,
+ * 1149-1150): with NoCutoff the fast mode truncates nothing and computes exactly what the Reference mode does.
+ * CutoffPeriodic is rejected (AGBNP_HIP_ERR_INVALID_ARGUMENT): no periodic box crosses this boundary.  Tiles beyond the
+ * cutoff are culled.
  * FP64 throughout; version 0 has no pair stage and is unaffected.  For comparisons with the OpenCL plugin; results
- * differ from the Reference platform by the truncated pairs.  Synchronises the device; bumps agbnp_hip_generation().
+ * differ from the Reference platform by the truncated pairs.  Drains this context's own stream (not the device); bumps
+ * agbnp_hip_generation().
  *
  * AGBNP_HIP_MODE_DETERMINISTIC (may be combined with either): bit-identical results from run to run.  By default sums
  * that many workgroups contribute to are FP64 atomics whose order is not fixed, so results differ by ~1e-16 relative
@@ -140,6 +144,8 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *          5 total tree nodes  6 kernel variant  7 max local atoms  8 work slots (forests) planned for the next evaluation
  *          9 1 if the range-limited pair stages run in row form (neighbour rows with a skin, rebuilt on the device when an
  *            atom has moved more than half the skin; Reference mode, version 1)  10 builds of those rows so far
+ *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; every overflow of a packed forest
+ *             adds one step of 15 %, sixteen clean plans in a row give one back)  12 evaluations since the packing was planned
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii)
  *          4 / 5 nodes / local atoms of the overlap subtree rooted at the atom (tree shape, capacity planning) */

@@ -229,9 +229,9 @@ class HipCalcAGBNPForceKernel:
         self._need()
         lib = _lib.load()
         n = lib.agbnp_hip_withheld_evaluations(self._h, None, 0)
-        idx = np.zeros(max(n, 1), dtype=np.int32)
+        idx = np.full(max(n, 1), -1, dtype=np.int32)  # the library fills as many indices as its log holds (it only COUNTS beyond bit 2047)
         lib.agbnp_hip_withheld_evaluations(self._h, _ip(idx), n)
-        return [int(k) for k in idx[:min(n, 2048)]]
+        return [int(k) for k in idx if k >= 0]
 
     def generation(self):
         """Changes when a captured HIP graph of execute_device has gone stale (capacity variant raised)."""
@@ -246,7 +246,7 @@ class HipCalcAGBNPForceKernel:
             raise OpenMMException(_lib.last_error(self._h))
 
     # ---- diagnostics (test support) -------------------------------------------------------------
-    SCALARS = dict(e_vol1=0, e_vol2=1, e_atom=2, e_gb_pair=3, max_subtree_nodes=4, total_nodes=5, variant=6, max_local_atoms=7, forests=8, rows_on=9, row_builds=10)
+    SCALARS = dict(e_vol1=0, e_vol2=1, e_atom=2, e_gb_pair=3, max_subtree_nodes=4, total_nodes=5, variant=6, max_local_atoms=7, forests=8, rows_on=9, row_builds=10, pack_level=11, pack_age=12)
     VECTORS = dict(selfvol_vdw=0, born=1, scale=2, selfvol_large=3, subtree_nodes=4, subtree_atoms=5)
 
     def scalar(self, name):

@@ -136,6 +136,11 @@ struct agbnp_hip_context {
   int tree_slots[5] = {1280, 1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
+  std::vector<int> carried;     // withheld evaluations of execute_device harvested by an execute_host call in between (see there)
+  int carried_count = 0, carried_seq = 0;
+  bool unfinished = false;      // evaluations enqueued by execute_device / execute_openmm since the last finish
+  int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
+  std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
   int last_rows[2] = {0, 0};   // {stale flag, builds so far} of the row-form neighbour rows, as of the last harvest
   bool have_results = false;
   bool diagnostics = false;
@@ -273,8 +278,12 @@ void wire_args(agbnp_hip_context* c) {
   P.srec = c->d_srec.p;
   P.ys = c->d_ys.p;
   P.abox = c->d_abox.p;
-  P.fast = (c->mode & AGBNP_HIP_MODE_FAST) ? 1 : 0;
-  P.single = (c->mode & AGBNP_HIP_MODE_FAST) && (c->mode & AGBNP_HIP_MODE_SINGLE) ? 1 : 0;
+  // The OpenCL platform only defines USE_CUTOFF for a method other than NoCutoff (OpenCLAGBNPKernels.cpp:487,1149-1150): with
+  // NoCutoff the fast mode truncates nothing and IS the reference mode (the cutoff distance "will have no effect",
+  // AGBNPForce.h); CutoffPeriodic is refused by agbnp_hip_set_mode (no box vectors cross this boundary).
+  const bool cut = (c->mode & AGBNP_HIP_MODE_FAST) && c->method != 0;
+  P.fast = cut ? 1 : 0;
+  P.single = cut && (c->mode & AGBNP_HIP_MODE_SINGLE) ? 1 : 0;
   P.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
   P.range2 = P.fast ? std::min(kI4MaxA * kI4MaxA, c->cutoff * c->cutoff) : kI4MaxA * kI4MaxA;
   P.gb_cut2 = P.fast ? c->cutoff * c->cutoff : 1e300;
@@ -310,8 +319,7 @@ void wire_args(agbnp_hip_context* c) {
   {
     // Row form (reference mode only: the fast mode cuts every stage at the cutoff and the deterministic mode fixes the
     // order of its sums through the tiles' quantized totals)
-    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 &&
-                !(c->mode & (AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_DETERMINISTIC)) ? 1 : 0;
+    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.fast && !P.det ? 1 : 0;
     const double reach = kI4MaxA + c->skin;
     P.nl_build2 = reach * reach;
     P.nl_move2 = 0.25 * c->skin * c->skin;
@@ -397,6 +405,11 @@ void wire_args(agbnp_hip_context* c) {
 }
 
 int upload_identity_packing(agbnp_hip_context* c);
+
+void note_stream(agbnp_hip_context* c, void* stream) {  // a caller's stream with work of this context on it
+  c->unfinished = true;
+  if (stream && std::find(c->user_streams.begin(), c->user_streams.end(), stream) == c->user_streams.end()) c->user_streams.push_back(stream);
+}
 
 // Buffers of the row form of the range-limited stages (k_rows): candidate orders sorted by type, neighbour rows at a fixed
 // stride, the power-form spline coefficients.  Systems it does not take (version 0, more radius types than the per-wave
@@ -631,7 +644,7 @@ int upload_identity_packing(agbnp_hip_context* c) {
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
   // [slots+3] how often a packed forest has overflowed so far (kept), [slots+4] the age of the packing in evaluations
   // (huge: this one is no plan, the next evaluation's bookkeeping plans at once)
-  std::vector<int> forest(nslots + 3);
+  std::vector<int> forest(nslots + 3);  // (+ three persistent words behind it, see below)
   for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
   forest[nslots + 1] = c->nh;
   forest[nslots + 2] = c->nh;
@@ -639,6 +652,7 @@ int upload_identity_packing(agbnp_hip_context* c) {
   if (c->d_forest.p == nullptr) {
     forest.push_back(0);
     forest.push_back(no_plan);
+    forest.push_back(0);  // [slots+5] clean plans in a row since the assumed capacity was last tightened
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
@@ -664,6 +678,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
   if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
@@ -820,8 +835,11 @@ int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radiu
   }
   HIP_TRY(c, hipSetDevice(c->device));
   // the parameter arrays are rewritten in place (their addresses stay valid for captured graphs), so nothing of this
-  // context may be in flight on ANY stream: this is the platform's synchronisation point, as in the reference
-  HIP_TRY(c, hipDeviceSynchronize());
+  // context may be in flight: the context's own stream is drained here, and a caller who enqueues on streams of its own
+  // (agbnp_hip_execute_device / _openmm with a stream argument) calls agbnp_hip_finish on them first -- as it must anyway
+  // to learn about withheld evaluations.  (Not hipDeviceSynchronize: that would stall every other context of the device.)
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (void* st : c->user_streams) HIP_TRY(c, hipStreamSynchronize((hipStream_t)st));
   int rc = upload_parameters(c);
   if (rc != AGBNP_HIP_OK) return rc;
   wire_args(c);
@@ -833,6 +851,7 @@ int agbnp_hip_execute_device(agbnp_hip_context* c, const double* d_pos, double* 
   if (!d_pos || !d_force || !d_energy) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_device: null pointer");
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  note_stream(c, stream);
   return enqueue(c, d_pos, d_force, d_energy, st);
 }
 
@@ -847,6 +866,7 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   if (energy_slot < 0) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_openmm: negative energy slot");
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  note_stream(c, stream);
   // the staging buffers start as zeros (allocation) and every output adapter hands them back as zeros
   HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, c->d_ctx_slot.p, st));
   // the output side is the engine's own last kernel: forces as fixed point at the context's slots, energy into its
@@ -869,7 +889,21 @@ int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIP_TRY(c, hipStreamSynchronize(st));
-  return harvest(c, must_repeat);
+  c->user_streams.erase(std::remove(c->user_streams.begin(), c->user_streams.end(), stream), c->user_streams.end());
+  int rc = harvest(c, must_repeat);
+  if (rc != AGBNP_HIP_OK) return rc;
+  if (c->carried_count > 0) {
+    // evaluations of execute_device that a call of agbnp_hip_execute_host in between had to harvest: they were enqueued
+    // BEFORE everything this finish has just read, so they come first and the later indices move up
+    for (int& k : c->withheld) k += c->carried_seq;
+    c->withheld.insert(c->withheld.begin(), c->carried.begin(), c->carried.end());
+    c->withheld_count += c->carried_count;
+    *must_repeat = c->withheld_count;
+  }
+  c->carried.clear();
+  c->carried_count = c->carried_seq = 0;
+  c->unfinished = !c->user_streams.empty();
+  return AGBNP_HIP_OK;
 }
 
 int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forces, double* energy) {
@@ -877,6 +911,21 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
   if (!pos || !forces || !energy) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_execute_host: null pointer");
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
+  if (c->unfinished) {
+    // The sticky overflow log is about to be read and cleared by this call's own harvest.  Evaluations that the caller
+    // has enqueued with agbnp_hip_execute_device and not yet finished must not lose their entries: they are harvested
+    // now and carried over to the caller's next agbnp_hip_finish.
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (void* st : c->user_streams) HIP_TRY(c, hipStreamSynchronize((hipStream_t)st));
+    int pending = 0;
+    int rc = harvest(c, &pending);
+    if (rc != AGBNP_HIP_OK) return rc;
+    const int seq = c->last_status[kStatEvalSeq];
+    for (int k : c->withheld) c->carried.push_back(k + c->carried_seq);
+    c->carried_count += pending;
+    c->carried_seq += seq;
+    c->unfinished = false;
+  }
   for (int attempt = 0; attempt < 8; attempt++) {
     HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, pos, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_force_tmp.p, 0, bytes, c->stream));
@@ -913,6 +962,8 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 8: *value = c->last_status[kStatForests]; break;
     case 9: *value = c->P.rows_on; break;        // 1: the range-limited pair stages run in row form
     case 10: *value = c->last_rows[1]; break;    // builds of the neighbour rows so far
+    case 11: *value = c->last_pack[0]; break;    // forest packing: how far the assumed store capacity is tightened (0 = not)
+    case 12: *value = c->last_pack[1]; break;    // ... evaluations since the packing in use was planned
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;
@@ -979,10 +1030,12 @@ int agbnp_hip_set_mode(agbnp_hip_context* c, int mode) {
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: unknown mode bits");
   if ((mode & AGBNP_HIP_MODE_SINGLE) && !(mode & AGBNP_HIP_MODE_FAST))
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: single precision is an option of the fast mode (the Reference semantics are FP64)");
-  if ((mode & AGBNP_HIP_MODE_FAST) && !(c->cutoff > 0.0))
+  if ((mode & AGBNP_HIP_MODE_FAST) && c->method == 2)
+    return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: the fast mode does not take CutoffPeriodic (no periodic box crosses this boundary)");
+  if ((mode & AGBNP_HIP_MODE_FAST) && c->method != 0 && !(c->cutoff > 0.0))
     return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "agbnp_hip_set_mode: the fast mode needs a positive cutoff distance");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // (this context's own work; other contexts of the device are not stalled)
   if (mode != c->mode) c->generation++;  // other kernel arguments: a captured graph is stale
   c->mode = mode;
   wire_args(c);

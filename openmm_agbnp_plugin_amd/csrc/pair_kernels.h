@@ -69,7 +69,8 @@ struct PairArgs {
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
-  int* pack_state;         // [2] persistent: how often a packed forest has overflowed (tightens the packing); evaluations since
+  int* pack_state;         // [3] persistent: how often a packed forest has overflowed (tightens the packing; relaxes again after
+                           // clean plans: word [2] counts them); evaluations since
                            // the packing in use was planned (huge = it is no plan: one subtree per slot)
   int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 4)
   int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k

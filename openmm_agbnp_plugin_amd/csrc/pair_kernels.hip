@@ -444,7 +444,12 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   };
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
   const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
-  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0);
+  // level: how often the assumed capacity has been tightened by 15 % (a forest outgrew its store).  It relaxes again: after
+  // kPackRelax plans in a row without a misprediction one step is given back, so a run with the occasional overflow does
+  // not drift to one subtree per slot for the life of the context.
+  constexpr int kPackRelax = 16;
+  const bool relax = P.status[kStatPackOverflow] == 0 && P.pack_state[0] > 0 && P.pack_state[2] >= kPackRelax;
+  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0) - (relax ? 1 : 0);
   const bool pack = P.pack_enabled && !overflow && level < 6;
   float share = 0.9f;
   for (int k = 0; k < level; k++) share *= 0.85f;
@@ -508,7 +513,9 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
     P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
     P.pack_state[0] = level;
-    if (P.pack_enabled != 3) P.pack_state[1] = plan ? 0 : age + 1;
+    // (after an overflow the one-subtree-per-slot fallback written below is no plan: the next clean evaluation plans anew)
+    if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
+    if (plan) P.pack_state[2] = (overflow || relax) ? 0 : P.pack_state[2] + 1;
     if (!plan) {
       P.status[kStatForests] = P.nforests[0];       // (the packing stays)
       P.forest_time[P.tree_slot_cap] = 2;           // tells dealing_role that there is nothing to deal

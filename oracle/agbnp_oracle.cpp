@@ -599,8 +599,9 @@ struct Oracle {
   // FAST-MODE switch (not the Reference platform): cutoff2 > 0 restates the pair truncation of the reference's OpenCL
   // platform on top of the same FP64 arithmetic -- every pair loop of AGBNP1 skips pairs with r^2 >= CUTOFF_SQUARED
   // (platforms/opencl/src/kernels/AGBNPBornRadii.cl:268,430 descreening sums and their derivative pass,
-  // AGBNPGBEnergy.cl:145,186 GB pairs; CUTOFF_SQUARED = cutoffDistance^2 for every nonbonded method,
-  // OpenCLAGBNPKernels.cpp:490,1155).  No reference-held vector exists for that platform: this mode is PARITY UNPINNED;
+  // AGBNPGBEnergy.cl:145,186 GB pairs; all of them inside #ifdef USE_CUTOFF, which that platform only defines for a
+  // nonbonded method other than NoCutoff, OpenCLAGBNPKernels.cpp:487,1149-1150 -- the caller of this switch applies that
+  // gate: oracle.py passes no cutoff for NoCutoff).  No reference-held vector exists for that platform: this mode is PARITY UNPINNED;
   // it is tied to the pinned path by the limit cutoff -> infinity (tests/test_oracle_golden.py).
   double cutoff2 = 0.0;
 

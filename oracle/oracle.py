@@ -67,9 +67,15 @@ class Oracle:
     SCALARS = dict(e_vol1=0, e_vol2=1, e_gb=2, e_vdw=3, volume1=4, volume2=5, slots=6, nscreened=7, nscreener=8)
     VECTORS = dict(selfvol_large=0, selfvol_vdw=1, born=2, scale=3, brw=4, bru=5, Y=6, W=7, U=8, freevol_vdw=9)
 
-    def __init__(self, radius, gamma, alpha, charge, ishydrogen, version=1, cutoff=None):
+    def __init__(self, radius, gamma, alpha, charge, ishydrogen, version=1, cutoff=None, method=1):
         """cutoff=None: the Reference platform's semantics (the pinned oracle).  cutoff=c: the FAST-mode restatement of
-        the reference's OpenCL platform -- every AGBNP1 pair loop truncated at r < c (parity unpinned, see the .cpp)."""
+        the reference's OpenCL platform -- every AGBNP1 pair loop truncated at r < c (parity unpinned, see the .cpp).
+        method: the force's nonbonded method (0 NoCutoff, 1 CutoffNonPeriodic, 2 CutoffPeriodic); as on that platform the
+        cutoff only exists for a method other than NoCutoff (OpenCLAGBNPKernels.cpp:487), and CutoffPeriodic is not restated."""
+        if cutoff is not None and method == 2:
+            raise OracleError("the fast-mode switch does not restate CutoffPeriodic")
+        if method == 0:
+            cutoff = None
         lib = _load()
         self.n = len(radius)
         self._p = [_d(radius), _d(gamma), _d(alpha), _d(charge), np.ascontiguousarray(ishydrogen, dtype=np.int32)]

@@ -906,3 +906,85 @@ def test_neighbour_rows_are_exact_for_any_skin(gpu_required, systems, monkeypatc
     assert k.scalar("rows_on") == 1
     builds = int(k.scalar("row_builds"))  # (jitter of 0.004 nm: 0.01 nm = half of 0.02 is exceeded by some atom, 0.15 nm never)
     assert builds == 4 if skin == "0.0" else 1 <= builds <= 4 if skin == "0.02" else builds == 1
+
+
+# ---- round-3 contract fixes ----------------------------------------------------------------------------------------
+def test_fast_mode_honours_the_nonbonded_method(gpu_required, systems):
+    """The OpenCL platform only has a cutoff for a nonbonded method other than NoCutoff (USE_CUTOFF,
+    OpenCLAGBNPKernels.cpp:487,1149-1150): a default force (NoCutoff, cutoff distance 1.0 'without effect') in fast mode
+    computes ALL pairs -- the reference mode's numbers -- and CutoffPeriodic is refused (no box crosses the boundary)."""
+    s = systems("trpcage")
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)  # NoCutoff, cutoff distance 1.0: the reference's defaults
+    assert force.getNonbondedMethod() == P.AGBNPForce.NoCutoff and force.getCutoffDistance() == 1.0
+    k = P.HipCalcAGBNPForceKernel(mode="fast")
+    k.initialize(force)
+    f = np.zeros((s.n, 3))
+    e = k.execute(s.pos, f)
+    eo, fo = Oracle(*s.params(), version=1, cutoff=1.0, method=0).execute(s.pos)  # (the oracle's switch takes the same gate)
+    er, fr = Oracle(*s.params(), version=1).execute(s.pos)
+    assert eo == er
+    assert_close(e, f, er, fr)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffPeriodic)
+    k2 = P.HipCalcAGBNPForceKernel(mode="fast")
+    with pytest.raises(P.OpenMMException, match="CutoffPeriodic"):
+        k2.initialize(force)
+    k3 = P.HipCalcAGBNPForceKernel()  # reference mode: every method is accepted and inert, as on the Reference platform
+    k3.initialize(force)
+    f3 = np.zeros((s.n, 3))
+    assert_close(k3.execute(s.pos, f3), f3, er, fr)
+
+
+def test_host_call_does_not_swallow_the_device_log(gpu_required, systems):
+    """agbnp_hip_execute_host reads and clears the sticky overflow log for its own repeat protocol.  Evaluations that the
+    caller has enqueued with execute_device and not yet finished must still be reported by the caller's next finish()."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    squeezed = centre + 0.85 * (s.pos - centre)  # outgrows the smallest capacity variant
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack([s.pos, squeezed]), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # 0: complete
+    k.execute_device(pos[1].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # 1: withheld
+    f = np.zeros((s.n, 3))
+    e = k.execute(s.jittered(3), f)  # a host call in between: harvests, repeats itself as needed, returns complete numbers
+    eo, fo = Oracle(*s.params(), version=1).execute(s.jittered(3))
+    assert_close(e, f, eo, fo)
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # 2: complete
+    assert k.finish(stream) == 1
+    assert k.withheld() == [1]
+    assert k.finish(stream) == 0 and k.withheld() == []
+
+
+def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
+    """Every overflow of a packed forest tightens the capacity the packing assumes (pack_level + 1); sixteen clean plans
+    in a row give one step back, so occasional mispredictions do not push a long run to one subtree per slot for good.
+    After an overflow the very next clean evaluation plans anew (the unpacked fallback is not kept for a replan period)."""
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_REPLAN_EVERY", "1")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    centre = s.pos.mean(axis=0)
+    f = np.zeros((s.n, 3))
+    for step in range(3):
+        k.execute(s.jittered(step), f)
+    assert k.scalar("pack_level") == 0
+    packed = int(k.scalar("forests"))
+    assert packed < s.nheavy
+    k.execute(centre + 0.9 * (s.pos - centre), f)  # trees grow beyond the plan: the packed forests overflow, the call repeats itself
+    level = int(k.scalar("pack_level"))
+    assert level >= 1
+    k.execute(s.jittered(4), f)
+    k.execute(s.jittered(5), f)
+    assert int(k.scalar("forests")) < s.nheavy  # packed again at once (tighter than before)
+    for step in range(16 * level + 2):
+        k.execute(s.jittered(6 + step), f)
+    assert k.scalar("pack_level") == 0
+    assert int(k.scalar("forests")) <= packed + 8  # back at the original packing density

@@ -170,3 +170,21 @@ def test_unit_quantities_are_stripped_like_the_swig_layer():
     assert f.getParticleParameters(0) == (pytest.approx(0.2), 1.0, 2.0, 3.0, True)
     f.setCutoffDistance(Quantity(12.0, 0.1))
     assert f.getCutoffDistance() == pytest.approx(1.2)
+
+
+def test_bench_instruction_table_tracks_the_counters():
+    """bench.py prices the pair kernels' vector-issue roof with SQ_INSTS_VALU of the committed counter pass; its hand-read
+    fallback table (instructions per wave-step x wave-steps of the geometry) must stay within 3 % of those counters, or it
+    has rotted with a kernel edit."""
+    import bench
+    import openmm_agbnp_plugin_amd as P
+    counters, source = bench.counter_valu_instructions("1dwc")
+    if counters is None:
+        pytest.skip("no counter summary under profiles/")
+    s = P.load_system("1dwc")
+    steps = bench.pair_wave_steps(s, s.jittered(1020))
+    for kernel, kinds in bench.PAIR_STEP_VALU.items():
+        if kernel not in counters:
+            continue  # (a kernel that the profiled configuration does not launch)
+        model = sum(steps[kernel][kind] * valu for kind, (valu, _) in kinds.items())
+        assert abs(model / counters[kernel]["valu"] - 1.0) < 0.03, (kernel, model, counters[kernel]["valu"], source)
