@@ -7,7 +7,7 @@ The reference scripts run a full OpenMM MD loop (DesmondDMSFile.createSystem(imp
 LangevinIntegrator, 10 000 steps); OpenMM is outside this repository's scope, so only the AGBNP force
 itself is evaluated here, and ns/day is the AGBNP-force-limited figure at the scripts' 1 fs step.
 
-  python examples/evaluate_agbnp.py 1dwc                # bundled fixture (tests/golden/1dwc.dat)
+  python examples/evaluate_agbnp.py 1dwc                # bundled structure (openmm_agbnp_plugin_amd/data/1dwc.dat)
   python examples/evaluate_agbnp.py /path/to/file.dms   # Desmond .dms with an agbnp2 table
 """
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Export the reference's bundled structures as DATA fixtures (inputs only).
+"""Export the reference's bundled structures as package DATA (inputs only; what load_system() and the examples read).
 
 Run in the build container only (needs /root/reference); the GPU box never runs this.
 

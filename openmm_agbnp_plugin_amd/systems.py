@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")  # package data: the bundled structures (inputs only)
 
 BUNDLED = {
     "fixture264": "fixture264.dat",        # platforms/reference/tests/gaussvol.dat
@@ -95,7 +95,7 @@ def parse_structure(text, name="structure"):
 
 def load_system(name):
     """Load one of the bundled structures by name, or any file in the 8-column format by path."""
-    path = os.path.join(GOLDEN_DIR, BUNDLED[name]) if name in BUNDLED else name
+    path = os.path.join(DATA_DIR, BUNDLED[name]) if name in BUNDLED else name
     with open(path) as f:
         return parse_structure(f.read(), name=os.path.splitext(os.path.basename(path))[0])
 
@@ -106,7 +106,7 @@ def load_dms(path, name=None):
     trpcage's `agbnp1` table lists every id twice, so `agbnp2` is the one to join), hydrogens by atomic number.
     The .dms -> addParticle mapping of OpenMM's DesmondDMSFile is outside the reference tree and unpinned
     (SURVEY.md s.8c); this loader applies the reference TEST's parameterisation instead, exactly like the
-    bundled .dat fixtures (tests/golden/make_fixtures.py uses the same query)."""
+    bundled .dat structures (openmm_agbnp_plugin_amd/data/make_fixtures.py uses the same query)."""
     import sqlite3
     con = sqlite3.connect(f"file:{path}?mode=ro", uri=True)
     try:

@@ -4,11 +4,11 @@ A. Shipped with the reference (platforms/reference/tests/):
    v0.reference:4-7   Volume energy 1: 2287.78 / 2: -1415.27 / Energy: 872.514; after +2e-3 nm on atom 121, y:
                       Energy 872.576, Energy Change 0.0615433, Energy Change from Gradient 0.0619746 (lines 8-15)
    v1.reference:2-5   Energy: -2476.66; -2476.58; 0.0874992; 0.0886249
-   input: platforms/reference/tests/gaussvol.dat (tests/golden/fixture264.dat), parameterisation of
+   input: platforms/reference/tests/gaussvol.dat (openmm_agbnp_plugin_amd/data/fixture264.dat), parameterisation of
    TestReferenceAGBNPForce.cpp:47-70, probe of TestReferenceAGBNPForce.cpp:117-127 (pmove=121, direction=1, 2e-3).
 B. Recorded by the survey from its run of the unmodified reference sources,
    13 significant digits.  The survey's export of the .dms coordinates was rounded differently from
-   tests/golden/*.dat (full repr), so the .dms systems agree to ~1e-8 relative, the .dat fixtures to 1e-13.
+   openmm_agbnp_plugin_amd/data/*.dat (full repr), so the .dms systems agree to ~1e-8 relative, the .dat fixtures to 1e-13.
 C. Tree statistics recorded by the survey.
 """
 

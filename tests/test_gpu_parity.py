@@ -695,7 +695,7 @@ def test_cxx_mirror_reads_like_the_reference_test(gpu_required, tmp_path):
     libdir = os.path.join(root, "openmm_agbnp_plugin_amd")
     subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "cxx", "TestHipAGBNPForce.cpp"), "-o", exe,
                     os.path.join(libdir, "libagbnp_hip.so"), f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    data = open(os.path.join(root, "tests", "golden", "fixture264.dat")).read()
+    data = open(os.path.join(root, "openmm_agbnp_plugin_amd", "data", "fixture264.dat")).read()
     for version in (0, 1):
         want = REFERENCE_PRINTED[version]
         out = subprocess.run([exe, str(version), repr(want["energy"]), repr(want["energy_moved"])], input=data, text=True,

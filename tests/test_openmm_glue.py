@@ -50,7 +50,7 @@ def test_plugin_path_fails_cleanly_without_a_device(tmp_path):
     if _lib.load().agbnp_hip_device_count() > 0:
         pytest.skip("a HIP device is present")
     exe = build_test_program(tmp_path)
-    data = open(os.path.join(ROOT, "tests", "golden", "fixture264.dat")).read()
+    data = open(os.path.join(ROOT, "openmm_agbnp_plugin_amd", "data", "fixture264.dat")).read()
     out = subprocess.run([exe, "1", "double"], input=data, text=True, capture_output=True, timeout=120)
     assert out.returncode == 2 and out.stdout.startswith("exception:")
 
@@ -61,7 +61,7 @@ def test_plugin_path_fails_cleanly_without_a_device(tmp_path):
 def test_plugin_path_reproduces_the_reference_known_answers(gpu_required, tmp_path, version, precision):
     from tests.pins import REFERENCE_PRINTED
     exe = build_test_program(tmp_path)
-    data = open(os.path.join(ROOT, "tests", "golden", "fixture264.dat")).read()
+    data = open(os.path.join(ROOT, "openmm_agbnp_plugin_amd", "data", "fixture264.dat")).read()
     out = subprocess.run([exe, str(version), precision], input=data, text=True, capture_output=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.split("\n")
