@@ -107,7 +107,7 @@ struct agbnp_hip_context {
   DevBuf<unsigned> d_hperm, d_aperm, d_nlh, d_nla, d_bslice, d_cslice;
   DevBuf<int> d_nlh_count, d_nla_count, d_nl_flag;
   DevBuf<double> d_nl_ref, d_bw;
-  DevBuf<double4> d_rec_h, d_hrow, d_grec;
+  DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
@@ -341,6 +341,7 @@ void wire_args(agbnp_hip_context* c) {
     P.hrow = c->d_hrow.p;
     P.bw = c->d_bw.p;
     P.grec = c->d_grec.p;
+    P.hrec = c->d_hrec.p;
     const size_t tab = (size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1);
     P.pw_a = c->d_pw.p;
     P.pw_b = c->d_pw.p ? c->d_pw.p + tab : nullptr;
@@ -440,6 +441,7 @@ int allocate_rows(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_aperm.upload(aperm));
   // a list part takes every kBornParts-th (kChainParts-th) chunk of 64 candidates: it can hold all of them, up to the cap
   auto part_stride = [&](size_t candidates, int parts) { return std::max(128, std::min(64 * (int)((candidates / 64 + parts - 1) / parts), kRowCap)); };
+  static_assert(kRowCap % 256 == 0, "a list is walked in slices of 256 entries");
   c->nlh_stride = part_stride(hperm.size(), kBornParts);
   c->nla_stride = part_stride(aperm.size(), kChainParts);
   if (getenv("AGBNP_HIP_ROW_STRIDE")) c->nlh_stride = c->nla_stride = std::max(128, atoi(getenv("AGBNP_HIP_ROW_STRIDE")));  // (tests: force an overflow)
@@ -467,6 +469,8 @@ int allocate_rows(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_rec_h.alloc(nh));
   HIP_TRY(c, c->d_hrow.alloc(nh));
   HIP_TRY(c, c->d_grec.alloc(n));
+  HIP_TRY(c, c->d_hrec.alloc(nh));
+  HIP_TRY(c, hipMemset(c->d_hrec.p, 0, sizeof(double4) * nh));
   HIP_TRY(c, hipMemset(c->d_bw.p, 0, sizeof(double) * n));
   HIP_TRY(c, hipMemset(c->d_grec.p, 0, sizeof(double4) * n));
   // Power form of the natural cubic spline on interval k (t in [0, 1)): S = c0 + c1 t + c2 t^2 + c3 t^3 with the same

@@ -119,14 +119,15 @@ struct PairArgs {
   double4* rec_h;          // [nh] {x, y, z, 1 / V_vdw} by heavy index (k_prep): what a Born row gathers of a neighbour (+ its self volume)
   double4* hrow;           // [nh] {x, y, z, atom | screener type << 24} by heavy index (k_prep): a chain-rule row's own record
   double* bw;              // [n] brw + bru by atom: the GB stage adds alpha_i (diagonal tile) + beta_i * (Y of the tile) with atomics
-  double4* grec;           // [n] {G_x, G_y, G_z, -} of the Born rows: G_i = sum_j (r_j - r_i) s_j Q'_ij / d
+  double4* grec;           // [n] {G_x, G_y, G_z, -} of the Born rows: G_i = sum_j (r_j - r_i) s_j Q'_ij / d (atomic sums)
+  double4* hrec;           // [nh] {H_x, H_y, H_z, -} of the chain-rule rows, by heavy index (atomic sums)
   const unsigned *bslice, *cslice;  // [groups] the table slices (= types) of a group's four row atoms, one byte each (Born / chain-rule groups)
   const double2 *pw_a, *pw_b;    // power-form spline coefficients {c0, c1}, {c2, c3} by [screened][screener][15 intervals]
   const double2 *pwt_a, *pwt_b;  // the same by [screener][screened][15]
 };
 constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
 constexpr int kChainParts = 4;  // waves (list parts) per group of chain-rule rows
-constexpr int kBornParts = 4;   // ... per group of Born rows
+constexpr int kBornParts = 2;   // ... per group of Born rows
 
 // Optional per-kernel timing: an event is recorded on the evaluation's stream in front of every kernel
 // (and one after the last); durations are read back after the stream has been synchronised.

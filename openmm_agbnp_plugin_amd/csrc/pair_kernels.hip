@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
-  if (P.rows_on) P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
+  if (P.rows_on) {
+    P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
+    P.grec[i] = make_double4(0.0, 0.0, 0.0, 0.0);  // ... G through the Born rows'
+  }
   P.gb_fx[i] = 0.0;  // GB sums arrive through atomics
   P.gb_fy[i] = 0.0;
   P.gb_fz[i] = 0.0;
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
     if (P.rows_on) {
       P.rec_h[h] = make_double4(x, y, z, P.inv_vol_h[h]);
+      P.hrec[h] = make_double4(0.0, 0.0, 0.0, 0.0);  // H arrives through the chain-rule rows' atomics
       P.hrow[h] = make_double4(x, y, z, __hiloint2double(0, i | (P.ameta[i].y << 24)));
     }
   }
@@ -1583,27 +1587,38 @@ __device__ __forceinline__ int row_build(const RowAtoms& A, const unsigned* __re
   return cnt;
 }
 
+// Work items: a list is walked in SLICES of kRowSlice entries (four steps), one wave each, so that no wave works longer
+// than four steps whatever the length of its list (the launch lasts as long as its slowest wave); item = slice * lists +
+// list, eight consecutive items per workgroup (a workgroup's items are the same slice of eight neighbouring lists: it is
+// empty as a whole, and leaves at once, or not at all).  The sums of a wave leave as one set of FP64 atomics.
+constexpr int kRowSlice = 256, kRowWaves = 8;
+
 template <bool kChain>
-__global__ __launch_bounds__(256) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
-  constexpr int R = kRowGroup, NP = kChain ? kChainParts : kBornParts, G = 4 / NP;  // G groups of NP waves per workgroup
-  static_assert(4 % NP == 0 && R == 4, "a workgroup of four waves holds whole groups; the butterfly below folds 16 sums");
+// (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers)
+__global__ __launch_bounds__(64 * kRowWaves, 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
+  constexpr int R = kRowGroup, NP = kChain ? kChainParts : kBornParts;
+  static_assert(R == 4, "the butterfly below folds 16 sums");
   extern __shared__ double2 s_dyn[];
-  __shared__ double s_comb[4][4][4 * R];  // [wave][16-lane row of the wave][sum]
+  __shared__ int s_busy;
   int blk = blockIdx.x;
-  if (kChain) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles)
+  if (kChain) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
+    if (blk < 2 && threadIdx.x >= 256) return;
     if (blk == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
     if (blk == 1) return dealing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
     blk -= 2;
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int born_groups = (P.n + R - 1) / R, chain_groups = (P.nh + R - 1) / R;
-  const int born_blocks = (born_groups * kBornParts + 3) >> 2, chain_blocks = (chain_groups * kChainParts + 3) >> 2;
+  const int stride = kChain ? P.nla_stride : P.nlh_stride;
+  const int nlists = (kChain ? chain_groups : born_groups) * NP, lists_pad = (nlists + kRowWaves - 1) & ~(kRowWaves - 1);
+  const int slices = (stride + kRowSlice - 1) / kRowSlice;
+  const int walk_blocks = lists_pad / kRowWaves * slices;
   const int stale = P.nl_flag[0];
-  if (!kChain && blk >= born_blocks) {
+  if (!kChain && blk >= walk_blocks) {
     // The chain-rule lists are built here, in the Born launch, by workgroups that exit at once in an evaluation whose
     // lists are still good.
     if (!stale) return;
-    const int sub = (blk - born_blocks) * 4 + wave;
+    const int sub = (blk - walk_blocks) * kRowWaves + wave;
     if (sub >= chain_groups * kChainParts) return;
     const int g = sub / kChainParts, part = sub - g * kChainParts;
     const RowAtoms A = row_atoms<true>(P, g);
@@ -1615,83 +1630,79 @@ __global__ __launch_bounds__(256) void k_rows(PairArgs P, double* __restrict__ e
     }
     return;
   }
-  if (kChain && blk >= chain_blocks) {  // hydrogens screen nobody: their chain-rule force is bw_a G_a
-    const int a = (blk - chain_blocks) * 256 + (int)threadIdx.x;
-    if (a < P.n && P.a2h[a] < 0) {
-      const double4 g = P.grec[a];
-      const double bwa = P.bw[a];
-      P.db_fx[a] = bwa * g.x;
-      P.db_fy[a] = bwa * g.y;
-      P.db_fz[a] = bwa * g.z;
-    }
-    return;
-  }
   PAIR_STAMP((kChain ? 2 : 0), 0);
-  const int sub = blk * 4 + wave;  // (group, part)
-  const int ngroups = kChain ? chain_groups : born_groups;
-  const bool active = sub / NP < ngroups;
-  const int group = min(sub / NP, ngroups - 1), part = sub % NP;
-  const int stride = kChain ? P.nla_stride : P.nlh_stride;
-  const unsigned* list = (kChain ? P.nla : P.nlh) + (size_t)(active ? sub : 0) * stride;  // (not restrict: a build rewrites it)
-  // Everything that does not depend on anything is asked for at once: the row atoms, the types of their table slices, the
-  // length of the list and its first two steps (the lists start out zeroed: an entry beyond the length is a valid index).
-  const int listed = active ? (kChain ? P.nla_count : P.nlh_count)[sub] : 0;
-  const unsigned slices = (kChain ? P.cslice : P.bslice)[group];  // one byte per row
-  unsigned e1 = list[lane], e2 = list[64 + lane];
-  // the whole table goes to LDS ({c0, c1} of every entry, then {c2, c3}): which slices the group needs is not waited for
-  const int ne = (kChain ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice
-  const int tab = P.nti * P.ntj * kRowIntervals;            // ... of the table
-  double2* const s_tab = s_dyn;
-  {
-    const double2* __restrict__ ga = kChain ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
-    for (int base = 0; base < 2 * tab; base += 256 * 4) {
-      double2 v[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) v[q] = ga[min(base + 256 * q + (int)threadIdx.x, 2 * tab - 1)];
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (base + 256 * q + (int)threadIdx.x < 2 * tab) s_tab[base + 256 * q + threadIdx.x] = v[q];
-    }
-  }
+  const int item = blk * kRowWaves + wave;
+  const int slice = item / lists_pad, li = item - slice * lists_pad;  // (a workgroup's eight items share the slice)
+  const bool active = li < nlists;
+  const int sub = active ? li : 0;  // (group, part)
+  const int group = sub / NP, part = sub - group * NP;
+  const unsigned* list = (kChain ? P.nla : P.nlh) + (size_t)sub * stride;  // (not restrict: a build rewrites it)
+  const int first = kRowSlice * slice;
+  // Everything that does not depend on anything is asked for at once: the length of the list, the first two steps of the
+  // slice (the lists start out zeroed: an entry beyond the length is a valid index), the row atoms and their types, the table.
+  const int listed = (kChain ? P.nla_count : P.nlh_count)[sub];
+  unsigned e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
+  const unsigned types = (kChain ? P.cslice : P.bslice)[group];  // one byte per row
   const RowAtoms A = row_atoms<kChain>(P, group);
-  PAIR_STAMP_WAIT((kChain ? 2 : 0), 7, "vmcnt(0) lgkmcnt(0)");  // the row atoms are here
-  int slice_at[R];  // first entry of the row's slice
+  const int ne = (kChain ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice of the table (one row type)
+  const int tab = P.nti * P.ntj * kRowIntervals;            // ... of the table: {c0, c1} of every entry, then {c2, c3}
+  double2* const s_tab = s_dyn;
+  constexpr int kWg = 64 * kRowWaves;
+  const double2* __restrict__ gtab = kChain ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
+  const int tx = threadIdx.x;
+  // a workgroup whose eight slices are all beyond the ends of their lists has nothing to do (not known while the lists
+  // are being rebuilt); it leaves before it asks for the table: nearly half of the workgroups of a launch are such
+  if (threadIdx.x == 0) s_busy = 0;
+  __syncthreads();
+  const bool mine = active && (stale || first < listed);
+  if (mine && lane == 0) s_busy = 1;
+  __syncthreads();
+  if (!s_busy) return;
+  const double2 tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
+  PAIR_STAMP_WAIT((kChain ? 2 : 0), 7, "vmcnt(0) lgkmcnt(0)");
+  if (tx < 2 * tab) s_tab[tx] = tv0;
+  if (kWg + tx < 2 * tab) s_tab[kWg + tx] = tv1;
+  if (2 * kWg + tx < 2 * tab) s_tab[2 * kWg + tx] = tv2;
+  for (int base = 3 * kWg; base < 2 * tab; base += kWg)  // (larger tables)
+    if (base + tx < 2 * tab) s_tab[base + tx] = gtab[base + tx];
+  int slice_at[R];  // first entry of the row's slice of the table
 #pragma unroll
-  for (int r = 0; r < R; r++) slice_at[r] = uniform((int)((slices >> (8 * r)) & 0xffu) * ne);
+  for (int r = 0; r < R; r++) slice_at[r] = uniform((int)((types >> (8 * r)) & 0xffu) * ne);
   int count = listed;
-  if (!kChain && stale) {
-    count = active ? row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2,
-                               P.nlh + (size_t)sub * stride, stride, lane) : 0;
-    if (active && lane == 0) {
+  if (!kChain && stale && active) {
+    // every slice of a list rebuilds the list for itself (the same entries at the same places: the copies agree), so that
+    // no wave waits for another workgroup's
+    count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
+    if (lane == 0 && slice == 0) {
       P.nlh_count[sub] = min(count, stride);
       if (count > stride) P.status[kStatRowOverflow] = 1;
       if (sub == 0) P.nl_flag[1] += 1;  // (builds so far: agbnp_hip_get_scalar)
     }
-    if (active && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
+    if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
       const int a = kRowGroup * group + lane;
       P.nl_ref[3 * a] = P.pos[3 * a], P.nl_ref[3 * a + 1] = P.pos[3 * a + 1], P.nl_ref[3 * a + 2] = P.pos[3 * a + 2];
     }
     count = min(count, stride);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
-    e1 = list[lane], e2 = list[64 + lane];
+    e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
+  const int todo = active ? max(0, min(count - first, kRowSlice)) : 0;  // entries of this slice
   const double4* __restrict__ rec = kChain ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
   const double* __restrict__ wsrc = kChain ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
-  const int nsteps = (count + 63) >> 6;
+  const int nsteps = (todo + 63) >> 6;
   // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
   // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
   double4 r1 = rec[e1 & 0xffffffu];
   double w1 = wsrc[e1 & 0xffffffu];
-  __syncthreads();  // the slices are in LDS
+  __syncthreads();  // the table is in LDS
   PAIR_STAMP((kChain ? 2 : 0), 8);
   double acc[4 * R];
 #pragma unroll
   for (int q = 0; q < 4 * R; q++) acc[q] = 0.0;
   PAIR_STAMP_WAIT((kChain ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
 #ifdef AGBNP_PAIR_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(kChain ? 2 : 0)][blockIdx.x][6] = (unsigned)count, g_pair_log[(kChain ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
+  if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(kChain ? 2 : 0)][blockIdx.x][6] = (unsigned)todo, g_pair_log[(kChain ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
 #endif
-  const int last = stride - 1;
   constexpr double kPerNode = (kI4Nodes - 1) / kI4MaxA;
   for (int k = 0; k < nsteps; k++) {
     const unsigned e = e1;
@@ -1700,11 +1711,11 @@ __global__ __launch_bounds__(256) void k_rows(PairArgs P, double* __restrict__ e
     e1 = e2;
     r1 = rec[e1 & 0xffffffu];
     w1 = wsrc[e1 & 0xffffffu];
-    e2 = list[min(64 * (k + 2) + lane, last)];
+    e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
     const int b = (int)(e & 0xffffffu);
     const int tent = (int)(e >> 24) * kRowIntervals;
     const double w = (kChain ? wb : wb * rb.w) * kPerNode;  // bw_b, or s_b = selfvol_b / V_b (times the table's d(t)/d(d))
-    const double range2 = 64 * k + lane < count ? P.range2 : -1.0;  // (a lane beyond the list meets nobody)
+    const double range2 = 64 * k + lane < todo ? P.range2 : -1.0;  // (a lane beyond the slice meets nobody)
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
@@ -1727,49 +1738,29 @@ __global__ __launch_bounds__(256) void k_rows(PairArgs P, double* __restrict__ e
     }
   }
   PAIR_STAMP((kChain ? 2 : 0), 2);
-  // 16 sums per lane -> one per lane and 16-lane row: four transposing butterfly stages (a lane keeps the half of the sums
-  // that its bit of the stage selects and adds its partner's copy of them; DPP moves, no LDS)
-  {
-    const bool u0 = lane & 1, u1 = lane & 2, u2 = lane & 4, u3 = lane & 8;
+  if (nsteps == 0) return;
+  // 16 sums per lane -> one per lane: four transposing butterfly stages (a lane keeps the half of the sums that its bit of
+  // the stage selects and adds its partner's copy of them; DPP moves), then the four 16-lane rows of the wave are added up
+  const bool u0 = lane & 1, u1 = lane & 2, u2 = lane & 4, u3 = lane & 8;
 #pragma unroll
-    for (int q = 0; q < 8; q++) acc[q] = (u0 ? acc[q + 8] : acc[q]) + lane_xor1(u0 ? acc[q] : acc[q + 8]);
+  for (int q = 0; q < 8; q++) acc[q] = (u0 ? acc[q + 8] : acc[q]) + lane_xor1(u0 ? acc[q] : acc[q + 8]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) acc[q] = (u1 ? acc[q + 4] : acc[q]) + lane_xor2(u1 ? acc[q] : acc[q + 4]);
+  for (int q = 0; q < 4; q++) acc[q] = (u1 ? acc[q + 4] : acc[q]) + lane_xor2(u1 ? acc[q] : acc[q + 4]);
 #pragma unroll
-    for (int q = 0; q < 2; q++) acc[q] = (u2 ? acc[q + 2] : acc[q]) + lane_xor4(u2 ? acc[q] : acc[q + 2]);
-    acc[0] = (u3 ? acc[1] : acc[0]) + lane_xor8(u3 ? acc[0] : acc[1]);
-    // bit s of the lane chose the halves of stage s: the lane's sum is number bit-reversed(lane & 15); the unit of the
-    // value sums goes back in (w carried the table's d(t)/d(d) for the derivatives)
-    const int q = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    s_comb[wave][lane >> 4][q] = (q & 3) == 0 ? acc[0] * (1.0 / kPerNode) : acc[0];
-  }
-  __syncthreads();
-  PAIR_STAMP((kChain ? 2 : 0), 10);
-  // one thread per row of the workgroup: the sums of the parts and of their 16-lane rows, then the row's results
-  const int t = threadIdx.x;
-  if (t >= G * R) return;
-  const int gw = t / R, r = t % R;                 // group of the workgroup, row of the group
-  const int tgroup = (blk * 4 + gw * NP) / NP;
-  const int nrows = kChain ? P.nh : P.n;
-  const int row = R * tgroup + r;
-  if (tgroup >= ngroups || row >= nrows) return;
-  double sv = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-  for (int p = 0; p < NP; p++)
-    for (int lr = 0; lr < 4; lr++) {
-      const double* c = s_comb[gw * NP + p][lr] + 4 * r;
-      sv += c[0], sx += c[1], sy += c[2], sz += c[3];
-    }
-  if (!kChain) {
-    P.born_part[row] = sv;
-    P.grec[row] = make_double4(sx, sy, sz, 0.0);
-  } else {
-    const int atom = __double2loint(static_cast<const double4*>(P.hrow)[row].w) & 0xffffff;
-    const double sa = P.sv_vdw[row] * P.inv_vol_h[row], bwa = P.bw[atom];
-    const double4 g = P.grec[atom];
-    P.db_wu[row] = sv;
-    P.db_fx[atom] = fma(bwa, g.x, sa * sx);
-    P.db_fy[atom] = fma(bwa, g.y, sa * sy);
-    P.db_fz[atom] = fma(bwa, g.z, sa * sz);
+  for (int q = 0; q < 2; q++) acc[q] = (u2 ? acc[q + 2] : acc[q]) + lane_xor4(u2 ? acc[q] : acc[q + 2]);
+  double total = (u3 ? acc[1] : acc[0]) + lane_xor8(u3 ? acc[0] : acc[1]);
+  total += __shfl_xor(total, 16, 64);
+  total += __shfl_xor(total, 32, 64);
+  // bit s of the lane chose the halves of stage s: the lane's sum is number bit-reversed(lane & 15) = 4 * row + quantity
+  const int q = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+  const int r = q >> 2, c = q & 3;
+  if (lane < 16 && r < A.rows) {
+    const int row = R * group + r;  // atom (Born rows) or heavy index (chain-rule rows)
+    // (the unit of the value sums goes back in: w carried the table's d(t)/d(d) for the derivatives)
+    if (c == 0)
+      hbm_add(kChain ? &P.db_wu[row] : &P.born_part[row], total * (1.0 / kPerNode));
+    else
+      hbm_add(reinterpret_cast<double*>((kChain ? P.hrec : P.grec) + row) + (c - 1), total);
   }
   PAIR_STAMP((kChain ? 2 : 0), 3);
 }
@@ -1806,7 +1797,17 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     fy = -P.gy[h];
     fz = -P.gz[h];
   }
-  if (version == 1) {
+  if (version == 1 && P.rows_on) {
+    // chain-rule force of the row form: bw_i G_i + s_i H_i (the second term for heavy atoms only, see k_rows)
+    const double bwi = P.bw[i];
+    const double4 g = P.grec[i];
+    double sh = 0.0;
+    double4 hh = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (h >= 0) sh = P.sv_vdw[h] * P.inv_vol_h[h], hh = P.hrec[h];
+    fx += P.gb_fx[i] + fma(bwi, g.x, sh * hh.x);
+    fy += P.gb_fy[i] + fma(bwi, g.y, sh * hh.y);
+    fz += P.gb_fz[i] + fma(bwi, g.z, sh * hh.z);
+  } else if (version == 1) {
     fx += P.gb_fx[i] + P.db_fx[i];
     fy += P.gb_fy[i] + P.db_fy[i];
     fz += P.gb_fz[i] + P.db_fz[i];
@@ -1860,18 +1861,20 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   if (P.rows_on) {  // row form of the two range-limited stages
     auto gb = k_gb_tiles<false, false>;
     const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
-    const int born_blocks = (born_groups * kBornParts + 3) / 4, chain_blocks = (chain_groups * kChainParts + 3) / 4;
+    auto walk_blocks = [](int lists, int stride) { return (lists + kRowWaves - 1) / kRowWaves * ((stride + kRowSlice - 1) / kRowSlice); };
+    const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_stride), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_stride);
+    const int build_blocks = (chain_groups * kChainParts + kRowWaves - 1) / kRowWaves;  // the chain-rule lists are built in the Born launch
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
     AGBNP_MARK(kKBornRows);
-    hipLaunchKernelGGL(k_rows<false>, dim3(born_blocks + chain_blocks), dim3(256), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    hipLaunchKernelGGL(k_rows<false>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
     AGBNP_CHECK_LAUNCH();
     AGBNP_MARK(kKGbTiles);
     hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
                        (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
     AGBNP_CHECK_LAUNCH();
     AGBNP_MARK(kKDbornRows);
-    hipLaunchKernelGGL(k_rows<true>, dim3(2 + chain_blocks + (P.n + 255) / 256), dim3(256), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    hipLaunchKernelGGL(k_rows<true>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
     AGBNP_CHECK_LAUNCH();
     return hipSuccess;
   }

@@ -27,7 +27,7 @@ for kern, nm in ((0, "k_rows<born>"), (2, "k_rows<chain>")):
     us = lambda v: (v - t0) / 100.0
     print(f"== {nm}: {int(ok.sum())} working workgroups; entries from 0 to {us(W[:, 0]).max():.2f} us; last end {us(W[:, 3]).max():.2f} us")
     phases = (("entry -> row atoms", W[:, 7] - W[:, 0]), ("-> slices in LDS (barrier)", W[:, 8] - W[:, 7]), ("-> first records", W[:, 1] - W[:, 8]),
-              ("loop", W[:, 2] - W[:, 1]), ("butterfly + barrier", W[:, 10] - W[:, 2]), ("results", W[:, 3] - W[:, 10]), ("lifetime", W[:, 3] - W[:, 0]))
+              ("loop", W[:, 2] - W[:, 1]), ("sums -> atomics", W[:, 3] - W[:, 2]), ("lifetime", W[:, 3] - W[:, 0]))
     for pn, v in phases:
         v = v / 100.0
         print(f"   {pn:28s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
@@ -35,4 +35,6 @@ for kern, nm in ((0, "k_rows<born>"), (2, "k_rows<chain>")):
     loop = (W[:, 2] - W[:, 1]) / 100.0
     print(f"   entries per part: mean {W[:, 6].mean():.0f} max {W[:, 6].max():.0f}; steps mean {steps.mean():.1f}; us per step {np.median(loop / np.maximum(steps, 1)):.3f}")
     end = us(W[:, 3])
+    ent = us(W[:, 0])
+    print(f"   entries: p50 {np.median(ent):.2f} p90 {np.percentile(ent, 90):.2f} p99 {np.percentile(ent, 99):.2f} max {ent.max():.2f}")
     print(f"   ends: p10 {np.percentile(end, 10):.2f} p50 {np.median(end):.2f} p90 {np.percentile(end, 90):.2f} max {end.max():.2f}")
