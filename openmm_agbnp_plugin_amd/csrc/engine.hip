@@ -109,6 +109,7 @@ struct agbnp_hip_context {
   DevBuf<double> d_nl_ref, d_bw;
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
+  bool fused_outputs = true;   // version 1: the pseudo-volume launch adds the forces itself (AGBNP_HIP_OUTPUT_LAUNCH=1: k_outputs does)
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
   double skin = 0.1;           // nm; AGBNP_HIP_SKIN
@@ -631,7 +632,29 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
+    // the forces leave with the pseudo-volume launch itself (TreeOutputs, tree_kernels.h): no output launch
+    TreeOutputs& O = c->T.out;
+    const bool fused = c->fused_outputs && c->nh > 0;  // (no heavy atom: no tree launch to carry them)
+    O.enabled = fused ? 1 : 0;
+    O.n = c->n;
+    O.a2h = c->d_a2h.p;
+    O.h2a = c->d_h2a.p;
+    O.force = c->P.omm.force_fixed ? nullptr : d_force;
+    O.force_fixed = c->P.omm.force_fixed;
+    O.padded = c->P.omm.padded;
+    O.ctx_slot = c->P.omm.ctx_slot;
+    O.gb_f = c->P.gb_fx;
+    O.db_f = c->P.db_fx;
+    O.rows_on = c->P.rows_on;
+    O.bw = c->P.bw;
+    O.grec = c->P.grec;
+    O.hrec = c->P.hrec;
+    O.nl_flag = c->P.nl_flag;
     HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, tree_grid, c->T, st));
+    if (fused) {
+      if (tl) HIP_TRY(c, tl->mark(-1, st));
+      return AGBNP_HIP_OK;
+    }
   }
   HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
   return AGBNP_HIP_OK;
@@ -750,6 +773,7 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   c->method = nonbonded_method;
   c->cutoff = cutoff;
   c->device = device;
+  c->fused_outputs = getenv("AGBNP_HIP_OUTPUT_LAUNCH") == nullptr;
   c->r_vdw.assign(radius, radius + n);
   c->gamma.resize(n);
   c->alpha.assign(vdw_alpha, vdw_alpha + n);

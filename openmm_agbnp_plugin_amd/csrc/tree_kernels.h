@@ -56,7 +56,27 @@ enum HeavyRow {
   kHvRows
 };
 
+// Where the forces of an AGBNP1 evaluation leave (version 1): the pseudo-volume launch is the last one that contributes to
+// them, so it adds them to the caller's buffer itself -- its forest workgroups their own gradients, a few workgroups at
+// the end of its grid everything that was complete before it started -- and the evaluation needs no output launch.
+struct TreeOutputs {
+  int enabled;                 // 0: k_tree_pseudo adds into the heavy-atom table's gradient rows and k_outputs follows
+  int n;                       // particles
+  int forest_blocks;           // workgroups of the launch that replay forests (the output workgroups follow them)
+  const int *a2h, *h2a;        // [n] atom -> heavy index or -1, [nh] back
+  double* force;               // [3n] the caller's FP64 forces (added to) ...
+  unsigned long long* force_fixed;  // ... or an OpenMM context's 2^32 fixed-point planes [3 * padded] at ctx_slot[atom]
+  int padded;
+  const int* ctx_slot;
+  const double *gb_f, *db_f;   // [3][n] GB direct force, chain-rule force (tile form), rows x | y | z
+  int rows_on;                 // chain-rule force of the row form instead: bw_i G_i + s_i H_i
+  const double* bw;            // [n]
+  const double4 *grec, *hrec;  // [n], [nh]
+  int* nl_flag;                // row form: [0] is cleared (this evaluation's neighbour lists are up to date)
+};
+
 struct TreeArgs {
+  TreeOutputs out;
   int nh;                      // heavy atoms
   unsigned hstride;            // row stride of the heavy-atom table
   double* hv;                  // [kHvRows][hstride]

@@ -88,9 +88,10 @@ __device__ unsigned long long g_wg_log[kWgLogSlots][24];
 // CU's time is proportional to the nodes it has to build (a workgroup timeline of 1dwc with one forest per
 // workgroup: CUs that happened to receive 1000 nodes finished at 68 us, CUs with 500 nodes at 35 us, and the kernel
 // lasts as long as its unluckiest CU), and the hardware dispatcher knows nothing about forest sizes.
-__device__ __forceinline__ int next_forest(int tid, int* lds_word, int ticket) {
+__device__ __forceinline__ int next_forest(int tid, int* lds_word, int ticket, int grid) {
   // ticket: what this workgroup's atomicAdd on the queue returned (lane 0); every lane gets the same next slot
-  if (tid == 0) *lds_word = (int)gridDim.x + ticket;
+  // grid: forest workgroups of the launch (each started on the forest of its own number)
+  if (tid == 0) *lds_word = grid + ticket;
   lds_barrier();
   const int slot = *lds_word;
   lds_barrier();
@@ -267,8 +268,56 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     CSTAMP_FLUSH();
     } while (false);
     if (!queued) break;
-    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
+    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, (int)gridDim.x));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
   }
+}
+
+// ---- the forces leave with the last tree launch (TreeOutputs) ------------------------------------------------------
+__device__ __forceinline__ bool evaluation_void(const int* __restrict__ status) {  // an overflowed evaluation adds nothing
+  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow]) != 0;
+}
+__device__ __forceinline__ void add_force(const TreeOutputs& O, int atom, double fx, double fy, double fz) {
+  if (O.force_fixed) {
+    // an OpenMM context's force buffer: 64-bit fixed point, value * 2^32 rounded to nearest, three planes over the padded
+    // atom count in the context's atom order, integer atomics (GVolReduceTree.cl:117-119)
+    auto to_fixed = [](double f) { return (unsigned long long)(long long)rint(f * 4294967296.0); };
+    const int s = O.ctx_slot[atom];
+    atomicAdd(&O.force_fixed[s], to_fixed(fx));
+    atomicAdd(&O.force_fixed[s + O.padded], to_fixed(fy));
+    atomicAdd(&O.force_fixed[s + 2 * O.padded], to_fixed(fz));
+  } else {
+    glb_add(&O.force[3 * atom], fx);
+    glb_add(&O.force[3 * atom + 1], fy);
+    glb_add(&O.force[3 * atom + 2], fz);
+  }
+}
+// everything that was complete before the pseudo-volume launch began: cavity gradients (rows of the heavy-atom table), GB
+// direct force, chain-rule force; one atom per lane.  (Atomic adds: the forest workgroups add to the same words.)
+__device__ __forceinline__ void outputs_role(const TreeArgs& A, int blk, int bs) {
+  const TreeOutputs& O = A.out;
+  const int i = blk * bs + (int)threadIdx.x;
+  if (O.rows_on && i == 0) O.nl_flag[0] = 0;
+  if (i >= O.n) return;
+  const int h = O.a2h[i];
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+  if (h >= 0) fx = -A.hvat(kHvGx, h), fy = -A.hvat(kHvGy, h), fz = -A.hvat(kHvGz, h);
+  const size_t n = (size_t)O.n;
+  if (O.rows_on) {  // bw_i G_i + s_i H_i (pair_kernels.hip, k_rows)
+    const double bwi = O.bw[i];
+    const double4 g = O.grec[i];
+    double sh = 0.0;
+    double4 hh = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (h >= 0) sh = A.hvat(kHvSvVdw, h) * A.hvat(kHvInvVol, h), hh = O.hrec[h];
+    fx += O.gb_f[i] + fma(bwi, g.x, sh * hh.x);
+    fy += O.gb_f[n + i] + fma(bwi, g.y, sh * hh.y);
+    fz += O.gb_f[2 * n + i] + fma(bwi, g.z, sh * hh.z);
+  } else {
+    fx += O.gb_f[i] + O.db_f[i];
+    fy += O.gb_f[n + i] + O.db_f[n + i];
+    fz += O.gb_f[2 * n + i] + O.db_f[2 * n + i];
+  }
+  if (evaluation_void(A.status)) return;
+  add_force(O, i, fx, fy, fz);
 }
 
 // Replay of a stored forest with vdW radii: reference steps K+L (ReferenceAGBNPKernels.cpp:718-747),
@@ -278,13 +327,20 @@ template <int NCAP, int ACAP, int BS, bool GLOBAL>
 __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
-  S.carve_replay(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;
   const int tid = threadIdx.x;
+  // forest workgroups of the launch; the output workgroups come FIRST in the grid (they only need what earlier launches
+  // left, and would otherwise wait for a forest workgroup to leave before they get a slot)
+  const int grid = A.out.enabled ? A.out.forest_blocks : (int)gridDim.x;
+  const int out_blocks = (int)gridDim.x - grid;
+  if ((int)blockIdx.x < out_blocks) return outputs_role(A, blockIdx.x, BS);
+  const int block = (int)blockIdx.x - out_blocks;  // number of the forest workgroup
+  S.carve_replay(GLOBAL ? (A.scratch + (size_t)block * A.scratch_stride) : smem);
+  const bool write_forces = A.out.enabled != 0;
   const int nforests = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
   // The workgroup's own work slot needs no test: k_tree_cavity leaves "nothing to replay" in the header of an idle slot,
   // so the forest's topology is requested straight away.
-  for (int slot = blockIdx.x;;) {
+  for (int slot = block;;) {
     int ticket = 0x3fffffff;  // (a forest that asks for no successor ends the workgroup's run)
     do {
     PSTAMP_BEGIN();
@@ -313,7 +369,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     }
     const int nnodes = H->nnodes, natoms = H->natoms, m = H->nroots;
     int npairs = H->npairs;
-    const bool queued = nforests > (int)gridDim.x;
+    const bool queued = nforests > grid;
     if (nnodes <= m) {  // not built (capacity overflow: the host repeats the evaluation), lone atoms only, or an idle slot
       if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
       break;
@@ -349,7 +405,8 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
       S.at[6][la] = 0.0;
       S.at[7][la] = 0.0;
       S.at[8][la] = 0.0;
-      S.at[9][la] = 0.0;
+      // (the self-volume accumulators are idle in this pass: the slot carries the atom's index for the flush)
+      S.at[9][la] = write_forces ? __hiloint2double(0, A.out.h2a[hj]) : 0.0;
     }
     tree_barrier<NCAP>();
     PSTAMP(0);
@@ -359,18 +416,23 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     volume_pass<NCAP, ACAP, BS, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, A.det != 0, kPairs ? pair_word : nullptr);
     PSTAMP(1);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
-    for (int la = tid; la < natoms; la += BS) {
-      const int hj = S.at_gidx[la];
-      glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
-      glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
-      glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+    if (write_forces) {  // force = -gradient, straight into the caller's buffer (nothing of an overflowed evaluation)
+      if (!evaluation_void(A.status))
+        for (int la = tid; la < natoms; la += BS) add_force(A.out, __double2loint(S.at[9][la]), -S.at[6][la], -S.at[7][la], -S.at[8][la]);
+    } else {
+      for (int la = tid; la < natoms; la += BS) {
+        const int hj = S.at_gidx[la];
+        glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+        glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+        glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+      }
     }
     tree_barrier<NCAP>();
     PSTAMP(2);
     PSTAMP_FLUSH();
     } while (false);
-    if (nforests <= (int)gridDim.x) break;  // every forest has a workgroup of its own
-    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
+    if (nforests <= grid) break;  // every forest has a workgroup of its own
+    slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, grid));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
     if (slot >= nforests) break;
   }
 }
@@ -477,15 +539,18 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
   }
 }
 
-hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
-  if (A.nh <= 0) return hipSuccess;
+hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A0, hipStream_t st) {
+  if (A0.nh <= 0) return hipSuccess;
+  // the forces leave with this launch (TreeOutputs): its forest workgroups are followed by one lane per atom
+  TreeArgs A = A0;
+  A.out.forest_blocks = variant <= 3 ? slots : (global_grid < A.nh ? global_grid : A.nh);
+  const int grid = A.out.forest_blocks + (A.out.enabled ? (A.out.n + kBS - 1) / kBS : 0);
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, slots, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
-    case 1: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, slots, TreeStore<512, 64>::kReplayBytes, A, st);
-    case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, slots, TreeStore<1024, 128>::kReplayBytes, A, st);
-    case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, slots, TreeStore<2048, 256>::kReplayBytes, A, st);
-    default:
-      return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, global_grid < A.nh ? global_grid : A.nh, 0, A, st);
+    case 0: return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
+    case 1: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
+    case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);
+    case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, grid, TreeStore<2048, 256>::kReplayBytes, A, st);
+    default: return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, grid, 0, A, st);
   }
 }
 
