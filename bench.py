@@ -266,6 +266,52 @@ def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_
     return entry
 
 
+def openmm_entry(torch, name, device, dev_index, steps, warmup):
+    """ms per evaluation through agbnp_hip_execute_openmm (an OpenMM GPU context's conventions: posq in the context's atom
+    order + atomIndex, fixed-point force planes, energy buffer) under the three host protocols of the glue: a blocking
+    finish() after every evaluation (strict, the reference's own protocol), a non-blocking poll() after every evaluation
+    (finish only on demand), and a finish every 64 evaluations."""
+    system = load_workload(name)
+    n = system.n
+    padded = (n + 31) // 32 * 32
+    force = P.AGBNPForce.from_arrays(*system.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
+    kernel.initialize(force)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)  # context slot -> particle
+    geoms = [system.jittered(5000 + k) for k in range(steps + warmup)]
+    posq = np.zeros((len(geoms), padded, 4))
+    for k, g in enumerate(geoms):
+        posq[k, :n, :3] = g[perm]
+    d_posq = torch.tensor(posq, dtype=torch.float64, device=device).contiguous()
+    d_index = torch.tensor(np.concatenate([perm, np.arange(n, padded)]), dtype=torch.int32, device=device)
+    d_force = torch.zeros((3 * padded,), dtype=torch.int64, device=device)
+    d_energy = torch.zeros((64,), dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    step_bytes = padded * 4 * 8
+
+    def run(k):
+        kernel.execute_openmm(d_posq.data_ptr() + k * step_bytes, True, 0, d_index.data_ptr(), padded, d_force.data_ptr(), d_energy.data_ptr(), True, 0, stream)
+
+    for k in range(warmup):
+        run(k)
+    kernel.finish(stream)
+    out = {"workload": name, "entry_point": "agbnp_hip_execute_openmm (double precision context, shuffled atom order)"}
+    for label, after in (("finish_every_evaluation", lambda k: kernel.finish(stream)),
+                         ("poll_every_evaluation", lambda k: kernel.poll()[1] and kernel.finish(stream)),
+                         ("finish_every_64", lambda k: (k % 64 == 63) and kernel.finish(stream))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            run(k)
+            after(k)
+        torch.cuda.synchronize()
+        out["ms_per_eval_" + label] = 1e3 * (time.perf_counter() - t0) / steps
+        kernel.finish(stream)
+    return out
+
+
 def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, warmup):
     """Aggregate throughput of several INDEPENDENT replicas sharing one GPU, each context on a stream of its own (multiple
     walkers / replica exchange on one device).  The evaluation is bound by dependent latency, not by throughput, so
@@ -564,6 +610,7 @@ def main():
         result["other_modes"] = [dict(mode=m, **secondary_entry(torch, "1dwc", 1, device, dev_index, 200, 20, 0, cutoff=1.0, mode=m))
                                  for m in ("fast", "fast+single", "deterministic")]
         result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(torch, "1dwc", device, dev_index, r, 200, 20) for r in (2, 4)]
+        result["openmm_entry"] = openmm_entry(torch, "1dwc", device, dev_index, 200, 20)
 
     if rank == 0:
         print(json.dumps(result))

@@ -103,6 +103,14 @@ int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
  * and returns their total number (-1: null context). */
 int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, int capacity);
 
+/* Non-blocking look at the overflow log (no device call, no synchronisation): how many of the evaluations enqueued since
+ * the last agbnp_hip_finish() have COMPLETED on the device and how many of those were withheld, read from pinned host
+ * memory that the device writes at the end of every evaluation.  A caller that must not stall its stream every step (an MD
+ * loop) polls this after each enqueue and calls agbnp_hip_finish() only when *withheld is non-zero (or now and then: the
+ * log names at most 2048 evaluations).  What it learns is at least one evaluation old.  The reference's GPU platform does a
+ * blocking read every step instead (OpenCLAGBNPKernels.cpp:3599-3634).  AGBNP_HIP_ERR_DEVICE: no pinned memory. */
+int agbnp_hip_poll(const agbnp_hip_context* ctx, int* evaluations_completed, int* withheld);
+
 /* Changes whenever kernel arguments that a captured HIP graph of agbnp_hip_execute_device has frozen go stale:
  * after a finish() that raised the capacity variant or grew the scratch pools.  A caller that replays a graph
  * compares the value at capture time with the current one after every finish() and re-captures on a difference.

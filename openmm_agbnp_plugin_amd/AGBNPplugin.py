@@ -223,6 +223,15 @@ class HipCalcAGBNPForceKernel:
             raise OpenMMException(_lib.last_error(self._h))
         return int(rep.value)
 
+    def poll(self):
+        """Non-blocking: (evaluations completed since the last finish(), how many of them were withheld), read from pinned
+        host memory the device writes at the end of every evaluation (no device call)."""
+        self._need()
+        done, bad = C.c_int(0), C.c_int(0)
+        if _lib.load().agbnp_hip_poll(self._h, C.byref(done), C.byref(bad)) != _lib.OK:
+            raise OpenMMException("agbnp_hip_poll: no pinned status memory")
+        return int(done.value), int(bad.value)
+
     def withheld(self):
         """Indices (enqueue order since the finish() before the last one) of the evaluations the last finish()
         reported as withheld."""

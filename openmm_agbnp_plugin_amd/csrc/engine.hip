@@ -141,6 +141,7 @@ struct agbnp_hip_context {
   int carried_count = 0, carried_seq = 0;
   bool unfinished = false;      // evaluations enqueued by execute_device / execute_openmm since the last finish
   int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
+  int* h_status = nullptr;      // pinned, mapped: {evaluations completed, withheld} since the last finish (agbnp_hip_poll)
   std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
   int last_rows[2] = {0, 0};   // {stale flag, builds so far} of the row-form neighbour rows, as of the last harvest
   bool have_results = false;
@@ -301,6 +302,10 @@ void wire_args(agbnp_hip_context* c) {
   P.sv_large = c->hrow(kHvSvLarge);
   P.epart = c->d_epart.p;
   P.status = c->d_status.p;
+  {
+    void* dev = nullptr;
+    P.host_status = (c->h_status && hipHostGetDevicePointer(&dev, c->h_status, 0) == hipSuccess) ? static_cast<volatile int*>(dev) : nullptr;
+  }
   P.born_part = c->d_born_part.p;
   P.born = c->d_born.p;
   P.born_fp = c->d_born_fp.p;
@@ -572,6 +577,10 @@ int allocate_work(agbnp_hip_context* c) {
   }
   HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess)
+    c->h_status[0] = c->h_status[1] = c->h_status[2] = c->h_status[3] = 0;
+  else
+    c->h_status = nullptr;  // (agbnp_hip_poll then reports "unknown")
   {
     // level-2 neighbour search: tiles of 64x64 heavy atoms (I <= J), one 64-bit mask per (atom, block)
     const int nhb = (nh + 63) / 64;
@@ -713,6 +722,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow]) : c->have_results;
   if (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0)  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
+  if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
   if (c->withheld_count == 0) return AGBNP_HIP_OK;
   for (int k = 0; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
     if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k);
@@ -1136,6 +1146,16 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* c, int* indices, int
 
 unsigned agbnp_hip_generation(const agbnp_hip_context* c) { return c ? c->generation : 0u; }
 
+int agbnp_hip_poll(const agbnp_hip_context* c, int* evaluations_completed, int* withheld) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!c->h_status) return AGBNP_HIP_ERR_DEVICE;
+  const volatile int* h = c->h_status;
+  const int done = h[0];  // (written after the withheld count, behind a system-scope fence)
+  if (evaluations_completed) *evaluations_completed = done;
+  if (withheld) *withheld = h[1];
+  return AGBNP_HIP_OK;
+}
+
 // ---- diagnostic entry points (not part of include/agbnp_hip.h; used by scripts/ only) ---------------------------------
 // the forest packing as the device holds it, in WORK-SLOT order: the items of slot s at forest_start[s] .. forest_start[s+1]),
 // and the per-subtree shapes
@@ -1189,6 +1209,7 @@ void agbnp_hip_destroy(agbnp_hip_context* c) {
     (void)hipStreamDestroy(c->stream);
   }
   for (hipEvent_t e : c->timeline.events) (void)hipEventDestroy(e);
+  if (c->h_status) (void)hipHostFree(c->h_status);
   delete c;
 }
 

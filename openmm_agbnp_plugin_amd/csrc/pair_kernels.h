@@ -86,6 +86,8 @@ struct PairArgs {
   int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 1000: every resident slot)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
   int* status;
+  volatile int* host_status;  // pinned host memory, mapped: [0] evaluations completed since the last finish, [1] of them withheld --
+                              // what agbnp_hip_poll reads without touching the device (written by the energy role)
   // ---- pair-stage intermediates
   double* born_part;       // [n] sum_j s_j Q (atomic sums of the tiles)
   double *born, *born_fp, *brw, *e_atom;  // [n]

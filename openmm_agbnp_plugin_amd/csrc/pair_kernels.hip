@@ -386,6 +386,11 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyRow] |= rowo;
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
+        if (P.host_status) {  // the host's window on the log (agbnp_hip_poll): the withheld count first, then the running number
+          P.host_status[1] = P.status[kStatBadCount];
+          __threadfence_system();
+          P.host_status[0] = P.status[kStatEvalSeq];
+        }
       }
 }
 

@@ -11,7 +11,9 @@
 // build container, also against the reference's own openmmapi/include headers taken in place.
 #include "HipAGBNPKernels.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "openmm/OpenMMException.h"
 #include "openmm/hip/HipPlatform.h"
@@ -48,7 +50,13 @@ class HipAGBNPKernelFactory : public KernelFactory {
 
 HipCalcAGBNPForceKernel::HipCalcAGBNPForceKernel(std::string name, const Platform& platform, HipContext& cu)
     : CalcAGBNPForceKernel(name, platform), cu(cu), engine(nullptr), checkInterval(1), sinceCheck(0) {
+  if (const char* env = getenv("AGBNP_HIP_CHECK_MODE")) setPollMode(std::string(env) == "poll");
   if (const char* env = getenv("AGBNP_HIP_CHECK_INTERVAL")) setCheckInterval(atoi(env));
+}
+
+void HipCalcAGBNPForceKernel::setPollMode(bool on) {
+  pollMode = on;
+  if (on && checkInterval == 1) checkInterval = 1024;  // the full check only bounds the log in this mode
 }
 
 HipCalcAGBNPForceKernel::~HipCalcAGBNPForceKernel() { agbnp_hip_destroy(engine); }
@@ -68,6 +76,8 @@ void HipCalcAGBNPForceKernel::initialize(const System& system, const AGBNPForce&
   if (agbnp_hip_create(&engine, (int)r.size(), r.data(), g.data(), a.data(), q.data(), h.data(), (int)force.getVersion(),
                        (int)force.getNonbondedMethod(), force.getCutoffDistance(), cu.getDeviceIndex()) != AGBNP_HIP_OK)
     throw OpenMMException(agbnp_hip_last_error(nullptr));
+  strictLeft = 8;
+  sinceCheck = 0;
 }
 
 void HipCalcAGBNPForceKernel::enqueue() {
@@ -85,16 +95,35 @@ double HipCalcAGBNPForceKernel::execute(ContextImpl& context, bool includeForces
   if (!engine) throw OpenMMException("HipCalcAGBNPForceKernel: initialize() has not been called");
   // both are always computed, as in the reference (ReferenceAGBNPKernels.cpp:139-149 ignores the two flags)
   enqueue();
-  if (++sinceCheck >= checkInterval) {
+  ++sinceCheck;
+  bool check = sinceCheck >= checkInterval;
+  if (pollMode && strictLeft > 0) {
+    strictLeft--;
+    check = true;
+  }
+  if (!check && pollMode) {  // a look at the pinned status words: no device call, nothing is waited for
+    int done = 0, bad = 0;
+    check = agbnp_hip_poll(engine, &done, &bad) != AGBNP_HIP_OK || bad > 0;
+  }
+  if (check) {
+    const bool only_this_one = sinceCheck == 1;
     sinceCheck = 0;
     for (int attempt = 0;; attempt++) {
       int withheld = 0;
       if (agbnp_hip_finish(engine, cu.getCurrentStream(), &withheld) != AGBNP_HIP_OK) throw OpenMMException(agbnp_hip_last_error(engine));
       if (withheld == 0) break;
+      strictLeft = 8;
       // a withheld evaluation added nothing to the context's buffers.  With a check after every evaluation it is this
       // one: run it again on the capacity the engine has just switched to (forces invalidated and recomputed in the
       // reference's words, OpenCLAGBNPKernels.cpp:3613-3634).
-      if (checkInterval != 1)
+      if (pollMode && !only_this_one) {  // found late: the engine has adapted; the steps in question ran without the AGBNP term
+        if (lateWithheld == 0)
+          fprintf(stderr, "AGBNPForce (HIP): %d evaluation(s) outgrew the overlap-tree capacity and were withheld before the poll saw it; "
+                          "capacity raised, run continues (AGBNP_HIP_CHECK_MODE unset = strict per-step check)\n", withheld);
+        lateWithheld += withheld;
+        break;
+      }
+      if (!only_this_one)
         throw OpenMMException("AGBNPForce (HIP): an overlap tree outgrew its capacity in an earlier step of this check interval; "
                               "its forces were not applied.  Restart from the last checkpoint (the capacity has been raised) "
                               "or run with AGBNP_HIP_CHECK_INTERVAL=1");

@@ -26,6 +26,16 @@ class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
   // no host synchronisation in between; a withheld evaluation found then cannot be repeated in place (the integrator has
   // moved on), so execute() throws.  Environment variable AGBNP_HIP_CHECK_INTERVAL overrides the default.
   void setCheckInterval(int evaluations);
+  // Poll mode (AGBNP_HIP_CHECK_MODE=poll): execute() never synchronises in the steady state.  After every enqueue it looks
+  // at the engine's pinned status words (agbnp_hip_poll: no device call) and only calls the blocking agbnp_hip_finish()
+  // when they report a withheld evaluation (or every 1024 evaluations, to keep the log bounded).  What the poll sees is at
+  // least one evaluation old, so a withheld evaluation is found AFTER the integrator has used the step's forces without
+  // the AGBNP term: the engine adapts at once (capacity / packing), the step is counted in getLateWithheld() and reported
+  // on stderr once.  The first eight evaluations of a context, and the eight after every adaptation, are checked the
+  // strict way (the capacity negotiation of a new system happens there).  The default stays the strict protocol above
+  // (exact, one synchronisation per step).
+  void setPollMode(bool on);
+  int getLateWithheld() const { return lateWithheld; }
   agbnp_hip_context* getEngine() { return engine; }
 
  private:
@@ -33,6 +43,9 @@ class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
   OpenMM::HipContext& cu;
   agbnp_hip_context* engine;
   int checkInterval, sinceCheck;
+  bool pollMode = false;
+  int lateWithheld = 0;
+  int strictLeft = 0;  // poll mode: evaluations that are still checked the strict way (a fresh context, or one that has just adapted)
 };
 
 }  // namespace AGBNPPlugin

@@ -988,3 +988,26 @@ def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
         k.execute(s.jittered(6 + step), f)
     assert k.scalar("pack_level") == 0
     assert int(k.scalar("forests")) <= packed + 8  # back at the original packing density
+
+
+def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
+    """agbnp_hip_poll reads pinned host memory that the device writes at the end of every evaluation: evaluations completed
+    since the last finish() and how many of them were withheld -- the same numbers finish() then returns."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack([s.pos, centre + 0.85 * (s.pos - centre)]), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert k.poll() == (0, 0)
+    for i in (0, 0, 1, 0):  # the third one outgrows the smallest capacity variant
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    torch.cuda.synchronize()  # (the test's own: poll itself never waits)
+    assert k.poll() == (4, 1)
+    assert k.finish(stream) == 1 and k.withheld() == [2]
+    assert k.poll() == (0, 0)
