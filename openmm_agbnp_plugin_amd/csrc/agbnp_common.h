@@ -82,6 +82,7 @@ enum StatusWord {
 enum KernelId {
   kKPrep = 0, kKTreeCavity, kKBornTiles, kKGbTiles, kKDbornTiles, kKTreePseudo, kKOutputs,
   kKBornRows, kKDbornRows,  // row form of the two range-limited stages (take the place of the two tile kernels)
+  kKGbRows,                 // row form of the GB stage (fast mode only)
   kKernelCount
 };
 

@@ -104,8 +104,13 @@ struct agbnp_hip_context {
   DevBuf<double> d_ys;
   DevBuf<int> d_a2s;
   // row form of the range-limited stages (pair_kernels.hip, k_rows)
-  DevBuf<unsigned> d_hperm, d_aperm, d_nlh, d_nla, d_bslice, d_cslice;
-  DevBuf<int> d_nlh_count, d_nla_count, d_nl_flag;
+  DevBuf<unsigned> d_hperm, d_aperm, d_nlh, d_nla, d_nlg, d_bslice, d_cslice;
+  DevBuf<int> d_nlh_count, d_nla_count, d_nlg_count, d_nl_flag;
+  DevBuf<double> d_egb_rows;   // per-wave energy partials of the GB rows
+  int rows_policy = -1;        // AGBNP_HIP_ROWS: 1 on wherever it can run, 0 off, unset (-1): on in fast mode (where only the pairs
+                               // inside the cutoff are met and the row form is several times faster), off in the reference mode
+                               // (where it is exact but, on 1dwc, not yet faster than the tiles)
+  int nlg_stride = 0;
   DevBuf<double> d_nl_ref, d_bw;
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
@@ -325,9 +330,22 @@ void wire_args(agbnp_hip_context* c) {
   {
     // Row form (reference mode only: the fast mode cuts every stage at the cutoff and the deterministic mode fixes the
     // order of its sums through the tiles' quantized totals)
-    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.fast && !P.det ? 1 : 0;
-    const double reach = kI4MaxA + c->skin;
+    const bool wanted = c->rows_policy == 1 || (c->rows_policy == -1 && P.fast);
+    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.det && !P.single && wanted ? 1 : 0;
+    P.gb_rows = P.rows_on && P.fast && c->d_nlg.p != nullptr && getenv("AGBNP_HIP_NO_GB_ROWS") == nullptr ? 1 : 0;
+    const double reach = sqrt(P.range2) + c->skin, gb_reach = c->cutoff + c->skin;  // (fast mode: the range-limited stages stop at the cutoff too)
     P.nl_build2 = reach * reach;
+    P.nlg_build2 = gb_reach * gb_reach;
+    P.nlg = c->d_nlg.p;
+    P.nlg_count = c->d_nlg_count.p;
+    P.nlg_stride = c->nlg_stride;
+    if (P.gb_rows) {  // the GB rows leave one energy partial per wave
+      P.egb_part = c->d_egb_rows.p;
+      P.egb_parts = (int)c->d_egb_rows.count;
+    } else {
+      P.egb_part = c->d_egb_part.p;
+      P.egb_parts = (int)c->d_egb_part.count;
+    }
     P.nl_move2 = 0.25 * c->skin * c->skin;
     P.nl_flag = c->d_nl_flag.p;
     P.nl_ref = c->d_nl_ref.p;
@@ -430,7 +448,8 @@ int allocate_rows(agbnp_hip_context* c) {
   // (round 3, work in progress: the row form is exact and tested but not yet faster than the tiles on 1dwc -- every
   // workgroup pays for its own copy of the table -- so it is opt-in until its persistent form is in)
   const char* want = getenv("AGBNP_HIP_ROWS");
-  if (c->version != 1 || nh == 0 || n > kMaxParticles || want == nullptr || atoi(want) == 0) return AGBNP_HIP_OK;
+  c->rows_policy = want == nullptr ? -1 : (atoi(want) != 0 ? 1 : 0);
+  if (c->version != 1 || nh == 0 || n > kMaxParticles || c->rows_policy == 0) return AGBNP_HIP_OK;
   if (c->lut.nscreened > kMaxTypes || c->lut.nscreener > kMaxTypes) return AGBNP_HIP_OK;
   if ((size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1) * 2 * sizeof(double2) > kMaxTableBytes) return AGBNP_HIP_OK;
   if (getenv("AGBNP_HIP_SKIN")) c->skin = std::min(1.0, std::max(0.0, atof(getenv("AGBNP_HIP_SKIN"))));
@@ -450,7 +469,19 @@ int allocate_rows(agbnp_hip_context* c) {
   static_assert(kRowCap % 256 == 0, "a list is walked in slices of 256 entries");
   c->nlh_stride = part_stride(hperm.size(), kBornParts);
   c->nla_stride = part_stride(aperm.size(), kChainParts);
-  if (getenv("AGBNP_HIP_ROW_STRIDE")) c->nlh_stride = c->nla_stride = std::max(128, atoi(getenv("AGBNP_HIP_ROW_STRIDE")));  // (tests: force an overflow)
+  // GB rows (fast mode; the cutoff is the force's and fixed for the life of the context): a list holds the atoms within
+  // cutoff + skin of a group of four bonded atoms -- at most what twice the density of a protein interior (~105 atoms per
+  // nm^3) puts into that sphere, whatever the size of the system
+  {
+    const double r = c->cutoff + c->skin + 0.3;
+    const double most = 2.0 * 105.0 * (4.0 / 3.0) * M_PI * r * r * r / kGbParts;
+    c->nlg_stride = c->method != 0 && c->cutoff > 0.0 && c->cutoff < 3.0
+                        ? std::max(256, std::min(part_stride(aperm.size(), kGbParts), (int)((most + 255) / 256) * 256)) : 0;
+  }
+  if (getenv("AGBNP_HIP_ROW_STRIDE")) {  // (tests: force an overflow)
+    c->nlh_stride = c->nla_stride = std::max(128, atoi(getenv("AGBNP_HIP_ROW_STRIDE")));
+    if (c->nlg_stride) c->nlg_stride = c->nlh_stride;
+  }
   const size_t born_lists = (size_t)((n + kRowGroup - 1) / kRowGroup) * kBornParts, chain_lists = (size_t)((nh + kRowGroup - 1) / kRowGroup) * kChainParts;
   HIP_TRY(c, c->d_nlh.alloc(born_lists * c->nlh_stride));
   HIP_TRY(c, c->d_nla.alloc(chain_lists * c->nla_stride));
@@ -462,6 +493,16 @@ int allocate_rows(agbnp_hip_context* c) {
     for (int h = 0; h < nh; h++) cs[h / kRowGroup] |= (unsigned)c->lut.type_screener[c->h2a[h]] << (8 * (h % kRowGroup));
     HIP_TRY(c, c->d_bslice.upload(bs));
     HIP_TRY(c, c->d_cslice.upload(cs));
+  }
+  if (c->nlg_stride > 0) {
+    const size_t gb_lists = (size_t)((n + kRowGroup - 1) / kRowGroup) * kGbParts;
+    HIP_TRY(c, c->d_nlg.alloc(gb_lists * c->nlg_stride));
+    HIP_TRY(c, hipMemset(c->d_nlg.p, 0, sizeof(unsigned) * gb_lists * c->nlg_stride));
+    HIP_TRY(c, c->d_nlg_count.alloc(gb_lists));
+    HIP_TRY(c, hipMemset(c->d_nlg_count.p, 0, sizeof(int) * gb_lists));
+    const size_t waves = (gb_lists + 7) / 8 * 8 * (size_t)((c->nlg_stride + 255) / 256);  // one energy partial per wave of the GB rows
+    HIP_TRY(c, c->d_egb_rows.alloc(waves));
+    HIP_TRY(c, hipMemset(c->d_egb_rows.p, 0, sizeof(double) * waves));
   }
   HIP_TRY(c, c->d_nlh_count.alloc(born_lists));
   HIP_TRY(c, c->d_nla_count.alloc(chain_lists));
@@ -1077,6 +1118,10 @@ int agbnp_hip_set_mode(agbnp_hip_context* c, int mode) {
   if (mode != c->mode) c->generation++;  // other kernel arguments: a captured graph is stale
   c->mode = mode;
   wire_args(c);
+  if (c->rows_capable) {  // the neighbour lists were built for the reach of the mode that is being left
+    const int stale = 1;
+    HIP_TRY(c, hipMemcpy(c->d_nl_flag.p, &stale, sizeof(int), hipMemcpyHostToDevice));
+  }
   return AGBNP_HIP_OK;
 }
 
@@ -1104,7 +1149,7 @@ int agbnp_hip_num_kernels(void) { return kKernelCount; }
 
 const char* agbnp_hip_kernel_name(int index) {
   static const char* names[kKernelCount] = {"k_prep",        "k_tree_cavity", "k_born_tiles", "k_gb_tiles", "k_dborn_tiles",
-                                            "k_tree_pseudo", "k_outputs",     "k_born_rows",  "k_dborn_rows"};
+                                            "k_tree_pseudo", "k_outputs",     "k_born_rows",  "k_dborn_rows",  "k_gb_rows"};
   return (index >= 0 && index < kKernelCount) ? names[index] : "";
 }
 
@@ -1195,6 +1240,16 @@ int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, 
     HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
   }
   c->P.pack_enabled = freeze ? 3 : c->P.pack_enabled;  // 3: the bookkeeping keeps its statistics but writes no packing
+  return AGBNP_HIP_OK;
+}
+
+// row form: bw_i = brw_i + bru_i as the GB stage left it [n], W+U by heavy index [nh] (what the chain-rule stage left)
+int agbnp_debug_get_rows(agbnp_hip_context* c, double* bw, double* wu) {
+  if (!c || !c->rows_capable) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(bw, c->d_bw.p, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(wu, c->d_dbf.p + 3 * (size_t)c->n, sizeof(double) * c->nh, hipMemcpyDeviceToHost));
   return AGBNP_HIP_OK;
 }
 

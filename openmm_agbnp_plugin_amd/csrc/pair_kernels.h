@@ -118,6 +118,11 @@ struct PairArgs {
   unsigned* nla;           // [groups of 4 heavy atoms x kChainParts][nla_stride] neighbours of any kind, entries as in aperm
   int* nla_count;          // [groups x kChainParts]
   int nla_stride;
+  int gb_rows;             // 1: the GB stage runs in row form too (fast mode: only pairs inside the cutoff are met)
+  unsigned* nlg;           // [groups of 4 atoms x kGbParts][nlg_stride] neighbours of any kind within the GB cutoff + skin
+  int* nlg_count;          // [groups x kGbParts]
+  int nlg_stride;
+  double nlg_build2;       // squared radius of those lists
   double4* rec_h;          // [nh] {x, y, z, 1 / V_vdw} by heavy index (k_prep): what a Born row gathers of a neighbour (+ its self volume)
   double4* hrow;           // [nh] {x, y, z, atom | screener type << 24} by heavy index (k_prep): a chain-rule row's own record
   double* bw;              // [n] brw + bru by atom: the GB stage adds alpha_i (diagonal tile) + beta_i * (Y of the tile) with atomics
@@ -130,6 +135,7 @@ struct PairArgs {
 constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
 constexpr int kChainParts = 4;  // waves (list parts) per group of chain-rule rows
 constexpr int kBornParts = 2;   // ... per group of Born rows
+constexpr int kGbParts = 2;     // ... per group of GB rows (fast mode)
 
 // Optional per-kernel timing: an event is recorded on the evaluation's stream in front of every kernel
 // (and one after the last); durations are read back after the stream has been synchronised.

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   // agbnp_hip_finish) are left alone, and the evaluation takes its running number
   if (i < kStatEvalWords && blockIdx.x == 0) P.status[i] = 0;
   if (i == 0) P.status[kStatEvalSeq] += 1;
-  if (i < P.nslots) {
+  if (i < P.nslots && !P.rows_on) {  // (the row form needs none of the tiles' records)
     // bounding box of every block of 64 slots in pair order (one wave each) for the tile culling of the
     // chain-rule stage; padding slots are neutral
     const int a = P.pslot[i];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
       }
     }
   }
-  if (P.fast && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage
+  if (P.fast && !P.gb_rows && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage
     double lo[3], hi[3];
     for (int d = 0; d < 3; d++) {
       lo[d] = i < P.n ? P.pos[3 * i + d] : 1e30;
@@ -798,7 +798,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   // (unconditional loads: a choice here would have to wait for them)
   const int ysa = P.a2s[min(64 * I0 + lane, n - 1)], ysc = P.a2s[min(64 * I0 + 64 + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];
   double beta_a = 0.0, beta_c = 0.0, beta_j = 0.0;  // row form of the chain rule: wave 3 (idle here) turns its Y totals into bw shares
-  if (!kCut && P.rows_on && wave == 3) {
+  if (P.rows_on && wave == 3) {
     const int ka = min(64 * I0 + lane, n - 1), kc = min(64 * I0 + 64 + lane, n - 1), kj = min(64 * J + lane, n - 1);
     const double ra = inv_rvdw[ka], rc = inv_rvdw[kc], rj = inv_rvdw[kj], pa = born_part[ka], pc = born_part[kc], pj = born_part[kj];
     beta_a = bw_beta(born_radius(ra, pa));
@@ -900,7 +900,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
   const bool det = P.det != 0;  // deterministic mode: a tile's totals are rounded to the sums' quantum (device_math.h)
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (!kCut && P.rows_on && wave == 3) {  // (the row form never runs in the deterministic mode)
+  if (P.rows_on && wave == 3) {  // (the row form never runs in the deterministic mode)
     if (ia < n) hbm_add(&P.bw[ia], beta_a * fold(3));
     if (ic < n) hbm_add(&P.bw[ic], beta_c * fold(7));
     if (j < n) hbm_add(&P.bw[j], beta_j * fold(11));
@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   PAIR_STAMP_WHERE(1, item);
   const int ysi = P.a2s[min(64 * I + lane, n - 1)], ysj = P.a2s[min(64 * J + lane, n - 1)];  // (the Y sums leave by pair-order slot, see gb_strip)
   double beta_i = 0.0, beta_j = 0.0;  // row form of the chain rule: see gb_strip
-  if (!kCut && P.rows_on && wave == 3) {
+  if (P.rows_on && wave == 3) {
     const int ki = min(64 * I + lane, n - 1), kj = min(64 * J + lane, n - 1);
     const double ri = inv_rvdw[ki], rj = inv_rvdw[kj], pi = born_part[ki], pj = born_part[kj];
     beta_i = bw_beta(born_radius(ri, pi));
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
         e_atom[a] = al / bh3 + kDielFactor * pa.w * pa.w * bra.inv_br;
         brw[a] = brw_a;
         P.srec[ysi] = make_double4(bra.br, bra.fp, brw_a, pa.w);  // the chain-rule stage's copy, by slot (a = 64 I + lane here)
-        if (!kCut && P.rows_on) hbm_add(&P.bw[a], bw_alpha(bra, brw_a, pa.w));
+        if (P.rows_on) hbm_add(&P.bw[a], bw_alpha(bra, brw_a, pa.w));
       }
     }
   }
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   const int i = 64 * I + lane, j = 64 * J + lane;
   const bool det = P.det != 0;
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (!kCut && P.rows_on && wave == 3) {
+  if (P.rows_on && wave == 3) {
     if (i < n) hbm_add(&P.bw[i], beta_i * tile_sums_fold(s_sums, 3, lane));
     if (j < n) hbm_add(&P.bw[j], beta_j * tile_sums_fold(s_sums, 7, lane));
   } else {
@@ -1538,25 +1538,29 @@ __device__ __forceinline__ double lane_xor2(double v) { return dpp_move<0x4E>(v)
 __device__ __forceinline__ double lane_xor4(double v) { return dpp_move<0x1B>(dpp_move<0x141>(v)); }  // row_half_mirror, then quad_perm [3, 2, 1, 0]
 __device__ __forceinline__ double lane_xor8(double v) { return dpp_move<0x128>(v); }                  // row_ror:8
 
+enum RowKind { kBornRows = 0, kChainRows = 1, kGbRows = 2 };
+// Which atoms own rows, which are candidates:   Born rows: every atom <- heavy atoms;  chain-rule rows: heavy atoms <- every
+// atom;  GB rows (fast mode only: the reference's GB meets ALL pairs and stays on the tiles): every atom <- every atom
+// within the cutoff.
 struct RowAtoms {  // wave-uniform (scalar registers): the row atoms of a group
   double x[kRowGroup], y[kRowGroup], z[kRowGroup];
   int self[kRowGroup];   // index of the row atom in the candidates' numbering (never met: -1 for a row that is no candidate)
   int rows;              // valid rows (the last group may be short)
 };
 
-template <bool kChain>
+template <int KIND>
 __device__ __forceinline__ RowAtoms row_atoms(const PairArgs& P, int group) {
   RowAtoms A;
-  const int nrows = kChain ? P.nh : P.n;
+  const int nrows = KIND == kChainRows ? P.nh : P.n;
   A.rows = min(kRowGroup, nrows - kRowGroup * group);
-  const double4* __restrict__ pos = kChain ? static_cast<const double4*>(P.hrow) : static_cast<const double4*>(P.aposq);
+  const double4* __restrict__ pos = KIND == kChainRows ? static_cast<const double4*>(P.hrow) : static_cast<const double4*>(P.aposq);
   double4 pr[kRowGroup];
   int self[kRowGroup];
 #pragma unroll
   for (int r = 0; r < kRowGroup; r++) {  // (all in flight together)
     const int row = min(kRowGroup * group + r, nrows - 1);
     pr[r] = pos[row];
-    self[r] = kChain ? 0 : P.a2h[row];  // (-1 for a hydrogen: no candidate has that index)
+    self[r] = KIND == kBornRows ? P.a2h[row] : row;  // (Born rows: -1 for a hydrogen, no candidate has that index)
   }
 #pragma unroll
   for (int r = 0; r < kRowGroup; r++) {
@@ -1564,7 +1568,7 @@ __device__ __forceinline__ RowAtoms row_atoms(const PairArgs& P, int group) {
     A.x[r] = uniform(there ? pr[r].x : 1e30);  // a row that does not exist is out of everybody's reach
     A.y[r] = uniform(pr[r].y);
     A.z[r] = uniform(pr[r].z);
-    A.self[r] = uniform(!there ? -1 : kChain ? (__double2loint(pr[r].w) & 0xffffff) : self[r]);
+    A.self[r] = uniform(!there ? -1 : KIND == kChainRows ? (__double2loint(pr[r].w) & 0xffffff) : self[r]);
   }
   return A;
 }
@@ -1598,83 +1602,134 @@ __device__ __forceinline__ int row_build(const RowAtoms& A, const unsigned* __re
 // empty as a whole, and leaves at once, or not at all).  The sums of a wave leave as one set of FP64 atomics.
 constexpr int kRowSlice = 256, kRowWaves = 8;
 
-template <bool kChain>
-// (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers)
-__global__ __launch_bounds__(64 * kRowWaves, 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
-  constexpr int R = kRowGroup, NP = kChain ? kChainParts : kBornParts;
+struct RowLists {  // the lists of one kind
+  unsigned* list;
+  int* count;
+  int stride, groups, parts;
+};
+template <int KIND>
+__device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
+  RowLists L;
+  L.list = KIND == kBornRows ? P.nlh : KIND == kChainRows ? P.nla : P.nlg;
+  L.count = KIND == kBornRows ? P.nlh_count : KIND == kChainRows ? P.nla_count : P.nlg_count;
+  L.stride = KIND == kBornRows ? P.nlh_stride : KIND == kChainRows ? P.nla_stride : P.nlg_stride;
+  L.groups = ((KIND == kChainRows ? P.nh : P.n) + kRowGroup - 1) / kRowGroup;
+  L.parts = KIND == kBornRows ? kBornParts : KIND == kChainRows ? kChainParts : kGbParts;
+  return L;
+}
+// one wave builds list `sub` of kind KIND (the lists of the later launches are built in the Born launch: both see the same
+// positions, and an overflowing list is known before the energy is added up)
+template <int KIND>
+__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane) {
+  const RowLists L = row_lists<KIND>(P);
+  if (sub >= L.groups * L.parts) return;
+  const int g = sub / L.parts, part = sub - g * L.parts;
+  const RowAtoms A = row_atoms<KIND>(P, g);
+  const int cnt = row_build(A, P.aperm, P.aperm_n, part, L.parts, static_cast<const double4*>(P.aposq), KIND == kGbRows ? P.nlg_build2 : P.nl_build2,
+                            L.list + (size_t)sub * L.stride, L.stride, lane);
+  if (lane == 0) {
+    L.count[sub] = min(cnt, L.stride);
+    if (cnt > L.stride) P.status[kStatRowOverflow] = 1;
+  }
+}
+
+// (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers; the GB rows, whose pair terms and
+// bookkeeping role need more, four)
+template <int KIND>
+__global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
+  constexpr int R = kRowGroup;
   static_assert(R == 4, "the butterfly below folds 16 sums");
   extern __shared__ double2 s_dyn[];
   __shared__ int s_busy;
   int blk = blockIdx.x;
-  if (kChain) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
+  if (KIND == kChainRows) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
     if (blk < 2 && threadIdx.x >= 256) return;
     if (blk == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
     if (blk == 1) return dealing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
     blk -= 2;
   }
+  if (KIND == kGbRows) {  // the GB launch carries the first half of the bookkeeping (see k_gb_tiles)
+    if (blk == 0) {
+      if (threadIdx.x >= 256) return;
+      PAIR_STAMP(1, 0);
+      packing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
+      PAIR_STAMP(1, 3);
+      return;
+    }
+    blk -= 1;
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int born_groups = (P.n + R - 1) / R, chain_groups = (P.nh + R - 1) / R;
-  const int stride = kChain ? P.nla_stride : P.nlh_stride;
-  const int nlists = (kChain ? chain_groups : born_groups) * NP, lists_pad = (nlists + kRowWaves - 1) & ~(kRowWaves - 1);
+  const RowLists L = row_lists<KIND>(P);
+  const int NP = L.parts, stride = L.stride;
+  const int nlists = L.groups * NP, lists_pad = (nlists + kRowWaves - 1) & ~(kRowWaves - 1);
   const int slices = (stride + kRowSlice - 1) / kRowSlice;
   const int walk_blocks = lists_pad / kRowWaves * slices;
   const int stale = P.nl_flag[0];
-  if (!kChain && blk >= walk_blocks) {
-    // The chain-rule lists are built here, in the Born launch, by workgroups that exit at once in an evaluation whose
-    // lists are still good.
+  if (KIND == kBornRows && blk >= walk_blocks) {
+    // The lists of the later launches are built here, in the Born launch, by workgroups that exit at once in an
+    // evaluation whose lists are still good.
     if (!stale) return;
     const int sub = (blk - walk_blocks) * kRowWaves + wave;
-    if (sub >= chain_groups * kChainParts) return;
-    const int g = sub / kChainParts, part = sub - g * kChainParts;
-    const RowAtoms A = row_atoms<true>(P, g);
-    const int cnt = row_build(A, P.aperm, P.aperm_n, part, kChainParts, static_cast<const double4*>(P.aposq), P.nl_build2,
-                              P.nla + (size_t)sub * P.nla_stride, P.nla_stride, lane);
-    if (lane == 0) {
-      P.nla_count[sub] = min(cnt, P.nla_stride);
-      if (cnt > P.nla_stride) P.status[kStatRowOverflow] = 1;
-    }
+    const int chain_lists = row_lists<kChainRows>(P).groups * kChainParts;
+    if (sub < chain_lists)
+      build_list<kChainRows>(P, sub, lane);
+    else if (P.gb_rows)
+      build_list<kGbRows>(P, sub - chain_lists, lane);
     return;
   }
-  PAIR_STAMP((kChain ? 2 : 0), 0);
+  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 0);
   const int item = blk * kRowWaves + wave;
   const int slice = item / lists_pad, li = item - slice * lists_pad;  // (a workgroup's eight items share the slice)
   const bool active = li < nlists;
   const int sub = active ? li : 0;  // (group, part)
   const int group = sub / NP, part = sub - group * NP;
-  const unsigned* list = (kChain ? P.nla : P.nlh) + (size_t)sub * stride;  // (not restrict: a build rewrites it)
+  const unsigned* list = L.list + (size_t)sub * stride;  // (not restrict: a build rewrites it)
   const int first = kRowSlice * slice;
   // Everything that does not depend on anything is asked for at once: the length of the list, the first two steps of the
   // slice (the lists start out zeroed: an entry beyond the length is a valid index), the row atoms and their types, the table.
-  const int listed = (kChain ? P.nla_count : P.nlh_count)[sub];
+  const int listed = L.count[sub];
   unsigned e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
-  const unsigned types = (kChain ? P.cslice : P.bslice)[group];  // one byte per row
-  const RowAtoms A = row_atoms<kChain>(P, group);
-  const int ne = (kChain ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice of the table (one row type)
-  const int tab = P.nti * P.ntj * kRowIntervals;            // ... of the table: {c0, c1} of every entry, then {c2, c3}
+  const unsigned types = KIND == kGbRows ? 0u : (KIND == kChainRows ? P.cslice : P.bslice)[group];  // one byte per row
+  const RowAtoms A = row_atoms<KIND>(P, group);
+  double row_rv[R], row_bp[R], row_q[R];  // GB rows: 1/R_vdw, descreening sum and charge of the row atoms
+  if (KIND == kGbRows) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int a = min(R * group + r, P.n - 1);
+      row_rv[r] = P.inv_rvdw[a], row_bp[r] = P.born_part[a], row_q[r] = static_cast<const double4*>(P.aposq)[a].w;
+    }
+  }
+  const int ne = (KIND == kChainRows ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice of the table (one row type)
+  const int tab = P.nti * P.ntj * kRowIntervals;                        // ... of the table: {c0, c1} of every entry, then {c2, c3}
   double2* const s_tab = s_dyn;
   constexpr int kWg = 64 * kRowWaves;
-  const double2* __restrict__ gtab = kChain ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
+  const double2* __restrict__ gtab = KIND == kChainRows ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
   const int tx = threadIdx.x;
   // a workgroup whose eight slices are all beyond the ends of their lists has nothing to do (not known while the lists
   // are being rebuilt); it leaves before it asks for the table: nearly half of the workgroups of a launch are such
   if (threadIdx.x == 0) s_busy = 0;
   __syncthreads();
-  const bool mine = active && (stale || first < listed);
+  // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
+  const bool mine = active && ((KIND == kBornRows && stale) || first < listed || (KIND == kGbRows && slice == 0 && part == 0));
   if (mine && lane == 0) s_busy = 1;
+  if (KIND == kGbRows && lane == 0 && !mine && item < P.egb_parts) P.egb_part[item] = 0.0;  // (every partial is summed up)
   __syncthreads();
   if (!s_busy) return;
-  const double2 tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
-  PAIR_STAMP_WAIT((kChain ? 2 : 0), 7, "vmcnt(0) lgkmcnt(0)");
-  if (tx < 2 * tab) s_tab[tx] = tv0;
-  if (kWg + tx < 2 * tab) s_tab[kWg + tx] = tv1;
-  if (2 * kWg + tx < 2 * tab) s_tab[2 * kWg + tx] = tv2;
-  for (int base = 3 * kWg; base < 2 * tab; base += kWg)  // (larger tables)
-    if (base + tx < 2 * tab) s_tab[base + tx] = gtab[base + tx];
+  double2 tv0, tv1, tv2;
+  if (KIND != kGbRows) tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
+  PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 7, "vmcnt(0) lgkmcnt(0)");
+  if (KIND != kGbRows) {
+    if (tx < 2 * tab) s_tab[tx] = tv0;
+    if (kWg + tx < 2 * tab) s_tab[kWg + tx] = tv1;
+    if (2 * kWg + tx < 2 * tab) s_tab[2 * kWg + tx] = tv2;
+    for (int base = 3 * kWg; base < 2 * tab; base += kWg)  // (larger tables)
+      if (base + tx < 2 * tab) s_tab[base + tx] = gtab[base + tx];
+  }
   int slice_at[R];  // first entry of the row's slice of the table
 #pragma unroll
   for (int r = 0; r < R; r++) slice_at[r] = uniform((int)((types >> (8 * r)) & 0xffu) * ne);
   int count = listed;
-  if (!kChain && stale && active) {
+  if (KIND == kBornRows && stale && active) {
     // every slice of a list rebuilds the list for itself (the same entries at the same places: the copies agree), so that
     // no wave waits for another workgroup's
     count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
@@ -1692,57 +1747,133 @@ __global__ __launch_bounds__(64 * kRowWaves, 6) void k_rows(PairArgs P, double* 
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
   const int todo = active ? max(0, min(count - first, kRowSlice)) : 0;  // entries of this slice
-  const double4* __restrict__ rec = kChain ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
-  const double* __restrict__ wsrc = kChain ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
   const int nsteps = (todo + 63) >> 6;
-  // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
-  // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
-  double4 r1 = rec[e1 & 0xffffffu];
-  double w1 = wsrc[e1 & 0xffffffu];
-  __syncthreads();  // the table is in LDS
-  PAIR_STAMP((kChain ? 2 : 0), 8);
   double acc[4 * R];
 #pragma unroll
   for (int q = 0; q < 4 * R; q++) acc[q] = 0.0;
-  PAIR_STAMP_WAIT((kChain ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
-#ifdef AGBNP_PAIR_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(kChain ? 2 : 0)][blockIdx.x][6] = (unsigned)todo, g_pair_log[(kChain ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
-#endif
   constexpr double kPerNode = (kI4Nodes - 1) / kI4MaxA;
-  for (int k = 0; k < nsteps; k++) {
-    const unsigned e = e1;
-    const double4 rb = r1;
-    const double wb = w1;
-    e1 = e2;
-    r1 = rec[e1 & 0xffffffu];
-    w1 = wsrc[e1 & 0xffffffu];
-    e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
-    const int b = (int)(e & 0xffffffu);
-    const int tent = (int)(e >> 24) * kRowIntervals;
-    const double w = (kChain ? wb : wb * rb.w) * kPerNode;  // bw_b, or s_b = selfvol_b / V_b (times the table's d(t)/d(d))
-    const double range2 = 64 * k + lane < todo ? P.range2 : -1.0;  // (a lane beyond the slice meets nobody)
+  double esum = 0.0;    // GB rows: sum of q_a q_b f over the wave's pairs
+  double beta_r[R];     // GB rows: beta of the row atoms (see bw_beta)
+  if (KIND != kGbRows) {
+    const double4* __restrict__ rec = KIND == kChainRows ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
+    const double* __restrict__ wsrc = KIND == kChainRows ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
+    // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
+    // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
+    double4 r1 = rec[e1 & 0xffffffu];
+    double w1 = wsrc[e1 & 0xffffffu];
+    __syncthreads();  // the table is in LDS
+    PAIR_STAMP((KIND == kChainRows ? 2 : 0), 8);
+    PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
+#ifdef AGBNP_PAIR_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(KIND == kChainRows ? 2 : 0)][blockIdx.x][6] = (unsigned)todo, g_pair_log[(KIND == kChainRows ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
+#endif
+    for (int k = 0; k < nsteps; k++) {
+      const unsigned e = e1;
+      const double4 rb = r1;
+      const double wb = w1;
+      e1 = e2;
+      r1 = rec[e1 & 0xffffffu];
+      w1 = wsrc[e1 & 0xffffffu];
+      e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
+      const int b = (int)(e & 0xffffffu);
+      const int tent = (int)(e >> 24) * kRowIntervals;
+      const double w = (KIND == kChainRows ? wb : wb * rb.w) * kPerNode;  // bw_b, or s_b = selfvol_b / V_b (times the table's d(t)/d(d))
+      const double range2 = 64 * k + lane < todo ? P.range2 : -1.0;  // (a lane beyond the slice meets nobody)
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
-      const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-      if (d2 < range2 && b != A.self[r]) {
-        const double rinv = rsqrt_pos(d2);
-        const double u = (d2 * rinv) * kPerNode;
-        const int ent = slice_at[r] + tent + (int)u;
-        const double t = __builtin_amdgcn_fract(u);
-        const double2 ca = s_tab[ent], cb = s_tab[ent + tab];
-        // value and derivative of c0 + c1 t + c2 t^2 + c3 t^3 in five operations
-        const double b2 = fma(cb.y, t, cb.x), b1 = fma(b2, t, ca.y);
-        const double val = fma(b1, t, ca.x), der = fma(fma(cb.y, t, b2), t, b1);
-        acc[4 * r] = fma(w, val, acc[4 * r]);
-        const double g = w * der * rinv;
-        acc[4 * r + 1] = fma(dx, g, acc[4 * r + 1]);
-        acc[4 * r + 2] = fma(dy, g, acc[4 * r + 2]);
-        acc[4 * r + 3] = fma(dz, g, acc[4 * r + 3]);
+      for (int r = 0; r < R; r++) {
+        const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
+        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (d2 < range2 && b != A.self[r]) {
+          const double rinv = rsqrt_pos(d2);
+          const double u = (d2 * rinv) * kPerNode;
+          const int ent = slice_at[r] + tent + (int)u;
+          const double t = __builtin_amdgcn_fract(u);
+          const double2 ca = s_tab[ent], cb = s_tab[ent + tab];
+          // value and derivative of c0 + c1 t + c2 t^2 + c3 t^3 in five operations
+          const double b2 = fma(cb.y, t, cb.x), b1 = fma(b2, t, ca.y);
+          const double val = fma(b1, t, ca.x), der = fma(fma(cb.y, t, b2), t, b1);
+          acc[4 * r] = fma(w, val, acc[4 * r]);
+          const double g = w * der * rinv;
+          acc[4 * r + 1] = fma(dx, g, acc[4 * r + 1]);
+          acc[4 * r + 2] = fma(dy, g, acc[4 * r + 2]);
+          acc[4 * r + 3] = fma(dz, g, acc[4 * r + 3]);
+        }
       }
     }
+  } else {
+    // GB rows (fast mode): pair terms as in k_gb_tiles, every ordered pair from its row's side -- F_a = -2k sum_b D q_a q_b
+    // (1 - et/4) f^3, Y_a = sum_b q_a q_b (B_a B_b + d^2/4) et f^3, and the pair energy 2k sum_{a<b} = k sum_a sum_{b != a}.
+    // A neighbour's Born radius is formed from its finished descreening sum on the fly (one per lane and step).
+    const double4* __restrict__ rec = static_cast<const double4*>(P.aposq);
+    double qa[R], ba[R], ca_[R];  // charge, B, -log2(e) / (4 B) of the row atoms
+    BornRadius bra[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      bra[r] = born_radius(row_rv[r], row_bp[r]);
+      qa[r] = uniform(r < A.rows ? row_q[r] : 0.0);
+      ba[r] = uniform(bra[r].br);
+      ca_[r] = uniform((-0.25 * 1.4426950408889634074) * bra[r].inv_br);
+      beta_r[r] = bw_beta(bra[r]);
+    }
+    if (active && slice == 0 && part == 0 && lane < A.rows) {
+      // the first slice of a group's first list publishes the per-atom results once (as the diagonal tile does in
+      // k_gb_tiles): B_i, f'_i, vdW energy + GB self energy, brw_i, and alpha_i of bw_i (ReferenceAGBNPKernels.cpp:477,513-533)
+      const int a = R * group + lane;
+      BornRadius br = bra[0];
+      double qv = row_q[0];
+#pragma unroll
+      for (int r = 1; r < R; r++) {
+        if (lane == r) br = bra[r], qv = row_q[r];
+      }
+      const double al = P.alpha[a];
+      const double bh = br.br + kHBRadius, bh3 = bh * bh * bh;
+      const double brw_a = -(1. / (4. * kPi)) * 3. * al * br.br * br.br * br.fp / (bh3 * bh);
+      P.born[a] = br.br;
+      P.born_fp[a] = br.fp;
+      P.e_atom[a] = al / bh3 + kDielFactor * qv * qv * br.inv_br;
+      P.brw[a] = brw_a;
+      hbm_add(&P.bw[a], bw_alpha(br, brw_a, qv));
+    }
+    double4 r1 = rec[e1 & 0xffffffu];
+    double p1 = P.born_part[e1 & 0xffffffu], v1 = P.inv_rvdw[e1 & 0xffffffu];
+    PAIR_STAMP(1, 8);
+    PAIR_STAMP_WAIT(1, 1, "vmcnt(0)");  // the first records are here
+#ifdef AGBNP_PAIR_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[1][blockIdx.x][6] = (unsigned)todo, g_pair_log[1][blockIdx.x][9] = (unsigned)nsteps;
+#endif
+    for (int k = 0; k < nsteps; k++) {
+      const unsigned e = e1;
+      const double4 rb = r1;
+      const BornRadius bb_ = born_radius(v1, p1);
+      e1 = e2;
+      r1 = rec[e1 & 0xffffffu];
+      p1 = P.born_part[e1 & 0xffffffu], v1 = P.inv_rvdw[e1 & 0xffffffu];
+      e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
+      const int b = (int)(e & 0xffffffu);
+      const double cut2 = 64 * k + lane < todo ? P.gb_cut2 : -1.0;  // (a lane beyond the slice meets nobody)
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
+        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+        if (d2 < cut2 && b != A.self[r]) {
+          const double bb = ba[r] * bb_.br;
+          const double et = exp2_nonpositive(d2 * (ca_[r] * bb_.inv_br));  // exp(-d^2 / (4 B_a B_b))
+          const double fgb = rsqrt_pos(fma(bb, et, d2));
+          const double s1 = (qa[r] * rb.w) * fgb;
+          esum += s1;
+          const double s3 = s1 * (fgb * fgb);
+          const double mw = fma(-0.25, et, 1.0) * s3;
+          acc[4 * r] = fma(fma(0.25, d2, bb), et * s3, acc[4 * r]);  // Y
+          acc[4 * r + 1] = fma(dx, mw, acc[4 * r + 1]);
+          acc[4 * r + 2] = fma(dy, mw, acc[4 * r + 2]);
+          acc[4 * r + 3] = fma(dz, mw, acc[4 * r + 3]);
+        }
+      }
+    }
+    esum = wave_sum(esum);
+    if (lane == 0 && item < P.egb_parts) P.egb_part[item] = kDielFactor * esum;
   }
-  PAIR_STAMP((kChain ? 2 : 0), 2);
+  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 2);
   if (nsteps == 0) return;
   // 16 sums per lane -> one per lane: four transposing butterfly stages (a lane keeps the half of the sums that its bit of
   // the stage selects and adds its partner's copy of them; DPP moves), then the four 16-lane rows of the wave are added up
@@ -1760,14 +1891,23 @@ __global__ __launch_bounds__(64 * kRowWaves, 6) void k_rows(PairArgs P, double* 
   const int q = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
   const int r = q >> 2, c = q & 3;
   if (lane < 16 && r < A.rows) {
-    const int row = R * group + r;  // atom (Born rows) or heavy index (chain-rule rows)
-    // (the unit of the value sums goes back in: w carried the table's d(t)/d(d) for the derivatives)
-    if (c == 0)
-      hbm_add(kChain ? &P.db_wu[row] : &P.born_part[row], total * (1.0 / kPerNode));
-    else
-      hbm_add(reinterpret_cast<double*>((kChain ? P.hrec : P.grec) + row) + (c - 1), total);
+    const int row = R * group + r;  // atom (Born and GB rows) or heavy index (chain-rule rows)
+    if (KIND == kGbRows) {
+      double beta = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < R; rr++) beta = rr == r ? beta_r[rr] : beta;
+      if (c == 0)
+        hbm_add(&P.bw[row], beta * total);  // bw_a = alpha_a + beta_a Y_a
+      else
+        hbm_add(P.gb_fx + (size_t)(c - 1) * P.n + row, (-2.0 * kDielFactor) * total);
+    } else if (c == 0) {
+      // (the unit of the value sums goes back in: w carried the table's d(t)/d(d) for the derivatives)
+      hbm_add(KIND == kChainRows ? &P.db_wu[row] : &P.born_part[row], total * (1.0 / kPerNode));
+    } else {
+      hbm_add(reinterpret_cast<double*>((KIND == kChainRows ? P.hrec : P.grec) + row) + (c - 1), total);
+    }
   }
-  PAIR_STAMP((kChain ? 2 : 0), 3);
+  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 3);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1863,23 +2003,30 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dborn_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 3 * 64 * sizeof(double2)));
     if (e != hipSuccess) return e;
   }
-  if (P.rows_on) {  // row form of the two range-limited stages
-    auto gb = k_gb_tiles<false, false>;
+  if (P.rows_on) {  // row form of the two range-limited stages (and, in fast mode, of the GB stage)
+    auto gb = P.fast ? k_gb_tiles<true, false> : k_gb_tiles<false, false>;
     const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
     auto walk_blocks = [](int lists, int stride) { return (lists + kRowWaves - 1) / kRowWaves * ((stride + kRowSlice - 1) / kRowSlice); };
     const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_stride), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_stride);
-    const int build_blocks = (chain_groups * kChainParts + kRowWaves - 1) / kRowWaves;  // the chain-rule lists are built in the Born launch
+    const int gb_blocks = walk_blocks(born_groups * kGbParts, P.nlg_stride);
+    // the lists of the later launches are built in the Born launch
+    const int build_blocks = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kRowWaves - 1) / kRowWaves;
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
     AGBNP_MARK(kKBornRows);
-    hipLaunchKernelGGL(k_rows<false>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
     AGBNP_CHECK_LAUNCH();
-    AGBNP_MARK(kKGbTiles);
-    hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
-                       (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+    if (P.gb_rows) {
+      AGBNP_MARK(kKGbRows);
+      hipLaunchKernelGGL(k_rows<kGbRows>, dim3(1 + gb_blocks), dim3(64 * kRowWaves), sizeof(StripSums), st, P, (double*)nullptr, (double*)nullptr, (int)sizeof(StripSums));
+    } else {
+      AGBNP_MARK(kKGbTiles);
+      hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+                         (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
+    }
     AGBNP_CHECK_LAUNCH();
     AGBNP_MARK(kKDbornRows);
-    hipLaunchKernelGGL(k_rows<true>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    hipLaunchKernelGGL(k_rows<kChainRows>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
     AGBNP_CHECK_LAUNCH();
     return hipSuccess;
   }

@@ -8,8 +8,14 @@ import openmm_agbnp_plugin_amd as P
 from openmm_agbnp_plugin_amd import _lib
 
 name = sys.argv[1] if len(sys.argv) > 1 else "1dwc"
+mode = sys.argv[2] if len(sys.argv) > 2 else "reference"
 s = P.load_system(name)
-ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+os.environ.setdefault("AGBNP_HIP_ROWS", "1")
+force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+force.setCutoffDistance(1.0)
+ctx = P.AGBNPContext(force)
+ctx.kernel.set_mode(mode)
 lib = _lib.load()
 for k in range(6):
     ctx.setPositions(s.jittered(k)); ctx.getState()
@@ -17,8 +23,12 @@ SLOTS = 4096
 buf = (C.c_ulonglong * (3 * SLOTS * 12))()
 lib.agbnp_debug_pair_log(buf)
 log = np.frombuffer(buf, dtype=np.uint64).astype(np.float64).reshape(3, SLOTS, 12)
-for kern, nm in ((0, "k_rows<born>"), (2, "k_rows<chain>")):
+for kern, nm in ((0, "k_rows<born>"), (1, "k_rows<gb>"), (2, "k_rows<chain>")):
     L = log[kern]
+    if kern == 1 and mode != "fast":
+        continue
+    if kern == 1:
+        print(f"   (bookkeeping workgroup of the GB launch: entry {0.0:.2f}, end {(L[0, 3] - L[0, 0]) / 100.0:.2f} us after its entry)")
     ok = (L[:, 0] > 0) & (L[:, 3] >= L[:, 0])
     latest = L[ok, 0].max()
     ok &= L[:, 0] > latest - 20000

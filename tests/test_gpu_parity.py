@@ -1011,3 +1011,24 @@ def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
     assert k.poll() == (4, 1)
     assert k.finish(stream) == 1 and k.withheld() == [2]
     assert k.poll() == (0, 0)
+
+
+@pytest.mark.parametrize("name,cutoff", [("2clr", 1.0), ("1dwc_x4", 1.2)])
+def test_fast_mode_rows_on_larger_systems(gpu_required, systems, name, cutoff):
+    """Fast mode runs all three pair stages in row form (neighbour lists within cutoff + skin, no pair beyond the cutoff is
+    met): the second protein and the 16 608-atom lattice (BASELINE config 4) against the oracle's cutoff switch, on the
+    file geometry and after the atoms have moved (lists rebuilt)."""
+    s = P.lattice(systems("1dwc"), 2, 2, 1, 7.0) if name == "1dwc_x4" else systems(name)
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    force.setCutoffDistance(cutoff)
+    k = P.HipCalcAGBNPForceKernel(mode="fast")
+    k.initialize(force)
+    oracle = Oracle(*s.params(), version=1, cutoff=cutoff)
+    rng = np.random.default_rng(5)
+    for pos in (s.pos, s.pos + rng.normal(0.0, 0.04, s.pos.shape)):
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo, tol=FAST_TOL)
+    assert k.scalar("rows_on") == 1 and int(k.scalar("row_builds")) == 2
