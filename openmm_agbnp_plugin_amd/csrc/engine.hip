@@ -111,6 +111,8 @@ struct agbnp_hip_context {
                                // inside the cutoff are met and the row form is several times faster), off in the reference mode
                                // (where it is exact but, on 1dwc, not yet faster than the tiles)
   int nlg_stride = 0;
+  double row_fill = 1.5;       // AGBNP_HIP_ROW_FILL: the density bound behind the walked part of a list, in protein-interior densities
+  int row_boost = 1;           // widens the part of a list that the row launches walk (doubles when a list has outgrown it)
   DevBuf<double> d_nl_ref, d_bw;
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
@@ -339,6 +341,18 @@ void wire_args(agbnp_hip_context* c) {
     P.nlg = c->d_nlg.p;
     P.nlg_count = c->d_nlg_count.p;
     P.nlg_stride = c->nlg_stride;
+    {
+      // what the launches walk of a list: the atoms that 1.5 x the density of a protein interior (105 atoms, 52 heavy ones
+      // per nm^3) puts within reach + skin of a group of four bonded atoms (0.3 nm across), per part, in slices of 256 --
+      // times row_boost after a list has outgrown it
+      auto cap = [&](double radius, double density, int parts, int stride) {
+        const double r = radius + 0.3, most = c->row_fill * density * (4.0 / 3.0) * M_PI * r * r * r / parts * c->row_boost;
+        return std::max(256, (int)std::min(most + 255.0, 1e9) / 256 * 256);
+      };
+      P.nlh_cap = std::min(cap(reach, 52.0, kBornParts, c->nlh_stride), std::max(c->nlh_stride, 1));
+      P.nla_cap = std::min(cap(reach, 105.0, kChainParts, c->nla_stride), std::max(c->nla_stride, 1));
+      P.nlg_cap = std::min(cap(gb_reach, 105.0, kGbParts, c->nlg_stride), std::max(c->nlg_stride, 1));
+    }
     if (P.gb_rows) {  // the GB rows leave one energy partial per wave
       P.egb_part = c->d_egb_rows.p;
       P.egb_parts = (int)c->d_egb_rows.count;
@@ -453,6 +467,7 @@ int allocate_rows(agbnp_hip_context* c) {
   if (c->lut.nscreened > kMaxTypes || c->lut.nscreener > kMaxTypes) return AGBNP_HIP_OK;
   if ((size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1) * 2 * sizeof(double2) > kMaxTableBytes) return AGBNP_HIP_OK;
   if (getenv("AGBNP_HIP_SKIN")) c->skin = std::min(1.0, std::max(0.0, atof(getenv("AGBNP_HIP_SKIN"))));
+  if (getenv("AGBNP_HIP_ROW_FILL")) c->row_fill = std::max(0.01, atof(getenv("AGBNP_HIP_ROW_FILL")));  // (tests: force the walk to widen)
   auto sorted_by_type = [&](int count, auto type_of) {
     std::vector<unsigned> v;
     for (int k = 0; k < count; k++) v.push_back((unsigned)k | ((unsigned)type_of(k) << 24));
@@ -684,7 +699,12 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
     // the forces leave with the pseudo-volume launch itself (TreeOutputs, tree_kernels.h): no output launch
     TreeOutputs& O = c->T.out;
-    const bool fused = c->fused_outputs && c->nh > 0;  // (no heavy atom: no tree launch to carry them)
+    // The forces leave with the pseudo-volume launch when that launch is one round of workgroups (1dwc: -1 us, A/B on one
+    // box).  With more forests than resident workgroups a workgroup replays several forests in a row, and the next
+    // forest's loads queue behind the force atomics of the one before (three adds on one line of the caller's [n][3]
+    // buffer retire more slowly than the heavy-atom table's separate rows: lattice of 16.6 k atoms 49 -> 99 us): there the
+    // output launch stays.  (No heavy atom: no tree launch to carry them.)
+    const bool fused = c->fused_outputs && c->nh > 0 && c->nh <= 2 * c->tree_slots[c->variant];
     O.enabled = fused ? 1 : 0;
     O.n = c->n;
     O.a2h = c->d_a2h.p;
@@ -773,9 +793,14 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
   if (s[kStatStickyRow] && !c->rows_disabled) {
-    // a neighbour row of the row-form pair stages outgrew its stride: the tile kernels from here on (other launches:
-    // a captured graph of this context is stale)
-    c->rows_disabled = true;
+    // a neighbour list of the row-form pair stages outgrew what the launches walk of it: they walk twice as much from
+    // here on -- or, if that already was the whole stride, the tile kernels take over (other launches either way: a
+    // captured graph of this context is stale)
+    const bool whole = c->P.nlh_cap >= c->nlh_stride && c->P.nla_cap >= c->nla_stride && (!c->P.gb_rows || c->P.nlg_cap >= c->nlg_stride);
+    if (whole)
+      c->rows_disabled = true;
+    else
+      c->row_boost *= 2;
     wire_args(c);
     c->generation++;
   }

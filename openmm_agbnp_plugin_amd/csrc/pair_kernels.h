@@ -123,6 +123,9 @@ struct PairArgs {
   int* nlg_count;          // [groups x kGbParts]
   int nlg_stride;
   double nlg_build2;       // squared radius of those lists
+  int nlh_cap, nla_cap, nlg_cap;  // entries of a list that the launches walk (multiples of 256, <= the strides): what the reach
+                                  // of the current mode can fill at protein density; a list that outgrows it withholds the
+                                  // evaluation and the host widens the walk
   double4* rec_h;          // [nh] {x, y, z, 1 / V_vdw} by heavy index (k_prep): what a Born row gathers of a neighbour (+ its self volume)
   double4* hrow;           // [nh] {x, y, z, atom | screener type << 24} by heavy index (k_prep): a chain-rule row's own record
   double* bw;              // [n] brw + bru by atom: the GB stage adds alpha_i (diagonal tile) + beta_i * (Y of the tile) with atomics

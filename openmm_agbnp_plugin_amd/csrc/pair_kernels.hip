@@ -1605,7 +1605,7 @@ constexpr int kRowSlice = 256, kRowWaves = 8;
 struct RowLists {  // the lists of one kind
   unsigned* list;
   int* count;
-  int stride, groups, parts;
+  int stride, cap, groups, parts;  // cap: entries the launches walk (<= stride)
 };
 template <int KIND>
 __device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
@@ -1613,6 +1613,7 @@ __device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
   L.list = KIND == kBornRows ? P.nlh : KIND == kChainRows ? P.nla : P.nlg;
   L.count = KIND == kBornRows ? P.nlh_count : KIND == kChainRows ? P.nla_count : P.nlg_count;
   L.stride = KIND == kBornRows ? P.nlh_stride : KIND == kChainRows ? P.nla_stride : P.nlg_stride;
+  L.cap = KIND == kBornRows ? P.nlh_cap : KIND == kChainRows ? P.nla_cap : P.nlg_cap;
   L.groups = ((KIND == kChainRows ? P.nh : P.n) + kRowGroup - 1) / kRowGroup;
   L.parts = KIND == kBornRows ? kBornParts : KIND == kChainRows ? kChainParts : kGbParts;
   return L;
@@ -1620,16 +1621,20 @@ __device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
 // one wave builds list `sub` of kind KIND (the lists of the later launches are built in the Born launch: both see the same
 // positions, and an overflowing list is known before the energy is added up)
 template <int KIND>
-__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane) {
+__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane, int stale) {
   const RowLists L = row_lists<KIND>(P);
   if (sub >= L.groups * L.parts) return;
+  if (!stale) {  // the list stands; is all of it walked?  (the walk may have been set up for a shorter reach, or narrowed)
+    if (lane == 0 && L.count[sub] > L.cap) P.status[kStatRowOverflow] = 1;
+    return;
+  }
   const int g = sub / L.parts, part = sub - g * L.parts;
   const RowAtoms A = row_atoms<KIND>(P, g);
   const int cnt = row_build(A, P.aperm, P.aperm_n, part, L.parts, static_cast<const double4*>(P.aposq), KIND == kGbRows ? P.nlg_build2 : P.nl_build2,
                             L.list + (size_t)sub * L.stride, L.stride, lane);
   if (lane == 0) {
     L.count[sub] = min(cnt, L.stride);
-    if (cnt > L.stride) P.status[kStatRowOverflow] = 1;
+    if (cnt > L.cap) P.status[kStatRowOverflow] = 1;
   }
 }
 
@@ -1662,19 +1667,18 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
   const RowLists L = row_lists<KIND>(P);
   const int NP = L.parts, stride = L.stride;
   const int nlists = L.groups * NP, lists_pad = (nlists + kRowWaves - 1) & ~(kRowWaves - 1);
-  const int slices = (stride + kRowSlice - 1) / kRowSlice;
+  const int slices = (L.cap + kRowSlice - 1) / kRowSlice;
   const int walk_blocks = lists_pad / kRowWaves * slices;
   const int stale = P.nl_flag[0];
   if (KIND == kBornRows && blk >= walk_blocks) {
-    // The lists of the later launches are built here, in the Born launch, by workgroups that exit at once in an
-    // evaluation whose lists are still good.
-    if (!stale) return;
+    // The lists of the later launches are built here, in the Born launch, by workgroups that only look at the lists'
+    // lengths in an evaluation whose lists are still good.
     const int sub = (blk - walk_blocks) * kRowWaves + wave;
     const int chain_lists = row_lists<kChainRows>(P).groups * kChainParts;
     if (sub < chain_lists)
-      build_list<kChainRows>(P, sub, lane);
+      build_list<kChainRows>(P, sub, lane, stale);
     else if (P.gb_rows)
-      build_list<kGbRows>(P, sub - chain_lists, lane);
+      build_list<kGbRows>(P, sub - chain_lists, lane, stale);
     return;
   }
   PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 0);
@@ -1735,7 +1739,7 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
     count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
     if (lane == 0 && slice == 0) {
       P.nlh_count[sub] = min(count, stride);
-      if (count > stride) P.status[kStatRowOverflow] = 1;
+      if (count > L.cap) P.status[kStatRowOverflow] = 1;
       if (sub == 0) P.nl_flag[1] += 1;  // (builds so far: agbnp_hip_get_scalar)
     }
     if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
@@ -1746,6 +1750,7 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
+  if (KIND == kBornRows && active && slice == 0 && lane == 0 && count > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
   const int todo = active ? max(0, min(count - first, kRowSlice)) : 0;  // entries of this slice
   const int nsteps = (todo + 63) >> 6;
   double acc[4 * R];
@@ -2006,9 +2011,9 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   if (P.rows_on) {  // row form of the two range-limited stages (and, in fast mode, of the GB stage)
     auto gb = P.fast ? k_gb_tiles<true, false> : k_gb_tiles<false, false>;
     const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
-    auto walk_blocks = [](int lists, int stride) { return (lists + kRowWaves - 1) / kRowWaves * ((stride + kRowSlice - 1) / kRowSlice); };
-    const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_stride), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_stride);
-    const int gb_blocks = walk_blocks(born_groups * kGbParts, P.nlg_stride);
+    auto walk_blocks = [](int lists, int cap) { return (lists + kRowWaves - 1) / kRowWaves * ((cap + kRowSlice - 1) / kRowSlice); };
+    const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_cap), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_cap);
+    const int gb_blocks = walk_blocks(born_groups * kGbParts, P.nlg_cap);
     // the lists of the later launches are built in the Born launch
     const int build_blocks = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kRowWaves - 1) / kRowWaves;
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);

@@ -1032,3 +1032,22 @@ def test_fast_mode_rows_on_larger_systems(gpu_required, systems, name, cutoff):
         eo, fo = oracle.execute(pos)
         assert_close(e, f, eo, fo, tol=FAST_TOL)
     assert k.scalar("rows_on") == 1 and int(k.scalar("row_builds")) == 2
+
+
+def test_neighbour_list_walk_widens_on_demand(gpu_required, systems, monkeypatch):
+    """The row launches walk as much of a list as protein density can fill at the current reach; a list that outgrows that
+    (forced here with an absurdly low density bound) withholds the evaluation like any capacity overflow, the host doubles
+    the walk and repeats: exact numbers, and the row form stays on."""
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_ROW_FILL", "0.05")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    for step in range(2):
+        pos = s.jittered(step)
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+    assert k.scalar("rows_on") == 1
