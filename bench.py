@@ -44,7 +44,7 @@ PAIR_STEP_VALU = {
     "k_born_tiles": {"hh": (49.6, 35), "hl": (35.9, 26)},   # (loop body + the tile's prologue / epilogue spread over its steps)
     "k_dborn_tiles": {"hh": (75, 56), "hl": (52.7, 40)},
 }
-ISSUE_BOUND_KERNELS = ("k_gb_tiles", "k_born_tiles", "k_dborn_tiles", "k_born_rows", "k_dborn_rows")
+ISSUE_BOUND_KERNELS = ("k_gb_tiles", "k_born_tiles", "k_dborn_tiles", "k_born_rows", "k_dborn_rows", "k_gb_rows")
 
 
 def newest_profile_dir():
@@ -53,24 +53,32 @@ def newest_profile_dir():
     return os.path.join(root, tags[-1]) if tags else None
 
 
-def counter_valu_instructions(system_name):
+ROW_KERNEL_NAMES = {"k_rows<0>": "k_born_rows", "k_rows<1>": "k_dborn_rows", "k_rows<2>": "k_gb_rows"}  # rocprof name -> engine name
+
+
+def counter_valu_instructions(system_name, mode=None):
     """Vector wave-instructions per launch of every kernel as the SQ counters saw them (SQ_INSTS_VALU of the newest
-    profiles/rNN/pmc_utilization.csv, taken on this workload with scripts/profile_round.sh).  None when there is none."""
+    profiles/rNN counter summaries, taken on this workload with scripts/profile_round.sh / profile_rows.sh: the default
+    configuration, the reference mode with the row form, the fast mode).  None when there is none."""
     d = newest_profile_dir()
     if d is None or system_name != "1dwc":
         return None, None
-    path = os.path.join(d, "pmc_utilization.csv")
-    if not os.path.exists(path):
-        return None, None
     import csv
-    out = {}
-    for row in csv.DictReader(open(path)):
-        try:
-            out[row["kernel"]] = {"valu": float(row["SQ_INSTS_VALU"]), "lds_conflict_share": float(row["lds_bank_conflict_share"]),
-                                  "valu_share_of_wave_cycles": float(row["valu_share_of_wave_cycles"])}
-        except (KeyError, ValueError):
+    out, used = {}, []
+    files = ["fast_pmc_utilization.csv"] if mode in ("fast", "fast+single") else ["rows_pmc_utilization.csv", "pmc_utilization.csv"]
+    for name in files:  # (later files win: the default configuration's own counters over the row-form run's)
+        path = os.path.join(d, name)
+        if not os.path.exists(path):
             continue
-    return out, os.path.relpath(path, ROOT)
+        used.append(os.path.relpath(path, ROOT))
+        for row in csv.DictReader(open(path)):
+            try:
+                out[ROW_KERNEL_NAMES.get(row["kernel"], row["kernel"])] = {
+                    "valu": float(row["SQ_INSTS_VALU"]), "lds_conflict_share": float(row["lds_bank_conflict_share"]),
+                    "valu_share_of_wave_cycles": float(row["valu_share_of_wave_cycles"])}
+            except (KeyError, ValueError):
+                continue
+    return (out, " + ".join(used)) if out else (None, None)
 
 
 def algorithmic_bytes(n_atoms, slots):
@@ -553,7 +561,7 @@ def main():
         # The roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave holds
         # its SIMD for 4 cycles at FP64 rate).  Instruction counts: SQ_INSTS_VALU of the committed counter pass where there
         # is one for this workload, else the hand-read table x the wave-steps this geometry makes the kernels execute.
-        counters, counter_file = counter_valu_instructions(args.system)
+        counters, counter_file = counter_valu_instructions(args.system, mode)
         steps_by_kernel = pair_wave_steps(system, rep.geoms[W])
         issue = []
         for kname in ISSUE_BOUND_KERNELS:
