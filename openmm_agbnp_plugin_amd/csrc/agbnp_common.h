@@ -65,15 +65,16 @@ enum StatusWord {
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
-  kStatEvalWords = 10,     // ---- everything below is sticky
-  kStatEvalSeq = 10,       // evaluations enqueued since the last agbnp_hip_finish
-  kStatBadCount = 11,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
-  kStatStickyNode = 12,    // OR of the per-evaluation overflow words over those evaluations
-  kStatStickyAtom = 13,
-  kStatStickyPack = 14,
-  kStatStickyRow = 15,
-  kStatWords = 16,
-  kStatBadBitmap = 16,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatTreeDone = 10,      // tree workgroups of k_tree_cavity that have left (what the Born rows at the launch's tail wait for)
+  kStatEvalWords = 12,     // ---- everything below is sticky
+  kStatEvalSeq = 12,       // evaluations enqueued since the last agbnp_hip_finish
+  kStatBadCount = 13,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
+  kStatStickyNode = 14,    // OR of the per-evaluation overflow words over those evaluations
+  kStatStickyAtom = 15,
+  kStatStickyPack = 16,
+  kStatStickyRow = 17,
+  kStatWords = 20,
+  kStatBadBitmap = 20,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
   kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };

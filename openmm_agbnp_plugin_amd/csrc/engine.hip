@@ -32,7 +32,7 @@ size_t tree_variant_scratch_bytes(int variant);
 int tree_variant_node_cap(int variant);
 int tree_variant_atom_cap(int variant);
 int tree_variant_wgs_per_cu(int variant);
-hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
+hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st, int tail_blocks);
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
 
@@ -117,6 +117,8 @@ struct agbnp_hip_context {
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
   bool fused_outputs = true;   // version 1: the pseudo-volume launch adds the forces itself (AGBNP_HIP_OUTPUT_LAUNCH=1: k_outputs does)
+  bool born_tail = false;      // row form: the Born rows ride at the tail of the cavity launch (AGBNP_HIP_BORN_TAIL=1; experiment)
+  DevBuf<PairArgs> d_pair_args;  // the pair stages' argument block in device memory (what the tail reads)
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
   double skin = 0.1;           // nm; AGBNP_HIP_SKIN
@@ -439,6 +441,13 @@ void wire_args(agbnp_hip_context* c) {
     T.slot_cap = c->slot_cap;
   }
   T.status = c->d_status.p;
+  if (c->rows_capable) {  // the tail of the cavity launch reads the pair stages' arguments from device memory
+    if (c->d_pair_args.p == nullptr) (void)c->d_pair_args.alloc(1);
+    if (c->d_pair_args.p) (void)hipMemcpy(c->d_pair_args.p, &c->P, sizeof(PairArgs), hipMemcpyHostToDevice);
+  }
+  T.pair_dev = c->d_pair_args.p;
+  T.born_tail = 0;
+  T.tree_blocks = 0;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
 }
@@ -693,7 +702,15 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   // workgroups of the tree launches: what the device keeps resident for this variant (they take forests from a queue);
   // fewer if there cannot be that many forests
   const int tree_grid = std::max(1, std::min(c->slot_cap, c->tree_slots[c->variant]));
-  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
+  // Born rows at the tail of the cavity launch (TreeArgs): the row form's Born launch is then not launched
+  int tail_blocks = 0;
+  c->P.born_in_tail = 0;
+  if (c->version == 1 && c->P.rows_on && c->born_tail && c->variant <= 3 &&
+      (size_t)2 * c->P.nti * c->P.ntj * (kI4Nodes - 1) * sizeof(double2) <= tree_variant_lds_bytes(c->variant)) {
+    tail_blocks = born_tail_blocks(c->P);
+    c->P.born_in_tail = 1;
+  }
+  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st, tail_blocks));
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
@@ -850,6 +867,10 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   c->cutoff = cutoff;
   c->device = device;
   c->fused_outputs = getenv("AGBNP_HIP_OUTPUT_LAUNCH") == nullptr;
+  // (measured on 1dwc, row form: cavity + Born 45.4 + 15.3 us as two launches, 70.7 us as one -- the Born workgroups'
+  // table copies and the three-wave workgroups they inherit from the tree launch cost more than the boundary saves: off
+  // unless asked for)
+  c->born_tail = getenv("AGBNP_HIP_BORN_TAIL") != nullptr && atoi(getenv("AGBNP_HIP_BORN_TAIL")) != 0;
   c->r_vdw.assign(radius, radius + n);
   c->gamma.resize(n);
   c->alpha.assign(vdw_alpha, vdw_alpha + n);

@@ -118,6 +118,7 @@ struct PairArgs {
   unsigned* nla;           // [groups of 4 heavy atoms x kChainParts][nla_stride] neighbours of any kind, entries as in aperm
   int* nla_count;          // [groups x kChainParts]
   int nla_stride;
+  int born_in_tail;        // 1: the Born rows (and the list builders) ride at the tail of the cavity launch (tree_kernels.hip)
   int gb_rows;             // 1: the GB stage runs in row form too (fast mode: only pairs inside the cutoff are met)
   unsigned* nlg;           // [groups of 4 atoms x kGbParts][nlg_stride] neighbours of any kind within the GB cutoff + skin
   int* nlg_count;          // [groups x kGbParts]
@@ -162,6 +163,7 @@ struct Timeline {
 };
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
+int born_tail_blocks(const PairArgs& P);  // workgroups of three waves that the Born rows + list builders take at the tail of the cavity launch
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl);
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl);

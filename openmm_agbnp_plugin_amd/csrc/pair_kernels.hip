@@ -60,6 +60,15 @@ __device__ unsigned long long g_pair_log[3][kPairLogSlots][12];
 #define PAIR_STAMP_WAIT(kern, idx, what)
 #define PAIR_STAMP_WHERE(kern, item)
 #endif
+#ifdef AGBNP_PAIR_STAMPS
+#define ROWS_LOG_COUNTS(kern, todo, nsteps)                                                                         \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[kern][blockIdx.x][6] = (unsigned)(todo), g_pair_log[kern][blockIdx.x][9] = (unsigned)(nsteps); \
+  } while (0)
+#endif
+}  // namespace agbnp
+#include "row_kernels.h"
+namespace agbnp {
 
 // ---- I4 spline (uniform nodes x_k = k*dr, k = 0..15; table entry = {y_k, z_k = y2_k*dr^2/6}) -------------------
 // Natural cubic spline of the reference (AGBNPUtils.h:104-115 -> SplineFitter): on interval k, with t in [0,1),
@@ -114,19 +123,6 @@ __device__ __forceinline__ void lut_store(double2* __restrict__ s_lut, const Lut
 }
 __device__ __forceinline__ void lut_copy_rest(double2* __restrict__ s_lut, const double2* __restrict__ lut, int lut_entries) {
   for (int base = 1024; base < lut_entries; base += 1024) lut_store(s_lut, lut_fetch(lut, lut_entries, base), lut_entries, base);
-}
-
-__device__ __forceinline__ void hbm_add(double* p, double v) {  // global_atomic_add_f64
-#ifdef AGBNP_TIMING_NO_ATOMICS  // timing experiment only: results are wrong
-  if (v == 1.2345e300) *p = v;
-  return;
-#endif
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
 }
 
 // ---- geometry in, accumulators cleared -------------------------------------------------------------------
@@ -267,31 +263,6 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     }
   }
 }
-
-// ---- per-atom Born-radius algebra, recomputed by its consumers instead of a kernel of its own ---------------
-// beta_i = 1/R_i - (1/4pi) sum_j s_j Q  ->  B_i = 1/f(beta_i), f' (ReferenceAGBNPKernels.cpp:41-55,450-454)
-struct BornRadius {
-  double br, inv_br, fp;
-};
-__device__ __forceinline__ BornRadius born_radius(double inv_rvdw, double qsum) {
-  const double beta = inv_rvdw - (1. / (4. * kPi)) * qsum;
-  const double amin = 1. / kI4MaxA, a2 = 1. / (kI4MaxA * kI4MaxA);
-  BornRadius r;
-  if (beta < 0.0) {
-    r.inv_br = amin;
-    r.fp = 0.0;
-  } else {
-    r.inv_br = sqrt(a2 + beta * beta);
-    r.fp = beta / r.inv_br;
-  }
-  r.br = 1. / r.inv_br;
-  return r;
-}
-// bw_i = brw_i + bru_i with bru_i = -(1/4pi) k (q_i^2 + Y_i B_i) f'_i (ReferenceAGBNPKernels.cpp:524-542) is linear in the GB
-// stage's Y sum: bw_i = alpha_i + beta_i Y_i.  With the row form of the chain rule the GB tiles add alpha_i (once, the
-// diagonal tile) and beta_i * (their share of Y_i) straight into bw_i, so that a chain-rule row gathers ONE word per neighbour.
-__device__ __forceinline__ double bw_beta(const BornRadius& r) { return -(1. / (4. * kPi)) * kDielFactor * r.br * r.fp; }
-__device__ __forceinline__ double bw_alpha(const BornRadius& r, double brw, double q) { return brw - (1. / (4. * kPi)) * kDielFactor * (q * q) * r.fp; }
 
 // ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
 // A workgroup of four waves owns one tile (I <= J).  In every wave lane l keeps atom i = 64 I + l and its sums in
@@ -1491,161 +1462,13 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
   PAIR_STAMP(2, 3);
 }
 
-// ---- row form of the two range-limited stages ------------------------------------------------------------------------
-// The tile kernels above meet every pair of two 64-atom blocks; on a protein of a few thousand atoms a third of those pairs
-// lie inside the tables' 2 nm reach, and a wave pays for all of them.  The row form meets (almost) only pairs in reach and
-// needs no atomics and no second look-up per pair:
-//
-//   Born row of atom a (every atom):      beta-sum_a = sum_b s_b Q_{t(a) t'(b)}(d)          b heavy, b != a, d < 2 nm
-//                                          G_a       = sum_b (r_b - r_a) s_b Q'_{t(a) t'(b)}(d) / d
-//   chain-rule row of heavy atom a:       (W+U)_a    = sum_b bw_b Q_{t(b) t'(a)}(d)           b of any kind, b != a, d < 2 nm
-//                                          H_a       = sum_b (r_b - r_a) bw_b Q'_{t(b) t'(a)}(d) / d
-//   chain-rule force:                      F_a      += bw_a G_a + s_a H_a                     (H_a = 0 for a hydrogen)
-//
-// which is the reference's loop (ReferenceAGBNPKernels.cpp:435-449,555-586) with its two force updates sorted by the atom
-// they land on: force[i] += w with w = dist bw_i s_j Q'/d sums up to bw_i G_i, force[j] -= w to s_j H_j.  G does not depend
-// on bw, so it rides in the Born rows, where the same table entry is being looked up anyway: each stage looks a pair up
-// once, as the symmetric tiles do.
-//
-// A GROUP = kRowGroup consecutive row atoms (bonded neighbours, a fraction of a nm apart) shares one neighbour list: a lane
-// gathers ONE neighbour record per step (list entry -> {x, y, z, .} and weight from memory: the vector-memory pipe is what
-// a one-row-per-wave form is bound by) and meets it with the group's row atoms, which are wave-uniform and live in scalar
-// registers.  The list of a group is cut into parts, one wave each (the parts take the 64-candidate chunks of the
-// candidate order in turn); the sums of a wave meet in a transposing butterfly, those of the parts in LDS, and leave
-// through plain stores.  Spline entries in 32-byte power form come from the slices of the group's row types in LDS.
-//
-// Neighbour lists: entries (index | type << 24) of every candidate within reach + skin of ANY row atom of the group, in
-// the order of a static candidate list sorted by type -- the lanes of a step then mostly read consecutive entries of one
-// table row: distinct LDS banks.  The lists are rebuilt, on the device and by the waves that own them, in the evaluation
-// whose k_prep found an atom further than skin / 2 from where it was at the last build (the lists of both kinds in the
-// Born launch, so both see the same positions and an overflowing list is known before the energy is added up);
-// d < 2 nm is still tested per pair, so the sums hold exactly the reference's pairs.
-constexpr int kRowIntervals = kI4Nodes - 1;
-
-// a value every lane holds alike, moved to scalar registers (the row atoms of a group: VALU operands, no vector registers)
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uniform(double v) {
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-template <int kCtrl>
-__device__ __forceinline__ double dpp_move(double v) {  // lane <- the lane that the DPP control names (bound_ctrl: no "old" operand)
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_xor1(double v) { return dpp_move<0xB1>(v); }                   // quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ double lane_xor2(double v) { return dpp_move<0x4E>(v); }                   // quad_perm [2, 3, 0, 1]
-__device__ __forceinline__ double lane_xor4(double v) { return dpp_move<0x1B>(dpp_move<0x141>(v)); }  // row_half_mirror, then quad_perm [3, 2, 1, 0]
-__device__ __forceinline__ double lane_xor8(double v) { return dpp_move<0x128>(v); }                  // row_ror:8
-
-enum RowKind { kBornRows = 0, kChainRows = 1, kGbRows = 2 };
-// Which atoms own rows, which are candidates:   Born rows: every atom <- heavy atoms;  chain-rule rows: heavy atoms <- every
-// atom;  GB rows (fast mode only: the reference's GB meets ALL pairs and stays on the tiles): every atom <- every atom
-// within the cutoff.
-struct RowAtoms {  // wave-uniform (scalar registers): the row atoms of a group
-  double x[kRowGroup], y[kRowGroup], z[kRowGroup];
-  int self[kRowGroup];   // index of the row atom in the candidates' numbering (never met: -1 for a row that is no candidate)
-  int rows;              // valid rows (the last group may be short)
-};
-
-template <int KIND>
-__device__ __forceinline__ RowAtoms row_atoms(const PairArgs& P, int group) {
-  RowAtoms A;
-  const int nrows = KIND == kChainRows ? P.nh : P.n;
-  A.rows = min(kRowGroup, nrows - kRowGroup * group);
-  const double4* __restrict__ pos = KIND == kChainRows ? static_cast<const double4*>(P.hrow) : static_cast<const double4*>(P.aposq);
-  double4 pr[kRowGroup];
-  int self[kRowGroup];
-#pragma unroll
-  for (int r = 0; r < kRowGroup; r++) {  // (all in flight together)
-    const int row = min(kRowGroup * group + r, nrows - 1);
-    pr[r] = pos[row];
-    self[r] = KIND == kBornRows ? P.a2h[row] : row;  // (Born rows: -1 for a hydrogen, no candidate has that index)
-  }
-#pragma unroll
-  for (int r = 0; r < kRowGroup; r++) {
-    const bool there = r < A.rows;
-    A.x[r] = uniform(there ? pr[r].x : 1e30);  // a row that does not exist is out of everybody's reach
-    A.y[r] = uniform(pr[r].y);
-    A.z[r] = uniform(pr[r].z);
-    A.self[r] = uniform(!there ? -1 : KIND == kChainRows ? (__double2loint(pr[r].w) & 0xffffff) : self[r]);
-  }
-  return A;
-}
-
-// builds one part of a group's list: the candidates perm[64 c + lane] of chunks c = part, part + parts, ... (index |
-// type << 24, ~0u = padding), their records rec[index] = {x, y, z, .}; returns the number of entries (may exceed stride)
-__device__ __forceinline__ int row_build(const RowAtoms& A, const unsigned* __restrict__ perm, int np, int part, int parts,
-                                         const double4* __restrict__ rec, double build2, unsigned* __restrict__ list, int stride, int lane) {
-  int cnt = 0;
-  for (int base = 64 * part; base < np; base += 64 * parts) {
-    const unsigned e = perm[base + lane];
-    const double4 r = rec[e != ~0u ? (int)(e & 0xffffffu) : 0];
-    double dmin = 1e300;
-#pragma unroll
-    for (int q = 0; q < kRowGroup; q++) {
-      const double dx = r.x - A.x[q], dy = r.y - A.y[q], dz = r.z - A.z[q];
-      dmin = fmin(dmin, fma(dz, dz, fma(dy, dy, dx * dx)));
-    }
-    const bool ok = e != ~0u && dmin < build2;
-    const unsigned long long m = __ballot(ok);
-    const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (ok && at < stride) list[at] = e;
-    cnt += __popcll(m);
-  }
-  return cnt;
-}
-
-// Work items: a list is walked in SLICES of kRowSlice entries (four steps), one wave each, so that no wave works longer
-// than four steps whatever the length of its list (the launch lasts as long as its slowest wave); item = slice * lists +
-// list, eight consecutive items per workgroup (a workgroup's items are the same slice of eight neighbouring lists: it is
-// empty as a whole, and leaves at once, or not at all).  The sums of a wave leave as one set of FP64 atomics.
-constexpr int kRowSlice = 256, kRowWaves = 8;
-
-struct RowLists {  // the lists of one kind
-  unsigned* list;
-  int* count;
-  int stride, cap, groups, parts;  // cap: entries the launches walk (<= stride)
-};
-template <int KIND>
-__device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
-  RowLists L;
-  L.list = KIND == kBornRows ? P.nlh : KIND == kChainRows ? P.nla : P.nlg;
-  L.count = KIND == kBornRows ? P.nlh_count : KIND == kChainRows ? P.nla_count : P.nlg_count;
-  L.stride = KIND == kBornRows ? P.nlh_stride : KIND == kChainRows ? P.nla_stride : P.nlg_stride;
-  L.cap = KIND == kBornRows ? P.nlh_cap : KIND == kChainRows ? P.nla_cap : P.nlg_cap;
-  L.groups = ((KIND == kChainRows ? P.nh : P.n) + kRowGroup - 1) / kRowGroup;
-  L.parts = KIND == kBornRows ? kBornParts : KIND == kChainRows ? kChainParts : kGbParts;
-  return L;
-}
-// one wave builds list `sub` of kind KIND (the lists of the later launches are built in the Born launch: both see the same
-// positions, and an overflowing list is known before the energy is added up)
-template <int KIND>
-__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane, int stale) {
-  const RowLists L = row_lists<KIND>(P);
-  if (sub >= L.groups * L.parts) return;
-  if (!stale) {  // the list stands; is all of it walked?  (the walk may have been set up for a shorter reach, or narrowed)
-    if (lane == 0 && L.count[sub] > L.cap) P.status[kStatRowOverflow] = 1;
-    return;
-  }
-  const int g = sub / L.parts, part = sub - g * L.parts;
-  const RowAtoms A = row_atoms<KIND>(P, g);
-  const int cnt = row_build(A, P.aperm, P.aperm_n, part, L.parts, static_cast<const double4*>(P.aposq), KIND == kGbRows ? P.nlg_build2 : P.nl_build2,
-                            L.list + (size_t)sub * L.stride, L.stride, lane);
-  if (lane == 0) {
-    L.count[sub] = min(cnt, L.stride);
-    if (cnt > L.cap) P.status[kStatRowOverflow] = 1;
-  }
-}
-
+// ---- row form of the pair stages: the launches (device code in row_kernels.h) -----------------------------------------
 // (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers; the GB rows, whose pair terms and
 // bookkeeping role need more, four)
 template <int KIND>
 __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
-  constexpr int R = kRowGroup;
-  static_assert(R == 4, "the butterfly below folds 16 sums");
   extern __shared__ double2 s_dyn[];
-  __shared__ int s_busy;
+
   int blk = blockIdx.x;
   if (KIND == kChainRows) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
     if (blk < 2 && threadIdx.x >= 256) return;
@@ -1663,256 +1486,8 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
     }
     blk -= 1;
   }
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const RowLists L = row_lists<KIND>(P);
-  const int NP = L.parts, stride = L.stride;
-  const int nlists = L.groups * NP, lists_pad = (nlists + kRowWaves - 1) & ~(kRowWaves - 1);
-  const int slices = (L.cap + kRowSlice - 1) / kRowSlice;
-  const int walk_blocks = lists_pad / kRowWaves * slices;
-  const int stale = P.nl_flag[0];
-  if (KIND == kBornRows && blk >= walk_blocks) {
-    // The lists of the later launches are built here, in the Born launch, by workgroups that only look at the lists'
-    // lengths in an evaluation whose lists are still good.
-    const int sub = (blk - walk_blocks) * kRowWaves + wave;
-    const int chain_lists = row_lists<kChainRows>(P).groups * kChainParts;
-    if (sub < chain_lists)
-      build_list<kChainRows>(P, sub, lane, stale);
-    else if (P.gb_rows)
-      build_list<kGbRows>(P, sub - chain_lists, lane, stale);
-    return;
-  }
-  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 0);
-  const int item = blk * kRowWaves + wave;
-  const int slice = item / lists_pad, li = item - slice * lists_pad;  // (a workgroup's eight items share the slice)
-  const bool active = li < nlists;
-  const int sub = active ? li : 0;  // (group, part)
-  const int group = sub / NP, part = sub - group * NP;
-  const unsigned* list = L.list + (size_t)sub * stride;  // (not restrict: a build rewrites it)
-  const int first = kRowSlice * slice;
-  // Everything that does not depend on anything is asked for at once: the length of the list, the first two steps of the
-  // slice (the lists start out zeroed: an entry beyond the length is a valid index), the row atoms and their types, the table.
-  const int listed = L.count[sub];
-  unsigned e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
-  const unsigned types = KIND == kGbRows ? 0u : (KIND == kChainRows ? P.cslice : P.bslice)[group];  // one byte per row
-  const RowAtoms A = row_atoms<KIND>(P, group);
-  double row_rv[R], row_bp[R], row_q[R];  // GB rows: 1/R_vdw, descreening sum and charge of the row atoms
-  if (KIND == kGbRows) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int a = min(R * group + r, P.n - 1);
-      row_rv[r] = P.inv_rvdw[a], row_bp[r] = P.born_part[a], row_q[r] = static_cast<const double4*>(P.aposq)[a].w;
-    }
-  }
-  const int ne = (KIND == kChainRows ? P.nti : P.ntj) * kRowIntervals;  // entries of a slice of the table (one row type)
-  const int tab = P.nti * P.ntj * kRowIntervals;                        // ... of the table: {c0, c1} of every entry, then {c2, c3}
-  double2* const s_tab = s_dyn;
-  constexpr int kWg = 64 * kRowWaves;
-  const double2* __restrict__ gtab = KIND == kChainRows ? P.pwt_a : P.pw_a;  // (pw_b / pwt_b follow pw_a / pwt_a in memory)
-  const int tx = threadIdx.x;
-  // a workgroup whose eight slices are all beyond the ends of their lists has nothing to do (not known while the lists
-  // are being rebuilt); it leaves before it asks for the table: nearly half of the workgroups of a launch are such
-  if (threadIdx.x == 0) s_busy = 0;
-  __syncthreads();
-  // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
-  const bool mine = active && ((KIND == kBornRows && stale) || first < listed || (KIND == kGbRows && slice == 0 && part == 0));
-  if (mine && lane == 0) s_busy = 1;
-  if (KIND == kGbRows && lane == 0 && !mine && item < P.egb_parts) P.egb_part[item] = 0.0;  // (every partial is summed up)
-  __syncthreads();
-  if (!s_busy) return;
-  double2 tv0, tv1, tv2;
-  if (KIND != kGbRows) tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
-  PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 7, "vmcnt(0) lgkmcnt(0)");
-  if (KIND != kGbRows) {
-    if (tx < 2 * tab) s_tab[tx] = tv0;
-    if (kWg + tx < 2 * tab) s_tab[kWg + tx] = tv1;
-    if (2 * kWg + tx < 2 * tab) s_tab[2 * kWg + tx] = tv2;
-    for (int base = 3 * kWg; base < 2 * tab; base += kWg)  // (larger tables)
-      if (base + tx < 2 * tab) s_tab[base + tx] = gtab[base + tx];
-  }
-  int slice_at[R];  // first entry of the row's slice of the table
-#pragma unroll
-  for (int r = 0; r < R; r++) slice_at[r] = uniform((int)((types >> (8 * r)) & 0xffu) * ne);
-  int count = listed;
-  if (KIND == kBornRows && stale && active) {
-    // every slice of a list rebuilds the list for itself (the same entries at the same places: the copies agree), so that
-    // no wave waits for another workgroup's
-    count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
-    if (lane == 0 && slice == 0) {
-      P.nlh_count[sub] = min(count, stride);
-      if (count > L.cap) P.status[kStatRowOverflow] = 1;
-      if (sub == 0) P.nl_flag[1] += 1;  // (builds so far: agbnp_hip_get_scalar)
-    }
-    if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
-      const int a = kRowGroup * group + lane;
-      P.nl_ref[3 * a] = P.pos[3 * a], P.nl_ref[3 * a + 1] = P.pos[3 * a + 1], P.nl_ref[3 * a + 2] = P.pos[3 * a + 2];
-    }
-    count = min(count, stride);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
-    e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
-  }
-  if (KIND == kBornRows && active && slice == 0 && lane == 0 && count > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
-  const int todo = active ? max(0, min(count - first, kRowSlice)) : 0;  // entries of this slice
-  const int nsteps = (todo + 63) >> 6;
-  double acc[4 * R];
-#pragma unroll
-  for (int q = 0; q < 4 * R; q++) acc[q] = 0.0;
-  constexpr double kPerNode = (kI4Nodes - 1) / kI4MaxA;
-  double esum = 0.0;    // GB rows: sum of q_a q_b f over the wave's pairs
-  double beta_r[R];     // GB rows: beta of the row atoms (see bw_beta)
-  if (KIND != kGbRows) {
-    const double4* __restrict__ rec = KIND == kChainRows ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
-    const double* __restrict__ wsrc = KIND == kChainRows ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
-    // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
-    // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
-    double4 r1 = rec[e1 & 0xffffffu];
-    double w1 = wsrc[e1 & 0xffffffu];
-    __syncthreads();  // the table is in LDS
-    PAIR_STAMP((KIND == kChainRows ? 2 : 0), 8);
-    PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
-#ifdef AGBNP_PAIR_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[(KIND == kChainRows ? 2 : 0)][blockIdx.x][6] = (unsigned)todo, g_pair_log[(KIND == kChainRows ? 2 : 0)][blockIdx.x][9] = (unsigned)nsteps;
-#endif
-    for (int k = 0; k < nsteps; k++) {
-      const unsigned e = e1;
-      const double4 rb = r1;
-      const double wb = w1;
-      e1 = e2;
-      r1 = rec[e1 & 0xffffffu];
-      w1 = wsrc[e1 & 0xffffffu];
-      e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
-      const int b = (int)(e & 0xffffffu);
-      const int tent = (int)(e >> 24) * kRowIntervals;
-      const double w = (KIND == kChainRows ? wb : wb * rb.w) * kPerNode;  // bw_b, or s_b = selfvol_b / V_b (times the table's d(t)/d(d))
-      const double range2 = 64 * k + lane < todo ? P.range2 : -1.0;  // (a lane beyond the slice meets nobody)
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
-        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-        if (d2 < range2 && b != A.self[r]) {
-          const double rinv = rsqrt_pos(d2);
-          const double u = (d2 * rinv) * kPerNode;
-          const int ent = slice_at[r] + tent + (int)u;
-          const double t = __builtin_amdgcn_fract(u);
-          const double2 ca = s_tab[ent], cb = s_tab[ent + tab];
-          // value and derivative of c0 + c1 t + c2 t^2 + c3 t^3 in five operations
-          const double b2 = fma(cb.y, t, cb.x), b1 = fma(b2, t, ca.y);
-          const double val = fma(b1, t, ca.x), der = fma(fma(cb.y, t, b2), t, b1);
-          acc[4 * r] = fma(w, val, acc[4 * r]);
-          const double g = w * der * rinv;
-          acc[4 * r + 1] = fma(dx, g, acc[4 * r + 1]);
-          acc[4 * r + 2] = fma(dy, g, acc[4 * r + 2]);
-          acc[4 * r + 3] = fma(dz, g, acc[4 * r + 3]);
-        }
-      }
-    }
-  } else {
-    // GB rows (fast mode): pair terms as in k_gb_tiles, every ordered pair from its row's side -- F_a = -2k sum_b D q_a q_b
-    // (1 - et/4) f^3, Y_a = sum_b q_a q_b (B_a B_b + d^2/4) et f^3, and the pair energy 2k sum_{a<b} = k sum_a sum_{b != a}.
-    // A neighbour's Born radius is formed from its finished descreening sum on the fly (one per lane and step).
-    const double4* __restrict__ rec = static_cast<const double4*>(P.aposq);
-    double qa[R], ba[R], ca_[R];  // charge, B, -log2(e) / (4 B) of the row atoms
-    BornRadius bra[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      bra[r] = born_radius(row_rv[r], row_bp[r]);
-      qa[r] = uniform(r < A.rows ? row_q[r] : 0.0);
-      ba[r] = uniform(bra[r].br);
-      ca_[r] = uniform((-0.25 * 1.4426950408889634074) * bra[r].inv_br);
-      beta_r[r] = bw_beta(bra[r]);
-    }
-    if (active && slice == 0 && part == 0 && lane < A.rows) {
-      // the first slice of a group's first list publishes the per-atom results once (as the diagonal tile does in
-      // k_gb_tiles): B_i, f'_i, vdW energy + GB self energy, brw_i, and alpha_i of bw_i (ReferenceAGBNPKernels.cpp:477,513-533)
-      const int a = R * group + lane;
-      BornRadius br = bra[0];
-      double qv = row_q[0];
-#pragma unroll
-      for (int r = 1; r < R; r++) {
-        if (lane == r) br = bra[r], qv = row_q[r];
-      }
-      const double al = P.alpha[a];
-      const double bh = br.br + kHBRadius, bh3 = bh * bh * bh;
-      const double brw_a = -(1. / (4. * kPi)) * 3. * al * br.br * br.br * br.fp / (bh3 * bh);
-      P.born[a] = br.br;
-      P.born_fp[a] = br.fp;
-      P.e_atom[a] = al / bh3 + kDielFactor * qv * qv * br.inv_br;
-      P.brw[a] = brw_a;
-      hbm_add(&P.bw[a], bw_alpha(br, brw_a, qv));
-    }
-    double4 r1 = rec[e1 & 0xffffffu];
-    double p1 = P.born_part[e1 & 0xffffffu], v1 = P.inv_rvdw[e1 & 0xffffffu];
-    PAIR_STAMP(1, 8);
-    PAIR_STAMP_WAIT(1, 1, "vmcnt(0)");  // the first records are here
-#ifdef AGBNP_PAIR_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) g_pair_log[1][blockIdx.x][6] = (unsigned)todo, g_pair_log[1][blockIdx.x][9] = (unsigned)nsteps;
-#endif
-    for (int k = 0; k < nsteps; k++) {
-      const unsigned e = e1;
-      const double4 rb = r1;
-      const BornRadius bb_ = born_radius(v1, p1);
-      e1 = e2;
-      r1 = rec[e1 & 0xffffffu];
-      p1 = P.born_part[e1 & 0xffffffu], v1 = P.inv_rvdw[e1 & 0xffffffu];
-      e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
-      const int b = (int)(e & 0xffffffu);
-      const double cut2 = 64 * k + lane < todo ? P.gb_cut2 : -1.0;  // (a lane beyond the slice meets nobody)
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const double dx = rb.x - A.x[r], dy = rb.y - A.y[r], dz = rb.z - A.z[r];
-        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
-        if (d2 < cut2 && b != A.self[r]) {
-          const double bb = ba[r] * bb_.br;
-          const double et = exp2_nonpositive(d2 * (ca_[r] * bb_.inv_br));  // exp(-d^2 / (4 B_a B_b))
-          const double fgb = rsqrt_pos(fma(bb, et, d2));
-          const double s1 = (qa[r] * rb.w) * fgb;
-          esum += s1;
-          const double s3 = s1 * (fgb * fgb);
-          const double mw = fma(-0.25, et, 1.0) * s3;
-          acc[4 * r] = fma(fma(0.25, d2, bb), et * s3, acc[4 * r]);  // Y
-          acc[4 * r + 1] = fma(dx, mw, acc[4 * r + 1]);
-          acc[4 * r + 2] = fma(dy, mw, acc[4 * r + 2]);
-          acc[4 * r + 3] = fma(dz, mw, acc[4 * r + 3]);
-        }
-      }
-    }
-    esum = wave_sum(esum);
-    if (lane == 0 && item < P.egb_parts) P.egb_part[item] = kDielFactor * esum;
-  }
-  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 2);
-  if (nsteps == 0) return;
-  // 16 sums per lane -> one per lane: four transposing butterfly stages (a lane keeps the half of the sums that its bit of
-  // the stage selects and adds its partner's copy of them; DPP moves), then the four 16-lane rows of the wave are added up
-  const bool u0 = lane & 1, u1 = lane & 2, u2 = lane & 4, u3 = lane & 8;
-#pragma unroll
-  for (int q = 0; q < 8; q++) acc[q] = (u0 ? acc[q + 8] : acc[q]) + lane_xor1(u0 ? acc[q] : acc[q + 8]);
-#pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = (u1 ? acc[q + 4] : acc[q]) + lane_xor2(u1 ? acc[q] : acc[q + 4]);
-#pragma unroll
-  for (int q = 0; q < 2; q++) acc[q] = (u2 ? acc[q + 2] : acc[q]) + lane_xor4(u2 ? acc[q] : acc[q + 2]);
-  double total = (u3 ? acc[1] : acc[0]) + lane_xor8(u3 ? acc[0] : acc[1]);
-  total += __shfl_xor(total, 16, 64);
-  total += __shfl_xor(total, 32, 64);
-  // bit s of the lane chose the halves of stage s: the lane's sum is number bit-reversed(lane & 15) = 4 * row + quantity
-  const int q = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-  const int r = q >> 2, c = q & 3;
-  if (lane < 16 && r < A.rows) {
-    const int row = R * group + r;  // atom (Born and GB rows) or heavy index (chain-rule rows)
-    if (KIND == kGbRows) {
-      double beta = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < R; rr++) beta = rr == r ? beta_r[rr] : beta;
-      if (c == 0)
-        hbm_add(&P.bw[row], beta * total);  // bw_a = alpha_a + beta_a Y_a
-      else
-        hbm_add(P.gb_fx + (size_t)(c - 1) * P.n + row, (-2.0 * kDielFactor) * total);
-    } else if (c == 0) {
-      // (the unit of the value sums goes back in: w carried the table's d(t)/d(d) for the derivatives)
-      hbm_add(KIND == kChainRows ? &P.db_wu[row] : &P.born_part[row], total * (1.0 / kPerNode));
-    } else {
-      hbm_add(reinterpret_cast<double*>((KIND == kChainRows ? P.hrec : P.grec) + row) + (c - 1), total);
-    }
-  }
-  PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 3);
+  __shared__ int s_busy;
+  rows_workgroup<KIND, kRowWaves, false>(P, blk, s_dyn, &s_busy, 0);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -2000,6 +1575,15 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   return hipGetLastError();
 }
 
+// Born rows at the tail of the cavity launch: that launch's workgroups are AGBNP_TREE_BLOCK / 64 = 3 waves wide
+constexpr int kTailWaves = AGBNP_TREE_BLOCK / 64;
+int born_tail_blocks(const PairArgs& P) {
+  const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
+  const int walk = (born_groups * kBornParts + kTailWaves - 1) / kTailWaves * ((P.nlh_cap + kRowSlice - 1) / kRowSlice);
+  const int build = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kTailWaves - 1) / kTailWaves;
+  return walk + build;
+}
+
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl) {
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
   if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
@@ -2018,9 +1602,11 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     const int build_blocks = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kRowWaves - 1) / kRowWaves;
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
-    AGBNP_MARK(kKBornRows);
-    hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
-    AGBNP_CHECK_LAUNCH();
+    if (!P.born_in_tail) {
+      AGBNP_MARK(kKBornRows);
+      hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+      AGBNP_CHECK_LAUNCH();
+    }
     if (P.gb_rows) {
       AGBNP_MARK(kKGbRows);
       hipLaunchKernelGGL(k_rows<kGbRows>, dim3(1 + gb_blocks), dim3(64 * kRowWaves), sizeof(StripSums), st, P, (double*)nullptr, (double*)nullptr, (int)sizeof(StripSums));

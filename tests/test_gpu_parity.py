@@ -1051,3 +1051,23 @@ def test_neighbour_list_walk_widens_on_demand(gpu_required, systems, monkeypatch
         eo, fo = oracle.execute(pos)
         assert_close(e, f, eo, fo)
     assert k.scalar("rows_on") == 1
+
+
+def test_born_rows_at_the_tail_of_the_cavity_launch(gpu_required, systems, monkeypatch):
+    """AGBNP_HIP_BORN_TAIL=1 (experiment, off by default): the Born rows ride in the cavity launch behind the forest
+    workgroups and wait on a device-scope counter of finished tree workgroups.  Same numbers, lists rebuilt when atoms move."""
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_BORN_TAIL", "1")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    rng = np.random.default_rng(2)
+    pos = s.pos.copy()
+    for sigma in (0.0, 0.003, 0.07, 0.002):
+        pos = pos + rng.normal(0.0, sigma, pos.shape) if sigma > 0 else pos
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+    assert int(k.scalar("row_builds")) == 2
