@@ -105,11 +105,12 @@ struct agbnp_hip_context {
   DevBuf<int> d_a2s;
   // row form of the range-limited stages (pair_kernels.hip, k_rows)
   DevBuf<unsigned> d_hperm, d_aperm, d_nlh, d_nla, d_nlg, d_bslice, d_cslice;
-  DevBuf<int> d_nlh_count, d_nla_count, d_nlg_count, d_nl_flag;
+  DevBuf<int> d_nlh_count, d_nla_count, d_nlg_count, d_nl_flag, d_nl_nitems;
+  DevBuf<unsigned> d_nl_items;
+  int nl_items_cap = 0;
   DevBuf<double> d_egb_rows;   // per-wave energy partials of the GB rows
-  int rows_policy = -1;        // AGBNP_HIP_ROWS: 1 on wherever it can run, 0 off, unset (-1): on in fast mode (where only the pairs
-                               // inside the cutoff are met and the row form is several times faster), off in the reference mode
-                               // (where it is exact but, on 1dwc, not yet faster than the tiles)
+  int rows_policy = -1;        // AGBNP_HIP_ROWS: 0 = the tile kernels everywhere; unset or 1 = the row form wherever it can run (reference
+                               // and fast mode; the deterministic and single-precision modes keep the tiles)
   int nlg_stride = 0;
   double row_fill = 1.5;       // AGBNP_HIP_ROW_FILL: the density bound behind the walked part of a list, in protein-interior densities
   int row_boost = 1;           // widens the part of a list that the row launches walk (doubles when a list has outgrown it)
@@ -334,7 +335,7 @@ void wire_args(agbnp_hip_context* c) {
   {
     // Row form (reference mode only: the fast mode cuts every stage at the cutoff and the deterministic mode fixes the
     // order of its sums through the tiles' quantized totals)
-    const bool wanted = c->rows_policy == 1 || (c->rows_policy == -1 && P.fast);
+    const bool wanted = c->rows_policy != 0;  // (AGBNP_HIP_ROWS=0: the tile kernels everywhere)
     P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.det && !P.single && wanted ? 1 : 0;
     P.gb_rows = P.rows_on && P.fast && c->d_nlg.p != nullptr && getenv("AGBNP_HIP_NO_GB_ROWS") == nullptr ? 1 : 0;
     const double reach = sqrt(P.range2) + c->skin, gb_reach = c->cutoff + c->skin;  // (fast mode: the range-limited stages stop at the cutoff too)
@@ -343,6 +344,9 @@ void wire_args(agbnp_hip_context* c) {
     P.nlg = c->d_nlg.p;
     P.nlg_count = c->d_nlg_count.p;
     P.nlg_stride = c->nlg_stride;
+    P.nl_items = c->d_nl_items.p;
+    P.nl_nitems = c->d_nl_nitems.p;
+    P.nl_items_cap = c->nl_items_cap;
     {
       // what the launches walk of a list: the atoms that 1.5 x the density of a protein interior (105 atoms, 52 heavy ones
       // per nm^3) puts within reach + skin of a group of four bonded atoms (0.3 nm across), per part, in slices of 256 --
@@ -468,8 +472,6 @@ int allocate_rows(agbnp_hip_context* c) {
   constexpr int kMaxTypes = 255;     // a row's type is one byte of its group's slice word
   constexpr size_t kMaxTableBytes = 40 * 1024;  // the power-form table lives in LDS whole (1dwc: 8 x 6 types, 23 KB)
   constexpr int kMaxParticles = 65536;
-  // (round 3, work in progress: the row form is exact and tested but not yet faster than the tiles on 1dwc -- every
-  // workgroup pays for its own copy of the table -- so it is opt-in until its persistent form is in)
   const char* want = getenv("AGBNP_HIP_ROWS");
   c->rows_policy = want == nullptr ? -1 : (atoi(want) != 0 ? 1 : 0);
   if (c->version != 1 || nh == 0 || n > kMaxParticles || c->rows_policy == 0) return AGBNP_HIP_OK;
@@ -527,6 +529,17 @@ int allocate_rows(agbnp_hip_context* c) {
     const size_t waves = (gb_lists + 7) / 8 * 8 * (size_t)((c->nlg_stride + 255) / 256);  // one energy partial per wave of the GB rows
     HIP_TRY(c, c->d_egb_rows.alloc(waves));
     HIP_TRY(c, hipMemset(c->d_egb_rows.p, 0, sizeof(double) * waves));
+  }
+  {
+    // work items: at most every slice of every list of the largest kind
+    const size_t gb_lists = c->nlg_stride > 0 ? (size_t)((n + kRowGroup - 1) / kRowGroup) * kGbParts : 0;
+    const size_t most = std::max(std::max(born_lists * ((c->nlh_stride + 255) / 256), chain_lists * ((c->nla_stride + 255) / 256)),
+                                 gb_lists * ((c->nlg_stride + 255) / 256));
+    c->nl_items_cap = (int)std::min<size_t>(most + 8, 1u << 30);
+    HIP_TRY(c, c->d_nl_items.alloc((size_t)6 * c->nl_items_cap));
+    HIP_TRY(c, hipMemset(c->d_nl_items.p, 0, sizeof(unsigned) * 6 * (size_t)c->nl_items_cap));
+    HIP_TRY(c, c->d_nl_nitems.alloc(6));
+    HIP_TRY(c, hipMemset(c->d_nl_nitems.p, 0, sizeof(int) * 6));
   }
   HIP_TRY(c, c->d_nlh_count.alloc(born_lists));
   HIP_TRY(c, c->d_nla_count.alloc(chain_lists));
@@ -814,10 +827,13 @@ int harvest(agbnp_hip_context* c, int* repeat) {
     // here on -- or, if that already was the whole stride, the tile kernels take over (other launches either way: a
     // captured graph of this context is stale)
     const bool whole = c->P.nlh_cap >= c->nlh_stride && c->P.nla_cap >= c->nla_stride && (!c->P.gb_rows || c->P.nlg_cap >= c->nlg_stride);
-    if (whole)
+    if (whole) {
       c->rows_disabled = true;
-    else
+    } else {
       c->row_boost *= 2;
+      const int stale = 1;  // (the work items were laid down for the narrower walk: rebuilt with the lists)
+      HIP_TRY(c, hipMemcpy(c->d_nl_flag.p, &stale, sizeof(int), hipMemcpyHostToDevice));
+    }
     wire_args(c);
     c->generation++;
   }

@@ -106,7 +106,7 @@ struct PairArgs {
   int rows_on;             // 1: Born sums and chain rule in row form
   double nl_build2;        // squared list radius: (reach + skin)^2
   double nl_move2;         // (skin / 2)^2: an atom further than this from where it was when the rows were built makes them stale
-  int* nl_flag;            // [0] != 0: the rows are stale for THIS evaluation (k_prep sets, k_outputs clears; 1 on a fresh context)
+  int* nl_flag;            // [0] != 0: the rows are stale for THIS evaluation (k_prep sets, the output side clears and counts the build; 1 on a fresh context)
                            // [1] how often the rows have been built so far (diagnostic)
   double* nl_ref;          // [3n] positions at the last build (NaN on a fresh context)
   const unsigned* hperm;   // [hperm_n] heavy index | screener type << 24, sorted by (type, index), padded with ~0u to whole chunks of 64
@@ -124,6 +124,13 @@ struct PairArgs {
   int* nlg_count;          // [groups x kGbParts]
   int nlg_stride;
   double nlg_build2;       // squared radius of those lists
+  // Work items of the row launches: (list | slice << 24) of every slice that exists, appended when the lists are built, so
+  // that the workgroups with work are the FIRST of a launch and the surplus ones leave on one scalar load (a grid laid out
+  // by slice number is half empty workgroups, and those ahead of a working one delay it by microseconds).  Two buffers per
+  // kind: buffer (builds & 1) is the one in use, the other one is filled by the next rebuild.
+  unsigned* nl_items;      // [3 kinds][2][nl_items_cap]
+  int* nl_nitems;          // [3 kinds][2]
+  int nl_items_cap;
   int nlh_cap, nla_cap, nlg_cap;  // entries of a list that the launches walk (multiples of 256, <= the strides): what the reach
                                   // of the current mode can fill at protein density; a list that outgrows it withholds the
                                   // evaluation and the host widens the walk

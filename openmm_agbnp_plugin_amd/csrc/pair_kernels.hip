@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
       moved = !(fma(rz, rz, fma(ry, ry, rx * rx)) <= P.nl_move2);
     }
     if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&P.nl_flag[0], 1);
+    if (i < 3) P.nl_nitems[2 * i + ((P.nl_flag[1] + 1) & 1)] = 0;  // the work-item buffers that the next rebuild fills
   }
   if (i >= P.n) return;
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
@@ -1512,7 +1513,10 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   }
   const int t = threadIdx.x;
   const int i = blk * 256 + t;
-  if (P.rows_on && i == 0) P.nl_flag[0] = 0;  // this evaluation's neighbour rows are up to date (k_prep of the next one tests again)
+  if (P.rows_on && i == 0) {  // this evaluation's neighbour lists are up to date (k_prep of the next one tests again)
+    if (P.nl_flag[0]) P.nl_flag[1] += 1;  // (builds so far; its parity names the work-item buffers in use)
+    P.nl_flag[0] = 0;
+  }
   if (i >= P.n) return;
   double fx = 0, fy = 0, fz = 0;
   const int h = P.a2h[i];

@@ -183,6 +183,17 @@ __device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
   L.parts = KIND == kBornRows ? kBornParts : KIND == kChainRows ? kChainParts : kGbParts;
   return L;
 }
+// the work items of a freshly built list go into the buffer that the NEXT evaluations use (see PairArgs::nl_items); one lane
+template <int KIND>
+__device__ __forceinline__ void append_items(const PairArgs& P, int sub, int entries, bool at_least_one) {
+  const int nsl = max((entries + kRowSlice - 1) / kRowSlice, at_least_one ? 1 : 0);
+  if (nsl == 0) return;
+  const int buf = (P.nl_flag[1] + 1) & 1;
+  const int base = atomicAdd(&P.nl_nitems[2 * KIND + buf], nsl);
+  unsigned* items = P.nl_items + (size_t)(2 * KIND + buf) * P.nl_items_cap;
+  for (int sl = 0; sl < nsl && base + sl < P.nl_items_cap; sl++) items[base + sl] = (unsigned)sub | ((unsigned)sl << 24);
+}
+
 // one wave builds list `sub` of kind KIND (the lists of the later launches are built in the Born launch: both see the same
 // positions, and an overflowing list is known before the energy is added up)
 template <int KIND>
@@ -200,6 +211,8 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
   if (lane == 0) {
     L.count[sub] = min(cnt, L.stride);
     if (cnt > L.cap) P.status[kStatRowOverflow] = 1;
+    // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
+    append_items<KIND>(P, sub, min(cnt, L.cap), KIND == kGbRows && part == 0);
   }
 }
 
@@ -251,8 +264,27 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   }
   PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 0);
   const int item = blk * WAVES + wave;
-  const int slice = item / lists_pad, li = item - slice * lists_pad;  // (a workgroup's eight items share the slice)
-  const bool active = li < nlists;
+  // Work items.  Normally from the compact list laid down when the lists were built: the launch's first workgroups are the
+  // ones with work, the rest leave here.  The Born rows of a rebuild evaluation build their lists themselves, slice by
+  // slice, and are laid out by slice number for that one evaluation.
+  const bool compact = !(KIND == kBornRows && stale);
+  int slice, li;
+  bool active;
+  if (compact) {
+    const int buf = (P.nl_flag[1] + (stale ? 1 : 0)) & 1;  // (a rebuild evaluation's later launches already walk the new lists)
+    const int nitems = min(P.nl_nitems[2 * KIND + buf], P.nl_items_cap);
+    if (blk * WAVES >= nitems) {
+      if (KIND == kGbRows && lane == 0 && item < P.egb_parts) P.egb_part[item] = 0.0;  // (every partial is summed up)
+      return;
+    }
+    active = item < nitems;
+    const unsigned it = (P.nl_items + (size_t)(2 * KIND + buf) * P.nl_items_cap)[active ? item : 0];
+    li = (int)(it & 0xffffffu);
+    slice = (int)(it >> 24);
+  } else {
+    slice = item / lists_pad, li = item - slice * lists_pad;  // (a workgroup's items share the slice)
+    active = li < nlists;
+  }
   const int sub = active ? li : 0;  // (group, part)
   const int group = sub / NP, part = sub - group * NP;
   const unsigned* list = L.list + (size_t)sub * stride;  // (not restrict: a build rewrites it)
@@ -279,14 +311,16 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   const int tx = threadIdx.x;
   // a workgroup whose eight slices are all beyond the ends of their lists has nothing to do (not known while the lists
   // are being rebuilt); it leaves before it asks for the table: nearly half of the workgroups of a launch are such
-  if (threadIdx.x == 0) s_busy = 0;
-  __syncthreads();
   // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
   const bool mine = active && ((KIND == kBornRows && stale) || first < listed || (KIND == kGbRows && slice == 0 && part == 0));
-  if (mine && lane == 0) s_busy = 1;
   if (KIND == kGbRows && lane == 0 && !mine && item < P.egb_parts) P.egb_part[item] = 0.0;  // (every partial is summed up)
-  __syncthreads();
-  if (!s_busy) return;
+  if (!compact) {  // (laid out by slice number: a workgroup may be empty as a whole)
+    if (threadIdx.x == 0) s_busy = 0;
+    __syncthreads();
+    if (mine && lane == 0) s_busy = 1;
+    __syncthreads();
+    if (!s_busy) return;
+  }
   double2 tv0, tv1, tv2;
   if (KIND != kGbRows) tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
   PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 7, "vmcnt(0) lgkmcnt(0)");
@@ -308,7 +342,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     if (lane == 0 && slice == 0) {
       P.nlh_count[sub] = min(count, stride);
       if (count > L.cap) P.status[kStatRowOverflow] = 1;
-      if (sub == 0) P.nl_flag[1] += 1;  // (builds so far: agbnp_hip_get_scalar)
+      append_items<kBornRows>(P, sub, min(count, L.cap), false);
     }
     if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
       const int a = kRowGroup * group + lane;

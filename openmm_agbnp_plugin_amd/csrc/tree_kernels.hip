@@ -309,7 +309,10 @@ __device__ __forceinline__ void add_force(const TreeOutputs& O, int atom, double
 __device__ __forceinline__ void outputs_role(const TreeArgs& A, int blk, int bs) {
   const TreeOutputs& O = A.out;
   const int i = blk * bs + (int)threadIdx.x;
-  if (O.rows_on && i == 0) O.nl_flag[0] = 0;
+  if (O.rows_on && i == 0) {  // (as k_outputs does)
+    if (O.nl_flag[0]) O.nl_flag[1] += 1;
+    O.nl_flag[0] = 0;
+  }
   if (i >= O.n) return;
   const int h = O.a2h[i];
   double fx = 0.0, fy = 0.0, fz = 0.0;

@@ -46,5 +46,9 @@ for kern, nm in ((0, "k_rows<born>"), (1, "k_rows<gb>"), (2, "k_rows<chain>")):
     print(f"   entries per part: mean {W[:, 6].mean():.0f} max {W[:, 6].max():.0f}; steps mean {steps.mean():.1f}; us per step {np.median(loop / np.maximum(steps, 1)):.3f}")
     end = us(W[:, 3])
     ent = us(W[:, 0])
+    idx = np.flatnonzero(ok)
+    late = ent > 3.0
+    print(f"   late entrants (> 3 us): {int(late.sum())}: block numbers {idx[late][:24].tolist()} of {int(idx.max()) + 1} stamped blocks; "
+          f"working blocks by index range: <260 {int((idx < 260).sum())}, <520 {int((idx < 520).sum())}, <780 {int((idx < 780).sum())}, <1040 {int((idx < 1040).sum())}")
     print(f"   entries: p50 {np.median(ent):.2f} p90 {np.percentile(ent, 90):.2f} p99 {np.percentile(ent, 99):.2f} max {ent.max():.2f}")
     print(f"   ends: p10 {np.percentile(end, 10):.2f} p50 {np.median(end):.2f} p90 {np.percentile(end, 90):.2f} max {end.max():.2f}")
