@@ -59,13 +59,13 @@ ROW_KERNEL_NAMES = {"k_rows<0>": "k_born_rows", "k_rows<1>": "k_dborn_rows", "k_
 def counter_valu_instructions(system_name, mode=None):
     """Vector wave-instructions per launch of every kernel as the SQ counters saw them (SQ_INSTS_VALU of the newest
     profiles/rNN counter summaries, taken on this workload with scripts/profile_round.sh / profile_rows.sh: the default
-    configuration, the reference mode with the row form, the fast mode).  None when there is none."""
+    configuration, the reference mode on the tile kernels, the fast mode).  None when there is none."""
     d = newest_profile_dir()
     if d is None or system_name != "1dwc":
         return None, None
     import csv
     out, used = {}, []
-    files = ["fast_pmc_utilization.csv"] if mode in ("fast", "fast+single") else ["rows_pmc_utilization.csv", "pmc_utilization.csv"]
+    files = ["fast_pmc_utilization.csv"] if mode in ("fast", "fast+single") else ["tiles_pmc_utilization.csv", "pmc_utilization.csv"]
     for name in files:  # (later files win: the default configuration's own counters over the row-form run's)
         path = os.path.join(d, name)
         if not os.path.exists(path):

@@ -14,7 +14,7 @@ for r in csv.DictReader(open(src)):
     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
         "SQ_LDS_BANK_CONFLICT"]
-order = ["k_prep", "k_tree_cavity", "k_born_tiles", "k_gb_tiles", "k_dborn_tiles", "k_tree_pseudo", "k_outputs"]
+order = ["k_prep", "k_tree_cavity", "k_born_tiles", "k_rows<0>", "k_gb_tiles", "k_rows<2>", "k_dborn_tiles", "k_rows<1>", "k_tree_pseudo", "k_outputs"]
 with open(dst, "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["kernel", "launches"] + cols + ["valu_share_of_wave_cycles", "lds_bank_conflict_share"])
