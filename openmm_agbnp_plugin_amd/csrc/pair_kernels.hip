@@ -242,9 +242,11 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   P.gb_fy[i] = 0.0;
   P.gb_fz[i] = 0.0;
   P.born_part[i] = 0.0;  // Born sums and chain-rule sums arrive through atomics too
-  P.db_fx[i] = 0.0;
-  P.db_fy[i] = 0.0;
-  P.db_fz[i] = 0.0;
+  if (!P.rows_on) {      // (the row form assembles the chain-rule force from its G and H sums)
+    P.db_fx[i] = 0.0;
+    P.db_fy[i] = 0.0;
+    P.db_fz[i] = 0.0;
+  }
   P.db_wu[i] = 0.0;
   const int h = P.a2h[i];
   if (h >= 0) {

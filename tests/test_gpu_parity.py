@@ -1071,3 +1071,48 @@ def test_born_rows_at_the_tail_of_the_cavity_launch(gpu_required, systems, monke
         eo, fo = oracle.execute(pos)
         assert_close(e, f, eo, fo)
     assert int(k.scalar("row_builds")) == 2
+
+
+def test_two_contexts_on_two_streams_do_not_stall_or_disturb_each_other(gpu_required, systems):
+    """Multi-walker use: two contexts enqueue on streams of their own; parameters of one are updated (in place, behind a
+    drain of ITS streams only) while evaluations of the other are in flight.  Both end with the oracle's numbers."""
+    torch = pytest.importorskip("torch")
+    sa, sb = systems("trpcage"), systems("fixture264")
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    forces = [P.AGBNPForce.from_arrays(*sa.params(), version=1), P.AGBNPForce.from_arrays(*sb.params(), version=1)]
+    ks = [P.HipCalcAGBNPForceKernel(), P.HipCalcAGBNPForceKernel()]
+    for k, f in zip(ks, forces):
+        k.initialize(f)
+    geoms = [[s.jittered(i) for i in range(6)] for s in (sa, sb)]
+    pos = [torch.tensor(np.stack(g), dtype=torch.float64, device=dev).contiguous() for g in geoms]
+    frc = [torch.zeros((s.n, 3), dtype=torch.float64, device=dev) for s in (sa, sb)]
+    ene = [torch.zeros((1,), dtype=torch.float64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for w in (0, 1):  # settle capacities (the 264-atom fixture needs the second variant)
+        for attempt in range(4):
+            ks[w].execute_device(pos[w][0].data_ptr(), frc[w].data_ptr(), ene[w].data_ptr(), streams[w].cuda_stream)
+            if ks[w].finish(streams[w].cuda_stream) == 0:
+                break
+        frc[w].zero_()
+        ene[w].zero_()
+    torch.cuda.synchronize()
+    # walker 1 keeps evaluating; walker 0 evaluates, changes its charges, evaluates again
+    for i in range(3):
+        ks[1].execute_device(pos[1][i].data_ptr(), frc[1].data_ptr(), ene[1].data_ptr(), streams[1].cuda_stream)
+        ks[0].execute_device(pos[0][i].data_ptr(), frc[0].data_ptr(), ene[0].data_ptr(), streams[0].cuda_stream)
+    r, g, a, q, h = sa.params()
+    q2 = 0.5 * np.asarray(q)
+    f2 = P.AGBNPForce.from_arrays(r, g, a, q2, h, version=1)
+    assert ks[0].finish(streams[0].cuda_stream) == 0
+    ks[0].copyParametersToContext(f2)  # (walker 1's evaluations may still be in flight)
+    for i in range(3, 6):
+        ks[1].execute_device(pos[1][i].data_ptr(), frc[1].data_ptr(), ene[1].data_ptr(), streams[1].cuda_stream)
+        ks[0].execute_device(pos[0][i].data_ptr(), frc[0].data_ptr(), ene[0].data_ptr(), streams[0].cuda_stream)
+    assert ks[0].finish(streams[0].cuda_stream) == 0 and ks[1].finish(streams[1].cuda_stream) == 0
+    oa1, oa2, ob = Oracle(r, g, a, q, h, version=1), Oracle(r, g, a, q2, h, version=1), Oracle(*sb.params(), version=1)
+    want_a = [oa1.execute(geoms[0][i]) for i in range(3)] + [oa2.execute(geoms[0][i]) for i in range(3, 6)]
+    want_b = [ob.execute(geoms[1][i]) for i in range(6)]
+    for w, want in ((0, want_a), (1, want_b)):
+        assert abs(ene[w].item() - sum(x[0] for x in want)) < 6 * TIGHT * 10
+        assert np.abs(frc[w].cpu().numpy() - sum(x[1] for x in want)).max() < 6 * TIGHT
