@@ -576,7 +576,33 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.ncc[tid] = (unsigned short)cq;
   }
   // rank inside the root's candidates by switched volume (descending; exact ties by atom index) and create local
-  // atoms + level-2 nodes
+  // atoms + level-2 nodes.  The rank is a count over all candidates: a chain of LDS round trips, four reads each.  With
+  // up to 64 candidates (the usual forest) every wave counts a share of the list for candidate `lane` and the shares meet
+  // in LDS (the task-start words are idle until the expansion): a third of the trips for one barrier more.
+  constexpr int kWaves = BS / 64;
+  const bool split_rank = kWaves > 1 && ncand <= 64;
+  if (split_rank) {
+    const int c = tid & 63, w = tid >> 6;
+    const int share = (ncand + kWaves - 1) / kWaves, k0 = w * share, k1 = min(ncand, k0 + share);
+    int part = 0;
+    if (c < ncand) {
+      const double my = S.cand_vol[c];
+      const int packed = S.cand_idx[c];
+      const int q = packed >> 24, hj = packed & 0xffffff;
+      auto before = [&](double vk, int ik) {
+        return ((ik >> 24) == q && (vk > my || (vk == my && (ik & 0xffffff) < hj))) ? 1 : 0;
+      };
+      int k = k0;
+      for (; k + 4 <= k1; k += 4) {
+        const double v0 = S.cand_vol[k], v1 = S.cand_vol[k + 1], v2 = S.cand_vol[k + 2], v3 = S.cand_vol[k + 3];
+        const int i0 = S.cand_idx[k], i1 = S.cand_idx[k + 1], i2 = S.cand_idx[k + 2], i3 = S.cand_idx[k + 3];
+        part += (before(v0, i0) + before(v1, i1)) + (before(v2, i2) + before(v3, i3));
+      }
+      for (; k < k1; k++) part += before(S.cand_vol[k], S.cand_idx[k]);
+    }
+    S.tstart[w * 64 + c] = (unsigned short)part;
+    tree_barrier<NCAP>();
+  }
   for (int c = tid; c < ncand; c += BS) {
     const double my = S.cand_vol[c];
     const int packed = S.cand_idx[c];
@@ -587,6 +613,10 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     auto before = [&](double vk, int ik) {  // same root, larger volume; exact tie (incl. itself: never counted): atom index
       return ((ik >> 24) == q && (vk > my || (vk == my && (ik & 0xffffff) < hj))) ? 1 : 0;
     };
+    if (split_rank) {
+      for (int w = 0; w < kWaves; w++) rank += S.tstart[w * 64 + c];
+      k = ncand;
+    }
     for (; k + 4 <= ncand; k += 4) {
       const double v0 = S.cand_vol[k], v1 = S.cand_vol[k + 1], v2 = S.cand_vol[k + 2], v3 = S.cand_vol[k + 3];
       const int i0 = S.cand_idx[k], i1 = S.cand_idx[k + 1], i2 = S.cand_idx[k + 2], i3 = S.cand_idx[k + 3];
