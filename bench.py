@@ -519,6 +519,7 @@ def main():
             result["replicas_per_gpu"] = per_gpu
         if int(kernel.scalar("rows_on")):
             result["neighbour_rows"] = {"builds_so_far": int(kernel.scalar("row_builds")),
+                                        "entries_per_slice": int(kernel.scalar("row_slice")),
                                         "note": "rows built with a skin and rebuilt on the device when an atom has moved more than half of it; "
                                                 "the jittered geometries of this protocol stay within it"}
 

@@ -153,7 +153,8 @@ struct agbnp_hip_context {
   int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
   int* h_status = nullptr;      // pinned, mapped: {evaluations completed, withheld} since the last finish (agbnp_hip_poll)
   std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
-  int last_rows[2] = {0, 0};   // {stale flag, builds so far} of the row-form neighbour rows, as of the last harvest
+  int last_rows[3] = {0, 0, 0};  // {stale flag, builds so far, entries per slice} of the row-form neighbour rows, as of the last harvest
+  int row_slice = 0;           // AGBNP_HIP_ROW_SLICE: entries per slice, fixed (0: tuned on the device, see rows_close_evaluation)
   bool have_results = false;
   bool diagnostics = false;
 
@@ -368,6 +369,7 @@ void wire_args(agbnp_hip_context* c) {
     }
     P.nl_move2 = 0.25 * c->skin * c->skin;
     P.nl_flag = c->d_nl_flag.p;
+    P.row_target = c->row_slice > 0 ? 0 : 2 * c->cus;
     P.nl_ref = c->d_nl_ref.p;
     P.hperm = c->d_hperm.p;
     P.aperm = c->d_aperm.p;
@@ -478,6 +480,7 @@ int allocate_rows(agbnp_hip_context* c) {
   if (c->lut.nscreened > kMaxTypes || c->lut.nscreener > kMaxTypes) return AGBNP_HIP_OK;
   if ((size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1) * 2 * sizeof(double2) > kMaxTableBytes) return AGBNP_HIP_OK;
   if (getenv("AGBNP_HIP_SKIN")) c->skin = std::min(1.0, std::max(0.0, atof(getenv("AGBNP_HIP_SKIN"))));
+  if (getenv("AGBNP_HIP_ROW_SLICE")) c->row_slice = atoi(getenv("AGBNP_HIP_ROW_SLICE"));
   if (getenv("AGBNP_HIP_ROW_FILL")) c->row_fill = std::max(0.01, atof(getenv("AGBNP_HIP_ROW_FILL")));  // (tests: force the walk to widen)
   auto sorted_by_type = [&](int count, auto type_of) {
     std::vector<unsigned> v;
@@ -545,7 +548,8 @@ int allocate_rows(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_nla_count.alloc(chain_lists));
   HIP_TRY(c, hipMemset(c->d_nlh_count.p, 0, sizeof(int) * born_lists));
   HIP_TRY(c, hipMemset(c->d_nla_count.p, 0, sizeof(int) * chain_lists));
-  const std::vector<int> flag = {1, 0};  // stale: the first evaluation builds the rows
+  // {stale: the first evaluation builds the rows; builds so far; entries per slice}
+  const std::vector<int> flag = {1, 0, c->row_slice > 0 ? std::min(std::max(c->row_slice, kRowSlice), kRowSliceMax) / 64 * 64 : kRowSlice, 0};
   HIP_TRY(c, c->d_nl_flag.upload(flag));
   HIP_TRY(c, c->d_nl_ref.alloc(3 * (size_t)n));
   HIP_TRY(c, hipMemset(c->d_nl_ref.p, 0xff, sizeof(double) * 3 * (size_t)n));  // NaN: every atom has "moved"
@@ -750,6 +754,9 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     O.grec = c->P.grec;
     O.hrec = c->P.hrec;
     O.nl_flag = c->P.nl_flag;
+    O.nl_nitems = c->P.nl_nitems;
+    O.row_target = c->P.row_target;
+    O.gb_rows = c->P.gb_rows;
     HIP_TRY(c, launch_tree_pseudo(c->variant, kGlobalGrid, tree_grid, c->T, st));
     if (fused) {
       if (tl) HIP_TRY(c, tl->mark(-1, st));
@@ -804,7 +811,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   tl.used = 0;
   HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
-  if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost));
+  if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost));
   const int* s = c->last_status;
   c->withheld.clear();
@@ -1103,6 +1110,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 8: *value = c->last_status[kStatForests]; break;
     case 9: *value = c->P.rows_on; break;        // 1: the range-limited pair stages run in row form
     case 10: *value = c->last_rows[1]; break;    // builds of the neighbour rows so far
+    case 13: *value = c->last_rows[2]; break;    // entries per slice of a neighbour row (one wave walks a slice)
     case 11: *value = c->last_pack[0]; break;    // forest packing: how far the assumed store capacity is tightened (0 = not)
     case 12: *value = c->last_pack[1]; break;    // ... evaluations since the packing in use was planned
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");

@@ -106,7 +106,8 @@ struct PairArgs {
   int rows_on;             // 1: Born sums and chain rule in row form
   double nl_build2;        // squared list radius: (reach + skin)^2
   double nl_move2;         // (skin / 2)^2: an atom further than this from where it was when the rows were built makes them stale
-  int* nl_flag;            // [0] != 0: the rows are stale for THIS evaluation (k_prep sets, the output side clears and counts the build; 1 on a fresh context)
+  int row_target;          // workgroups of a row launch that the device takes two per CU of (0: the slice length stays); see rows_close_evaluation
+  int* nl_flag;            // [2]: entries per slice of a list (one wave walks a slice), tuned on the device; [0] != 0: the rows are stale for THIS evaluation (k_prep sets, the output side clears and counts the build; 1 on a fresh context)
                            // [1] how often the rows have been built so far (diagnostic)
   double* nl_ref;          // [3n] positions at the last build (NaN on a fresh context)
   const unsigned* hperm;   // [hperm_n] heavy index | screener type << 24, sorted by (type, index), padded with ~0u to whole chunks of 64
@@ -144,6 +145,8 @@ struct PairArgs {
   const double2 *pwt_a, *pwt_b;  // the same by [screener][screened][15]
 };
 constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
+constexpr int kRowSlice = 256, kRowWaves = 8;  // entries of the shortest slice of a list (what the launch grids are laid out for); waves per workgroup
+constexpr int kRowSliceMax = 512;
 constexpr int kChainParts = 4;  // waves (list parts) per group of chain-rule rows
 constexpr int kBornParts = 2;   // ... per group of Born rows
 constexpr int kGbParts = 2;     // ... per group of GB rows (fast mode)

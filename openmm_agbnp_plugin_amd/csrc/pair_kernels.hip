@@ -55,6 +55,16 @@ __device__ unsigned long long g_pair_log[3][kPairLogSlots][12];
       g_pair_log[kern][blockIdx.x][6] = (unsigned)(item);                                                            \
     }                                                                                                                \
   } while (0)
+#define PAIR_STAMP_HW(kern)                                                                                          \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kPairLogSlots) {                                                            \
+      unsigned xcc__ = 0, hw__ = 0;                                                                                  \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__));                                          \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                                            \
+      g_pair_log[kern][blockIdx.x][4] = hw__;                                                                        \
+      g_pair_log[kern][blockIdx.x][5] = xcc__;                                                                       \
+    }                                                                                                                \
+  } while (0)
 #else
 #define PAIR_STAMP(kern, idx)
 #define PAIR_STAMP_WAIT(kern, idx, what)
@@ -1516,8 +1526,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   const int t = threadIdx.x;
   const int i = blk * 256 + t;
   if (P.rows_on && i == 0) {  // this evaluation's neighbour lists are up to date (k_prep of the next one tests again)
-    if (P.nl_flag[0]) P.nl_flag[1] += 1;  // (builds so far; its parity names the work-item buffers in use)
-    P.nl_flag[0] = 0;
+    rows_close_evaluation(P.nl_flag, P.nl_nitems, P.row_target, P.gb_rows != 0);
   }
   if (i >= P.n) return;
   double fx = 0, fy = 0, fz = 0;

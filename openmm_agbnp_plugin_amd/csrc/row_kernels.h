@@ -12,6 +12,9 @@
 #define PAIR_STAMP_WAIT(kern, idx, what)
 #define PAIR_STAMP_WHERE(kern, item)
 #endif
+#ifndef PAIR_STAMP_HW
+#define PAIR_STAMP_HW(kern)
+#endif
 #ifndef ROWS_LOG_COUNTS
 #define ROWS_LOG_COUNTS(kern, todo, nsteps)
 #endif
@@ -165,7 +168,27 @@ __device__ __forceinline__ int row_build(const RowAtoms& A, const unsigned* __re
 // than four steps whatever the length of its list (the launch lasts as long as its slowest wave); item = slice * lists +
 // list, eight consecutive items per workgroup (a workgroup's items are the same slice of eight neighbouring lists: it is
 // empty as a whole, and leaves at once, or not at all).  The sums of a wave leave as one set of FP64 atomics.
-constexpr int kRowSlice = 256, kRowWaves = 8;
+// The slice length in use lives on the device (nl_flag[2]) and only grows.  A launch whose working workgroups are a few
+// more than two per CU is as long as the workgroups on the CUs that hold three (1dwc, 596 workgroups on 256 CUs: lifetimes
+// up to 9.5 us on the CUs with two, up to 12.9 us on those with three); longer slices for a fifth fewer workgroups take
+// that tail away.  The evaluation that has rebuilt the lists looks at the work items it laid down and, if any row launch
+// has between one and two times `row_target` workgroups, asks for one more rebuild with slices of 64 entries more.
+__device__ __forceinline__ int row_slice_length(const PairArgs& P) { return min(max(P.nl_flag[2], kRowSlice), kRowSliceMax); }
+// the last launch of an evaluation (one lane): a rebuild is counted, the lists are good from here on
+__device__ __forceinline__ void rows_close_evaluation(int* nl_flag, const int* nl_nitems, int row_target, bool gb_rows) {
+  if (!nl_flag[0]) return;
+  nl_flag[1] += 1;  // (builds so far; its parity names the work-item buffers in use)
+  nl_flag[0] = 0;
+  if (row_target <= 0) return;
+  const int buf = nl_flag[1] & 1;
+  int items = max(nl_nitems[2 * 0 + buf], nl_nitems[2 * 1 + buf]);  // (Born rows, chain-rule rows)
+  if (gb_rows) items = max(items, nl_nitems[2 * 2 + buf]);
+  const int wgs = (items + kRowWaves - 1) / kRowWaves, rs = nl_flag[2];
+  if (wgs > row_target && wgs <= 2 * row_target && rs < kRowSliceMax) {
+    nl_flag[2] = max(rs, kRowSlice) + 64;
+    nl_flag[0] = 1;
+  }
+}
 
 struct RowLists {  // the lists of one kind
   unsigned* list;
@@ -186,7 +209,8 @@ __device__ __forceinline__ RowLists row_lists(const PairArgs& P) {
 // the work items of a freshly built list go into the buffer that the NEXT evaluations use (see PairArgs::nl_items); one lane
 template <int KIND>
 __device__ __forceinline__ void append_items(const PairArgs& P, int sub, int entries, bool at_least_one) {
-  const int nsl = max((entries + kRowSlice - 1) / kRowSlice, at_least_one ? 1 : 0);
+  const int rs = row_slice_length(P);
+  const int nsl = max((entries + rs - 1) / rs, at_least_one ? 1 : 0);
   if (nsl == 0) return;
   const int buf = (P.nl_flag[1] + 1) & 1;
   const int base = atomicAdd(&P.nl_nitems[2 * KIND + buf], nsl);
@@ -248,9 +272,9 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   const RowLists L = row_lists<KIND>(P);
   const int NP = L.parts, stride = L.stride;
   const int nlists = L.groups * NP, lists_pad = (nlists + WAVES - 1) / WAVES * WAVES;
-  const int slices = (L.cap + kRowSlice - 1) / kRowSlice;
-  const int walk_blocks = lists_pad / WAVES * slices;
   const int stale = P.nl_flag[0];
+  const int rs = row_slice_length(P);
+  const int walk_blocks = lists_pad / WAVES * ((L.cap + kRowSlice - 1) / kRowSlice);  // (as the host lays the grid out)
   if (KIND == kBornRows && blk >= walk_blocks) {
     // The lists of the later launches are built here, in the Born launch, by workgroups that only look at the lists'
     // lengths in an evaluation whose lists are still good.
@@ -277,8 +301,11 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
       if (KIND == kGbRows && lane == 0 && item < P.egb_parts) P.egb_part[item] = 0.0;  // (every partial is summed up)
       return;
     }
+    PAIR_STAMP_HW((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0));
+    PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 10);
     active = item < nitems;
     const unsigned it = (P.nl_items + (size_t)(2 * KIND + buf) * P.nl_items_cap)[active ? item : 0];
+    PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 11, "vmcnt(0)");
     li = (int)(it & 0xffffffu);
     slice = (int)(it >> 24);
   } else {
@@ -288,7 +315,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   const int sub = active ? li : 0;  // (group, part)
   const int group = sub / NP, part = sub - group * NP;
   const unsigned* list = L.list + (size_t)sub * stride;  // (not restrict: a build rewrites it)
-  const int first = kRowSlice * slice;
+  const int first = rs * slice;
   // Everything that does not depend on anything is asked for at once: the length of the list, the first two steps of the
   // slice (the lists start out zeroed: an entry beyond the length is a valid index), the row atoms and their types, the table.
   const int listed = L.count[sub];
@@ -354,7 +381,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
   if (KIND == kBornRows && active && slice == 0 && lane == 0 && count > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
-  const int todo = active ? max(0, min(count - first, kRowSlice)) : 0;  // entries of this slice
+  const int todo = active ? max(0, min(count - first, rs)) : 0;  // entries of this slice
   const int nsteps = (todo + 63) >> 6;
   double acc[4 * R];
 #pragma unroll

@@ -72,6 +72,8 @@ struct TreeOutputs {
   int rows_on;                 // chain-rule force of the row form instead: bw_i G_i + s_i H_i
   const double* bw;            // [n]
   const double4 *grec, *hrec;  // [n], [nh]
+  const int* nl_nitems;        // row form: work items laid down by a rebuild, and what the slice length is tuned against (rows_close_evaluation)
+  int row_target, gb_rows;
   int* nl_flag;                // row form: [0] is cleared (this evaluation's neighbour lists are up to date)
 };
 

@@ -310,8 +310,7 @@ __device__ __forceinline__ void outputs_role(const TreeArgs& A, int blk, int bs)
   const TreeOutputs& O = A.out;
   const int i = blk * bs + (int)threadIdx.x;
   if (O.rows_on && i == 0) {  // (as k_outputs does)
-    if (O.nl_flag[0]) O.nl_flag[1] += 1;
-    O.nl_flag[0] = 0;
+    rows_close_evaluation(O.nl_flag, O.nl_nitems, O.row_target, O.gb_rows != 0);
   }
   if (i >= O.n) return;
   const int h = O.a2h[i];

@@ -3,9 +3,9 @@
 tag=$1; kexpr=$2; shift; shift
 mkdir -p gpurun_out
 if [ -n "$kexpr" ]; then
-  timeout -k 10 700 python -m pytest tests -m gpu -x -q -k "$kexpr" > gpurun_out/${tag}_pytest.log 2>&1
+  timeout -k 10 700 python -m pytest tests -m gpu -q -k "$kexpr" > gpurun_out/${tag}_pytest.log 2>&1
 else
-  timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1
+  timeout -k 10 700 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1
 fi
 rc=$?
 tail -12 gpurun_out/${tag}_pytest.log

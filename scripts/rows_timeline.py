@@ -41,6 +41,23 @@ for kern, nm in ((0, "k_rows<born>"), (1, "k_rows<gb>"), (2, "k_rows<chain>")):
     for pn, v in phases:
         v = v / 100.0
         print(f"   {pn:28s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
+    for pn, v in (("  entry -> item count (scalar)", W[:, 10] - W[:, 0]), ("  -> item word", W[:, 11] - W[:, 10]), ("  -> atoms, lists, table", W[:, 7] - W[:, 11])):
+        v = v / 100.0
+        print(f"   {pn:28s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
+    hw = W[:, 4].astype(np.int64); xcc = (W[:, 5].astype(np.int64)) & 15
+    cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    life = (W[:, 3] - W[:, 0]) / 100.0
+    pro = (W[:, 8] - W[:, 0]) / 100.0
+    uniq, inv, cnt = np.unique(cuid, return_inverse=True, return_counts=True)
+    per = cnt[inv]
+    print(f"   CUs used {len(uniq)}; workgroups per CU: " + ", ".join(f"{k}: {int((cnt == k).sum())} CUs" for k in sorted(set(cnt))))
+    for k in sorted(set(cnt)):
+        print(f"     workgroups on CUs that hold {k}: lifetime mean {life[per == k].mean():.2f} max {life[per == k].max():.2f}; prologue mean {pro[per == k].mean():.2f} max {pro[per == k].max():.2f}")
+    for x in range(8):
+        sel = xcc == x
+        if sel.any():
+            print(f"     XCD {x}: {int(sel.sum())} workgroups, lifetime mean {life[sel].mean():.2f} p90 {np.percentile(life[sel], 90):.2f} max {life[sel].max():.2f}; prologue mean {pro[sel].mean():.2f}; last end {us(W[sel, 3]).max():.2f}")
     steps = W[:, 9]
     loop = (W[:, 2] - W[:, 1]) / 100.0
     print(f"   entries per part: mean {W[:, 6].mean():.0f} max {W[:, 6].max():.0f}; steps mean {steps.mean():.1f}; us per step {np.median(loop / np.maximum(steps, 1)):.3f}")

@@ -848,6 +848,7 @@ def test_neighbour_rows_follow_moving_atoms(gpu_required, systems, monkeypatch):
     the oracle at every step, and the rows must have been rebuilt when -- and only when -- an atom had moved too far."""
     s = systems("1dwc")
     monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_ROW_SLICE", "256")  # (a fixed slice length: no extra build while it is being tuned)
     k = P.HipCalcAGBNPForceKernel()
     k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
     oracle = Oracle(*s.params(), version=1)
@@ -1053,12 +1054,57 @@ def test_neighbour_list_walk_widens_on_demand(gpu_required, systems, monkeypatch
     assert k.scalar("rows_on") == 1
 
 
+def test_slice_length_of_the_neighbour_rows_is_tuned_on_the_device(gpu_required, systems, monkeypatch):
+    """A wave of a row launch walks one slice of a list.  When the working workgroups of a launch are a few more than two
+    per CU (1dwc with slices of 256 entries: ~600 on 256 CUs) the evaluation that has built the lists asks for one more
+    build with longer slices: same numbers whatever the slice length, one extra build per step of 64 entries, and a
+    small system (whose launches are far from filling the device) or a fixed AGBNP_HIP_ROW_SLICE is left alone."""
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    s = systems("1dwc")
+    oracle = Oracle(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    for step in range(4):
+        pos = s.jittered(step)
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+    tuned = int(k.scalar("row_slice"))
+    assert 256 < tuned <= 512 and tuned % 64 == 0
+    assert int(k.scalar("row_builds")) == 1 + (tuned - 256) // 64
+    for fixed in (256, 448):
+        monkeypatch.setenv("AGBNP_HIP_ROW_SLICE", str(fixed))
+        k2 = P.HipCalcAGBNPForceKernel()
+        k2.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+        for step in range(3):
+            pos = s.jittered(step)
+            f = np.zeros((s.n, 3))
+            e = k2.execute(pos, f)
+            eo, fo = oracle.execute(pos)
+            assert_close(e, f, eo, fo)
+        assert int(k2.scalar("row_slice")) == fixed and int(k2.scalar("row_builds")) == 1
+    monkeypatch.delenv("AGBNP_HIP_ROW_SLICE")
+    t = systems("trpcage")
+    k3 = P.HipCalcAGBNPForceKernel()
+    k3.initialize(P.AGBNPForce.from_arrays(*t.params(), version=1))
+    to = Oracle(*t.params(), version=1)
+    for step in range(3):
+        pos = t.jittered(step)
+        f = np.zeros((t.n, 3))
+        e = k3.execute(pos, f)
+        eo, fo = to.execute(pos)
+        assert_close(e, f, eo, fo)
+    assert int(k3.scalar("row_slice")) == 256 and int(k3.scalar("row_builds")) == 1
+
+
 def test_born_rows_at_the_tail_of_the_cavity_launch(gpu_required, systems, monkeypatch):
     """AGBNP_HIP_BORN_TAIL=1 (experiment, off by default): the Born rows ride in the cavity launch behind the forest
     workgroups and wait on a device-scope counter of finished tree workgroups.  Same numbers, lists rebuilt when atoms move."""
     s = systems("1dwc")
     monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
     monkeypatch.setenv("AGBNP_HIP_BORN_TAIL", "1")
+    monkeypatch.setenv("AGBNP_HIP_ROW_SLICE", "320")  # (fixed: every build below is one that moving atoms asked for)
     k = P.HipCalcAGBNPForceKernel()
     k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
     oracle = Oracle(*s.params(), version=1)
