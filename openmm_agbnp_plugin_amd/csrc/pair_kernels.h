@@ -146,6 +146,14 @@ struct PairArgs {
 };
 constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
 constexpr int kRowSlice = 256, kRowWaves = 8;  // entries of the shortest slice of a list (what the launch grids are laid out for); waves per workgroup
+// The GB rows keep no table in LDS, so their workgroups can be small: the launch (fast mode, 1dwc: 2840 one-wave items) is
+// bound by the vector-memory pipe of the fullest CU (three gathers per step), and four-wave workgroups spread the waves more
+// evenly over the CUs than eight-wave ones (8 or 12 waves on a CU instead of 8 or 16).
+#ifndef AGBNP_GB_ROW_WAVES
+#define AGBNP_GB_ROW_WAVES 4
+#endif
+constexpr int kGbRowWaves = AGBNP_GB_ROW_WAVES;
+constexpr int row_waves(int kind) { return kind == 2 ? kGbRowWaves : kRowWaves; }  // (kind: RowKind)
 constexpr int kRowSliceMax = 512;
 constexpr int kChainParts = 4;  // waves (list parts) per group of chain-rule rows
 constexpr int kBornParts = 2;   // ... per group of Born rows

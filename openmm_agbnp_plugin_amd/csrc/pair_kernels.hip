@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
 // (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers; the GB rows, whose pair terms and
 // bookkeeping role need more, four)
 template <int KIND>
-__global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
+__global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
   extern __shared__ double2 s_dyn[];
 
   int blk = blockIdx.x;
@@ -1491,6 +1491,7 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
   }
   if (KIND == kGbRows) {  // the GB launch carries the first half of the bookkeeping (see k_gb_tiles)
     if (blk == 0) {
+      static_assert(kGbRowWaves >= 4, "the bookkeeping role is written for 256 lanes");
       if (threadIdx.x >= 256) return;
       PAIR_STAMP(1, 0);
       packing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(64 * kRowWaves, KIND == kGbRows ? 4 : 6) void k_row
     blk -= 1;
   }
   __shared__ int s_busy;
-  rows_workgroup<KIND, kRowWaves, false>(P, blk, s_dyn, &s_busy, 0);
+  rows_workgroup<KIND, row_waves(KIND), false>(P, blk, s_dyn, &s_busy, 0);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1612,7 +1613,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
     auto walk_blocks = [](int lists, int cap) { return (lists + kRowWaves - 1) / kRowWaves * ((cap + kRowSlice - 1) / kRowSlice); };
     const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_cap), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_cap);
-    const int gb_blocks = walk_blocks(born_groups * kGbParts, P.nlg_cap);
+    const int gb_blocks = (born_groups * kGbParts + kGbRowWaves - 1) / kGbRowWaves * ((P.nlg_cap + kRowSlice - 1) / kRowSlice);
     // the lists of the later launches are built in the Born launch
     const int build_blocks = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kRowWaves - 1) / kRowWaves;
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
@@ -1624,7 +1625,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     }
     if (P.gb_rows) {
       AGBNP_MARK(kKGbRows);
-      hipLaunchKernelGGL(k_rows<kGbRows>, dim3(1 + gb_blocks), dim3(64 * kRowWaves), sizeof(StripSums), st, P, (double*)nullptr, (double*)nullptr, (int)sizeof(StripSums));
+      hipLaunchKernelGGL(k_rows<kGbRows>, dim3(1 + gb_blocks), dim3(64 * kGbRowWaves), sizeof(StripSums), st, P, (double*)nullptr, (double*)nullptr, (int)sizeof(StripSums));
     } else {
       AGBNP_MARK(kKGbTiles);
       hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,

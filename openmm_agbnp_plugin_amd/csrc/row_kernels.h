@@ -182,7 +182,7 @@ __device__ __forceinline__ void rows_close_evaluation(int* nl_flag, const int* n
   if (row_target <= 0) return;
   const int buf = nl_flag[1] & 1;
   int items = max(nl_nitems[2 * 0 + buf], nl_nitems[2 * 1 + buf]);  // (Born rows, chain-rule rows)
-  if (gb_rows) items = max(items, nl_nitems[2 * 2 + buf]);
+  (void)gb_rows;  // (the GB rows' workgroups are small and their launch holds fewer waves than the device: left alone)
   const int wgs = (items + kRowWaves - 1) / kRowWaves, rs = nl_flag[2];
   if (wgs > row_target && wgs <= 2 * row_target && rs < kRowSliceMax) {
     nl_flag[2] = max(rs, kRowSlice) + 64;
