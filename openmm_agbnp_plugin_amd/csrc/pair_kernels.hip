@@ -809,6 +809,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   }
   __syncthreads();
   PAIR_STAMP(1, 1);
+  __builtin_amdgcn_s_setprio(0);  // (the walk: see k_gb_tiles)
   const int start = 16 * wave;  // the four waves take a quarter of the cyclic distances each
   const double2 axy = s_i[lane], azq = s_i[64 + lane], abc = s_i[128 + lane];
   const double2 cxy = s_i[192 + lane], czq = s_i[256 + lane], cbc = s_i[320 + lane];
@@ -859,6 +860,7 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
     yj = rot1(yj + (yta + ytc));
   }
   const double kf = -2.0 * kDielFactor;
+  __builtin_amdgcn_s_setprio(3);
   __syncthreads();  // every wave is done with the records
   PAIR_STAMP(1, 2);
   StripSums& S = *reinterpret_cast<StripSums*>(s_area);
@@ -1046,6 +1048,10 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   double2* const s_izq = s_ixy + 64;
   double2* const s_ibc = s_izq + 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // A workgroup's prologue and epilogue are a few instructions between memory round trips, its walk a few thousand
+  // instructions without one: the former run at high priority, so that a workgroup that arrives beside three that are
+  // walking gets its loads out at once instead of when the SIMD has nothing else to do (when it is too late to hide them).
+  __builtin_amdgcn_s_setprio(3);
   const int item = items[blockIdx.x - 1];
   const int I = item & 0xfff, J = (item >> 12) & 0xfff;
   PAIR_STAMP(1, 0);
@@ -1108,6 +1114,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   }
   __syncthreads();
   PAIR_STAMP(1, 1);
+  __builtin_amdgcn_s_setprio(0);
   // the four waves take a quarter of the cyclic distances each (diagonal tile: distances 1..32, 8 per wave)
   const int nsteps = diag ? 8 : 16;
   const int start = (diag ? 1 : 0) + nsteps * wave;  // cyclic offset of the first j met by lane l
@@ -1153,6 +1160,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
     yj_acc = rot1(yj_acc);
   }
   const double kf = -2.0 * kDielFactor;
+  __builtin_amdgcn_s_setprio(3);
   __syncthreads();  // every wave is done with the records
   PAIR_STAMP(1, 2);
   TileSums& s_sums = *reinterpret_cast<TileSums*>(s_area);
