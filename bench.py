@@ -276,9 +276,11 @@ def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_
 
 def openmm_entry(torch, name, device, dev_index, steps, warmup):
     """ms per evaluation through agbnp_hip_execute_openmm (an OpenMM GPU context's conventions: posq in the context's atom
-    order + atomIndex, fixed-point force planes, energy buffer) under the three host protocols of the glue: a blocking
-    finish() after every evaluation (strict, the reference's own protocol), a non-blocking poll() after every evaluation
-    (finish only on demand), and a finish every 64 evaluations."""
+    order + atomIndex, fixed-point force planes, energy buffer) under the host protocols of the glue: a blocking finish()
+    after every evaluation (the reference's own protocol: the stream is drained), wait_verdict() after every evaluation
+    (as strict -- the host learns whether THIS evaluation was withheld before it goes on -- but it waits for a pinned word
+    the device writes when the tree stage has ended, not for the stream), a non-blocking poll() after every evaluation
+    (finish only on demand; a withheld evaluation is found late), and a finish every 64 evaluations."""
     system = load_workload(name)
     n = system.n
     padded = (n + 31) // 32 * 32
@@ -307,6 +309,7 @@ def openmm_entry(torch, name, device, dev_index, steps, warmup):
     kernel.finish(stream)
     out = {"workload": name, "entry_point": "agbnp_hip_execute_openmm (double precision context, shuffled atom order)"}
     for label, after in (("finish_every_evaluation", lambda k: kernel.finish(stream)),
+                         ("wait_verdict_every_evaluation", lambda k: kernel.wait_verdict()[1] and kernel.finish(stream)),
                          ("poll_every_evaluation", lambda k: kernel.poll()[1] and kernel.finish(stream)),
                          ("finish_every_64", lambda k: (k % 64 == 63) and kernel.finish(stream))):
         torch.cuda.synchronize()

@@ -26,7 +26,8 @@ enum agbnp_hip_status {
   AGBNP_HIP_ERR_INVALID_ARGUMENT = 1, /* bad sizes / null pointers / illegal version                */
   AGBNP_HIP_ERR_PARAMETERS = 2,       /* the reference would throw OpenMMException for these params  */
   AGBNP_HIP_ERR_DEVICE = 3,           /* a HIP runtime call failed or no gfx950 device is available  */
-  AGBNP_HIP_ERR_CAPACITY = 4          /* an overlap subtree exceeded the largest supported capacity  */
+  AGBNP_HIP_ERR_CAPACITY = 4,         /* an overlap subtree exceeded the largest supported capacity  */
+  AGBNP_HIP_ERR_TIMEOUT = 5           /* agbnp_hip_wait_verdict: the device has not got that far yet */
 };
 
 /* nonbonded methods, values of AGBNPForce::NonbondedMethod (openmmapi/include/AGBNPForce.h:44-59) */
@@ -110,6 +111,21 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, i
  * log names at most 2048 evaluations).  What it learns is at least one evaluation old.  The reference's GPU platform does a
  * blocking read every step instead (OpenCLAGBNPKernels.cpp:3599-3634).  AGBNP_HIP_ERR_DEVICE: no pinned memory. */
 int agbnp_hip_poll(const agbnp_hip_context* ctx, int* evaluations_completed, int* withheld);
+
+/* The strict per-step check without draining the stream.  Blocks the calling HOST thread (no device call, nothing is
+ * synchronised) until the device has delivered its verdict on `evaluations` evaluations since the last agbnp_hip_finish()
+ * (0 or less: on every evaluation enqueued through this library's entry points since then; a caller that replays captured
+ * graphs passes its own count) or `timeout_seconds` have passed, by watching the pinned status words of agbnp_hip_poll().
+ * An evaluation's verdict -- complete, or withheld because a tree outgrew its store -- is final when its tree stage has
+ * ended, about three quarters into the evaluation, and is written there; the forces follow on the stream, gated on the
+ * device by the same words.  So *withheld == 0 on return means every one of those evaluations WILL add its forces and
+ * energy, in stream order, and the caller may go on enqueuing work behind them; *withheld != 0 means what it means
+ * after agbnp_hip_finish(): call it, then repeat.  This is the reference GPU platform's protocol (a blocking read of the
+ * overflow flag in every step, OpenCLAGBNPKernels.cpp:3599-3634) with the same guarantee and without its pipeline drain:
+ * the host waits for a word, not for the stream.  AGBNP_HIP_ERR_TIMEOUT: not there yet (the outputs are valid as far as
+ * they go); AGBNP_HIP_ERR_DEVICE: no pinned memory. */
+int agbnp_hip_wait_verdict(const agbnp_hip_context* ctx, int evaluations, double timeout_seconds, int* evaluations_completed,
+                           int* withheld);
 
 /* Changes whenever kernel arguments that a captured HIP graph of agbnp_hip_execute_device has frozen go stale:
  * after a finish() that raised the capacity variant or grew the scratch pools.  A caller that replays a graph

@@ -232,6 +232,20 @@ class HipCalcAGBNPForceKernel:
             raise OpenMMException("agbnp_hip_poll: no pinned status memory")
         return int(done.value), int(bad.value)
 
+    def wait_verdict(self, evaluations=0, timeout=10.0):
+        """The strict per-evaluation check without draining the stream: blocks this thread (no device call) until the device
+        has delivered its verdict on every evaluation enqueued since the last finish() (or on `evaluations` of them) and
+        returns (evaluations judged, how many were withheld).  The verdict of an evaluation is final when its tree stage
+        has ended; its forces follow on the stream, gated on the device by the same words.  Raises on a timeout."""
+        self._need()
+        done, bad = C.c_int(0), C.c_int(0)
+        rc = _lib.load().agbnp_hip_wait_verdict(self._h, int(evaluations), float(timeout), C.byref(done), C.byref(bad))
+        if rc == _lib.ERR_TIMEOUT:
+            raise OpenMMException(f"agbnp_hip_wait_verdict: timed out after {timeout} s with {int(done.value)} evaluation(s) judged")
+        if rc != _lib.OK:
+            raise OpenMMException("agbnp_hip_wait_verdict: no pinned status memory")
+        return int(done.value), int(bad.value)
+
     def withheld(self):
         """Indices (enqueue order since the finish() before the last one) of the evaluations the last finish()
         reported as withheld."""

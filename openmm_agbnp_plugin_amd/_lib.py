@@ -8,12 +8,12 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AGBNP_HIP_LIBRARY") or os.path.join(_HERE, "libagbnp_hip.so")  # override: diagnostic builds only
 
-OK, ERR_INVALID_ARGUMENT, ERR_PARAMETERS, ERR_DEVICE, ERR_CAPACITY = 0, 1, 2, 3, 4
+OK, ERR_INVALID_ARGUMENT, ERR_PARAMETERS, ERR_DEVICE, ERR_CAPACITY, ERR_TIMEOUT = 0, 1, 2, 3, 4, 5
 
 # every symbol include/agbnp_hip.h declares
 SYMBOLS = [
     "agbnp_hip_create", "agbnp_hip_update_parameters", "agbnp_hip_execute_host", "agbnp_hip_execute_device",
-    "agbnp_hip_execute_openmm", "agbnp_hip_finish", "agbnp_hip_poll", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
+    "agbnp_hip_execute_openmm", "agbnp_hip_finish", "agbnp_hip_poll", "agbnp_hip_wait_verdict", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
     "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
     "agbnp_hip_set_mode", "agbnp_hip_get_mode", "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
@@ -59,6 +59,7 @@ def load():
     lib.agbnp_hip_execute_openmm.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]
     lib.agbnp_hip_finish.argtypes = [vp, vp, ip]
     lib.agbnp_hip_poll.argtypes = [vp, ip, ip]
+    lib.agbnp_hip_wait_verdict.argtypes = [vp, C.c_int, C.c_double, ip, ip]
     lib.agbnp_hip_withheld_evaluations.argtypes = [vp, ip, C.c_int]
     lib.agbnp_hip_generation.argtypes = [vp]
     lib.agbnp_hip_generation.restype = C.c_uint

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +151,7 @@ struct agbnp_hip_context {
   std::vector<int> carried;     // withheld evaluations of execute_device harvested by an execute_host call in between (see there)
   int carried_count = 0, carried_seq = 0;
   bool unfinished = false;      // evaluations enqueued by execute_device / execute_openmm since the last finish
+  int enqueued = 0;             // ... how many: what agbnp_hip_wait_verdict waits for (the device numbers them the same way)
   int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
   int* h_status = nullptr;      // pinned, mapped: {evaluations completed, withheld} since the last finish (agbnp_hip_poll)
   std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
@@ -709,6 +711,7 @@ int allocate_work(agbnp_hip_context* c) {
 int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* d_energy, hipStream_t st) {
   int rc = ensure_scratch(c);
   if (rc != AGBNP_HIP_OK) return rc;
+  c->enqueued++;
   c->P.pos = d_pos;
   c->P.tree_node_cap = tree_variant_node_cap(c->variant);  // the packing of the next evaluation is sized for the variant in use
   c->P.tree_atom_cap = tree_variant_atom_cap(c->variant);
@@ -821,6 +824,7 @@ int harvest(agbnp_hip_context* c, int* repeat) {
   if (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0)  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
   if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
+  c->enqueued = 0;  // (the device's running number starts over with the log)
   if (c->withheld_count == 0) return AGBNP_HIP_OK;
   for (int k = 0; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
     if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k);
@@ -1269,6 +1273,22 @@ int agbnp_hip_poll(const agbnp_hip_context* c, int* evaluations_completed, int* 
   if (evaluations_completed) *evaluations_completed = done;
   if (withheld) *withheld = h[1];
   return AGBNP_HIP_OK;
+}
+
+int agbnp_hip_wait_verdict(const agbnp_hip_context* c, int evaluations, double timeout_seconds, int* evaluations_completed, int* withheld) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (!c->h_status) return AGBNP_HIP_ERR_DEVICE;
+  const int target = evaluations > 0 ? evaluations : c->enqueued;
+  const volatile int* h = c->h_status;
+  const auto t0 = std::chrono::steady_clock::now();
+  int done = h[0];
+  for (unsigned spins = 0; done < target; done = h[0]) {
+    __builtin_ia32_pause();
+    if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) break;
+  }
+  if (evaluations_completed) *evaluations_completed = done;
+  if (withheld) *withheld = h[1];  // (written before the running number, behind a system-scope fence)
+  return done >= target ? AGBNP_HIP_OK : AGBNP_HIP_ERR_TIMEOUT;
 }
 
 // ---- diagnostic entry points (not part of include/agbnp_hip.h; used by scripts/ only) ---------------------------------

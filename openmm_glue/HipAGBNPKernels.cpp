@@ -50,18 +50,30 @@ class HipAGBNPKernelFactory : public KernelFactory {
 
 HipCalcAGBNPForceKernel::HipCalcAGBNPForceKernel(std::string name, const Platform& platform, HipContext& cu)
     : CalcAGBNPForceKernel(name, platform), cu(cu), engine(nullptr), checkInterval(1), sinceCheck(0) {
-  if (const char* env = getenv("AGBNP_HIP_CHECK_MODE")) setPollMode(std::string(env) == "poll");
+  if (const char* env = getenv("AGBNP_HIP_CHECK_MODE")) {
+    setPollMode(std::string(env) == "poll");
+    setVerdictMode(std::string(env) == "verdict");  // ("finish": the reference's own protocol)
+  }
   if (const char* env = getenv("AGBNP_HIP_CHECK_INTERVAL")) setCheckInterval(atoi(env));
+}
+
+void HipCalcAGBNPForceKernel::setVerdictMode(bool on) {
+  verdictMode = on;
+  if (on) pollMode = false;
 }
 
 void HipCalcAGBNPForceKernel::setPollMode(bool on) {
   pollMode = on;
+  if (on) verdictMode = false;
   if (on && checkInterval == 1) checkInterval = 1024;  // the full check only bounds the log in this mode
 }
 
 HipCalcAGBNPForceKernel::~HipCalcAGBNPForceKernel() { agbnp_hip_destroy(engine); }
 
-void HipCalcAGBNPForceKernel::setCheckInterval(int evaluations) { checkInterval = evaluations < 1 ? 1 : evaluations; }
+void HipCalcAGBNPForceKernel::setCheckInterval(int evaluations) {
+  checkInterval = evaluations < 1 ? 1 : evaluations;
+  if (checkInterval > 1) verdictMode = false;  // (an interval only means something for the blocking check)
+}
 
 void HipCalcAGBNPForceKernel::initialize(const System& system, const AGBNPForce& force) {
   if (force.getNumParticles() != system.getNumParticles())
@@ -78,6 +90,7 @@ void HipCalcAGBNPForceKernel::initialize(const System& system, const AGBNPForce&
     throw OpenMMException(agbnp_hip_last_error(nullptr));
   strictLeft = 8;
   sinceCheck = 0;
+  sinceFinish = 0;
 }
 
 void HipCalcAGBNPForceKernel::enqueue() {
@@ -95,8 +108,17 @@ double HipCalcAGBNPForceKernel::execute(ContextImpl& context, bool includeForces
   if (!engine) throw OpenMMException("HipCalcAGBNPForceKernel: initialize() has not been called");
   // both are always computed, as in the reference (ReferenceAGBNPKernels.cpp:139-149 ignores the two flags)
   enqueue();
+  if (verdictMode) {
+    // the host waits for the device's word on this evaluation, not for the stream; the blocking path below is only taken
+    // for a withheld evaluation (repeat it, as the reference does), without pinned memory, and once in 1024 evaluations
+    int done = 0, bad = 0;
+    const int rc = agbnp_hip_wait_verdict(engine, 0, 10.0, &done, &bad);
+    if (rc == AGBNP_HIP_OK && bad == 0 && ++sinceFinish < 1024) return 0.0;
+    sinceFinish = 0;
+    sinceCheck = 0;  // (the blocking check below judges exactly this evaluation)
+  }
   ++sinceCheck;
-  bool check = sinceCheck >= checkInterval;
+  bool check = sinceCheck >= checkInterval || verdictMode;
   if (pollMode && strictLeft > 0) {
     strictLeft--;
     check = true;

@@ -20,20 +20,26 @@ class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
   double execute(OpenMM::ContextImpl& context, bool includeForces, bool includeEnergy) override;
   void copyParametersToContext(OpenMM::ContextImpl& context, const AGBNPForce& force) override;
 
-  // How often execute() synchronises to read the engine's overflow log.  1 (default) = every evaluation, the protocol of
-  // the reference's OpenCL platform (a blocking PanicButton read per step, OpenCLAGBNPKernels.cpp:3599-3634): an
-  // evaluation whose trees outgrew their store is repeated before execute() returns.  k > 1 = every k-th evaluation:
-  // no host synchronisation in between; a withheld evaluation found then cannot be repeated in place (the integrator has
-  // moved on), so execute() throws.  Environment variable AGBNP_HIP_CHECK_INTERVAL overrides the default.
+  // How execute() learns whether the evaluation it has just enqueued was withheld (a tree outgrew its store).
+  // Default: the VERDICT protocol.  execute() waits -- on the host, for a word in pinned memory, not for the stream -- until
+  // the device has judged THIS evaluation (agbnp_hip_wait_verdict: the verdict is final when the tree stage has ended, three
+  // quarters into the evaluation; the forces follow on the stream, gated on the device by the same words).  A withheld
+  // evaluation is repeated before execute() returns, exactly as under the reference's protocol (a blocking PanicButton read
+  // per step, OpenCLAGBNPKernels.cpp:3599-3634), but the stream is never drained in the steady state.
+  // AGBNP_HIP_CHECK_MODE=finish restores the reference's own protocol (agbnp_hip_finish after every evaluation: stream
+  // synchronisation + two device reads per step).
+  // Check interval k > 1 (setCheckInterval / AGBNP_HIP_CHECK_INTERVAL; finish mode): a blocking check every k-th evaluation
+  // only; a withheld evaluation found then cannot be repeated in place (the integrator has moved on), so execute() throws.
   void setCheckInterval(int evaluations);
+  void setVerdictMode(bool on);
   // Poll mode (AGBNP_HIP_CHECK_MODE=poll): execute() never synchronises in the steady state.  After every enqueue it looks
   // at the engine's pinned status words (agbnp_hip_poll: no device call) and only calls the blocking agbnp_hip_finish()
   // when they report a withheld evaluation (or every 1024 evaluations, to keep the log bounded).  What the poll sees is at
   // least one evaluation old, so a withheld evaluation is found AFTER the integrator has used the step's forces without
   // the AGBNP term: the engine adapts at once (capacity / packing), the step is counted in getLateWithheld() and reported
   // on stderr once.  The first eight evaluations of a context, and the eight after every adaptation, are checked the
-  // strict way (the capacity negotiation of a new system happens there).  The default stays the strict protocol above
-  // (exact, one synchronisation per step).
+  // strict way (the capacity negotiation of a new system happens there).  Not the default: the verdict protocol above is
+  // exact and costs about as little.
   void setPollMode(bool on);
   int getLateWithheld() const { return lateWithheld; }
   agbnp_hip_context* getEngine() { return engine; }
@@ -44,6 +50,8 @@ class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
   agbnp_hip_context* engine;
   int checkInterval, sinceCheck;
   bool pollMode = false;
+  bool verdictMode = true;
+  int sinceFinish = 0;  // verdict mode: evaluations since the last agbnp_hip_finish (one every 1024 keeps the device's log bounded)
   int lateWithheld = 0;
   int strictLeft = 0;  // poll mode: evaluations that are still checked the strict way (a fresh context, or one that has just adapted)
 };

@@ -1014,6 +1014,40 @@ def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
     assert k.poll() == (0, 0)
 
 
+def test_wait_verdict_judges_every_evaluation_without_draining_the_stream(gpu_required, systems):
+    """agbnp_hip_wait_verdict blocks the HOST until the device has written its verdict on every evaluation enqueued since
+    the last finish() -- no synchronisation call of ours in between -- and says how many were withheld: the strict
+    per-step check of the reference's GPU platform (OpenCLAGBNPKernels.cpp:3599-3634) without its pipeline drain.  What a
+    clean verdict promises is checked afterwards: the buffers hold the sum of the complete evaluations."""
+    torch = pytest.importorskip("torch")
+    from oracle import Oracle
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    geoms = [s.pos, s.jittered(1), centre + 0.85 * (s.pos - centre)]
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert k.wait_verdict() == (0, 0)  # nothing enqueued: nothing to wait for
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.wait_verdict() == (1, 0)
+    k.execute_device(pos[1].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.wait_verdict() == (2, 0)
+    k.execute_device(pos[2].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # outgrows the smallest capacity variant
+    assert k.wait_verdict() == (3, 1)
+    with pytest.raises(P.OpenMMException):  # a count the device will not reach: times out, says how far it got
+        k.wait_verdict(evaluations=5, timeout=0.05)
+    assert k.finish(stream) == 1 and k.withheld() == [2]
+    assert k.wait_verdict() == (0, 0)
+    o = Oracle(*s.params(), version=1)
+    (e0, f0), (e1, f1) = o.execute(geoms[0]), o.execute(geoms[1])
+    assert_close(float(ene.cpu()[0]), frc.cpu().numpy(), e0 + e1, f0 + f1)
+
+
 @pytest.mark.parametrize("name,cutoff", [("2clr", 1.0), ("1dwc_x4", 1.2)])
 def test_fast_mode_rows_on_larger_systems(gpu_required, systems, name, cutoff):
     """Fast mode runs all three pair stages in row form (neighbour lists within cutoff + skin, no pair beyond the cutoff is

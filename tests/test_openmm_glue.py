@@ -76,6 +76,20 @@ def test_plugin_path_reproduces_the_reference_known_answers(gpu_required, tmp_pa
 
 
 @pytest.mark.gpu
+def test_plugin_path_with_the_reference_blocking_check(gpu_required, tmp_path):
+    """AGBNP_HIP_CHECK_MODE=finish: the reference's own protocol (stream synchronisation and a read of the overflow log after
+    every evaluation) instead of the default wait for the device's verdict word; same numbers."""
+    from tests.pins import REFERENCE_PRINTED
+    exe = build_test_program(tmp_path)
+    data = open(os.path.join(ROOT, "openmm_agbnp_plugin_amd", "data", "fixture264.dat")).read()
+    env = dict(os.environ, AGBNP_HIP_CHECK_MODE="finish")
+    out = subprocess.run([exe, "1", "double"], input=data, text=True, capture_output=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.split("\n")[0] == f"Energy: {REFERENCE_PRINTED[1]['energy']:g}"
+    assert "PASS" in out.stdout
+
+
+@pytest.mark.gpu
 def test_plugin_path_in_poll_mode(gpu_required, tmp_path):
     """AGBNP_HIP_CHECK_MODE=poll: execute() looks at the engine's pinned status words instead of synchronising the stream
     every step; the numbers of a healthy run are the strict mode's."""
