@@ -154,6 +154,20 @@ struct agbnp_hip_context {
   int enqueued = 0;             // ... how many: what agbnp_hip_wait_verdict waits for (the device numbers them the same way)
   int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
   int* h_status = nullptr;      // pinned, mapped: {evaluations completed, withheld} since the last finish (agbnp_hip_poll)
+  // pinned staging of the host-facing paths: what harvest() reads of the device arrives by asynchronous copies in front of
+  // ONE stream synchronisation (four blocking reads before); execute_host's positions, forces and energy travel through
+  // h_xfer ([3n] in, [3n + 1] out) instead of pageable memory
+  struct HostReport {
+    int status[kStatTotalWords];
+    double components[4];
+    int rows[4], pack[4];
+  };
+  HostReport* h_report = nullptr;
+  double* h_xfer = nullptr;
+  // agbnp_hip_execute_host's short cut: an evaluation that the pinned status words call complete skips the reads of the
+  // device (they are diagnostics) and leaves the log running; the reads are caught up with when somebody asks for a
+  // diagnostic, when an evaluation is enqueued through a device-resident entry point, and every 1024 evaluations
+  int lazy_evals = 0;           // evaluations of execute_host since the log was last read and cleared
   std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
   int last_rows[3] = {0, 0, 0};  // {stale flag, builds so far, entries per slice} of the row-form neighbour rows, as of the last harvest
   int row_slice = 0;           // AGBNP_HIP_ROW_SLICE: entries per slice, fixed (0: tuned on the device, see rows_close_evaluation)
@@ -462,7 +476,16 @@ void wire_args(agbnp_hip_context* c) {
 
 int upload_identity_packing(agbnp_hip_context* c);
 
+int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st);
+// reads of the device that agbnp_hip_execute_host's short cut has put off (its stream is idle: every call ends with a wait)
+int catch_up(agbnp_hip_context* c) {
+  if (c->lazy_evals == 0) return AGBNP_HIP_OK;
+  int none = 0;
+  return harvest(c, &none, c->stream);  // (every one of them was complete: nothing to repeat)
+}
+
 void note_stream(agbnp_hip_context* c, void* stream) {  // a caller's stream with work of this context on it
+  (void)catch_up(c);  // (the log of the device-resident entry points starts at its evaluation 0)
   c->unfinished = true;
   if (stream && std::find(c->user_streams.begin(), c->user_streams.end(), stream) == c->user_streams.end()) c->user_streams.push_back(stream);
 }
@@ -700,11 +723,14 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_ctx_slot.alloc(std::max(n, 1)));
   HIP_TRY(c, hipMemset(c->d_ctx_slot.p, 0, sizeof(int) * std::max(n, 1)));
-  HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n));
+  HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n + 1));  // (+ the energy of agbnp_hip_execute_host)
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
-  HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * 3 * (size_t)n));
+  HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * (3 * (size_t)n + 1)));
   HIP_TRY(c, hipMemset(c->d_energy_tmp.p, 0, sizeof(double)));
-  c->h_force_tmp.resize(3 * (size_t)n);
+  c->h_force_tmp.resize(3 * (size_t)n + 1);
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_report), sizeof(agbnp_hip_context::HostReport), hipHostMallocDefault) != hipSuccess) c->h_report = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_xfer), sizeof(double) * (6 * (size_t)n + 8), hipHostMallocDefault) != hipSuccess) c->h_xfer = nullptr;
+  (void)hipGetLastError();  // (without pinned memory the host-facing paths fall back to pageable transfers)
   return AGBNP_HIP_OK;
 }
 
@@ -799,8 +825,19 @@ int upload_identity_packing(agbnp_hip_context* c) {
 
 // after the stream is idle: read status + components; react to overflow.  *repeat = number of evaluations since the
 // previous harvest whose forces and energy were withheld on the device (the caller must run those again).
-int harvest(agbnp_hip_context* c, int* repeat) {
+int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   *repeat = 0;
+  // what is read of the device: asked for behind everything on the stream, then ONE wait
+  if (c->h_report) {
+    agbnp_hip_context::HostReport* r = c->h_report;
+    HIP_TRY(c, hipMemcpyAsync(r->status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(r->components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+    if (c->rows_capable) HIP_TRY(c, hipMemcpyAsync(r->rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(r->pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+    // ... and a new log starts behind the reads, in front of the same wait (an empty log is cleared to what it is)
+    HIP_TRY(c, hipMemsetAsync(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq), st));
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));
   // per-kernel durations of everything enqueued since the last harvest
   Timeline& tl = c->timeline;
   for (size_t k = 0; k + 1 < tl.used; k++) {
@@ -812,19 +849,27 @@ int harvest(agbnp_hip_context* c, int* repeat) {
     c->kernel_launches[id]++;
   }
   tl.used = 0;
-  HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
-  if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost));
+  if (c->h_report) {
+    std::memcpy(c->last_status, c->h_report->status, sizeof(int) * kStatTotalWords);
+    std::memcpy(c->last_components, c->h_report->components, sizeof(double) * 4);
+    if (c->rows_capable) std::memcpy(c->last_rows, c->h_report->rows, sizeof(int) * 3);
+    std::memcpy(c->last_pack, c->h_report->pack, sizeof(int) * 3);
+  } else {
+    HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
+    if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost));
+  }
   const int* s = c->last_status;
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
   // the last evaluation's own words say whether the diagnostics on the device are those of a complete evaluation
   c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow]) : c->have_results;
-  if (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0)  // start a new log
+  if (!c->h_report && (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0))  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
   if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
   c->enqueued = 0;  // (the device's running number starts over with the log)
+  c->lazy_evals = 0;
   if (c->withheld_count == 0) return AGBNP_HIP_OK;
   for (int k = 0; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
     if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k);
@@ -1040,9 +1085,8 @@ int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {
   if (!must_repeat) must_repeat = &dummy;
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIP_TRY(c, hipStreamSynchronize(st));
   c->user_streams.erase(std::remove(c->user_streams.begin(), c->user_streams.end(), stream), c->user_streams.end());
-  int rc = harvest(c, must_repeat);
+  int rc = harvest(c, must_repeat, st);  // (waits for the stream)
   if (rc != AGBNP_HIP_OK) return rc;
   if (c->carried_count > 0) {
     // evaluations of execute_device that a call of agbnp_hip_execute_host in between had to harvest: they were enqueued
@@ -1070,7 +1114,7 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (void* st : c->user_streams) HIP_TRY(c, hipStreamSynchronize((hipStream_t)st));
     int pending = 0;
-    int rc = harvest(c, &pending);
+    int rc = harvest(c, &pending, c->stream);
     if (rc != AGBNP_HIP_OK) return rc;
     const int seq = c->last_status[kStatEvalSeq];
     for (int k : c->withheld) c->carried.push_back(k + c->carried_seq);
@@ -1078,22 +1122,34 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
     c->carried_seq += seq;
     c->unfinished = false;
   }
+  const size_t n3 = 3 * (size_t)c->n;
+  double* const d_energy = c->d_force_tmp.p + n3;  // forces and energy leave in one buffer: one clear, one copy back
+  double* const h_in = c->h_xfer ? c->h_xfer : nullptr;
+  double* const h_out = c->h_xfer ? c->h_xfer + n3 : c->h_force_tmp.data();
+  if (h_in) std::memcpy(h_in, pos, bytes);
   for (int attempt = 0; attempt < 8; attempt++) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, pos, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_force_tmp.p, 0, bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_energy_tmp.p, 0, sizeof(double), c->stream));
-    int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, h_in ? h_in : pos, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_force_tmp.p, 0, bytes + sizeof(double), c->stream));
+    int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, d_energy, c->stream);
     if (rc != AGBNP_HIP_OK) return rc;
-    double e = 0.0;
-    HIP_TRY(c, hipMemcpyAsync(c->h_force_tmp.data(), c->d_force_tmp.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&e, c->d_energy_tmp.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_out, c->d_force_tmp.p, bytes + sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (c->h_status && c->h_report && !c->timeline.enabled && c->enqueued < 1024) {
+      // the short cut: the device's own word on this evaluation (pinned memory, written when its tree stage had ended)
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      const volatile int* h = c->h_status;
+      if (h[0] == c->enqueued && h[1] == 0) {
+        c->lazy_evals++;
+        for (size_t k = 0; k < n3; k++) forces[k] += h_out[k];
+        *energy = h_out[n3];
+        return AGBNP_HIP_OK;
+      }
+    }
     int repeat = 0;
-    rc = harvest(c, &repeat);
+    rc = harvest(c, &repeat, c->stream);  // (its own reads follow on the stream; one wait for everything)
     if (rc != AGBNP_HIP_OK) return rc;
     if (repeat) continue;
-    for (size_t k = 0; k < 3 * (size_t)c->n; k++) forces[k] += c->h_force_tmp[k];
-    *energy = e;
+    for (size_t k = 0; k < n3; k++) forces[k] += h_out[k];
+    *energy = h_out[n3];
     return AGBNP_HIP_OK;
   }
   return c->fail(AGBNP_HIP_ERR_CAPACITY, "agbnp_hip_execute_host: capacity negotiation did not converge");
@@ -1101,6 +1157,11 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
 
 int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
   if (!c || !value) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (c->lazy_evals) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc_ = catch_up(c);
+    if (rc_ != AGBNP_HIP_OK) return rc_;
+  }
   if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");
   switch (which) {
     case 0: *value = c->last_components[0]; break;
@@ -1124,6 +1185,11 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
 
 int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
   if (!c || !out) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  if (c->lazy_evals) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc_ = catch_up(c);
+    if (rc_ != AGBNP_HIP_OK) return rc_;
+  }
   if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");
   HIP_TRY(c, hipSetDevice(c->device));
   const int n = c->n, nh = c->nh;
@@ -1269,7 +1335,7 @@ int agbnp_hip_poll(const agbnp_hip_context* c, int* evaluations_completed, int* 
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
   if (!c->h_status) return AGBNP_HIP_ERR_DEVICE;
   const volatile int* h = c->h_status;
-  const int done = h[0];  // (written after the withheld count, behind a system-scope fence)
+  const int done = h[0] - c->lazy_evals;  // (written after the withheld count, behind a system-scope fence; execute_host's own are not the caller's)
   if (evaluations_completed) *evaluations_completed = done;
   if (withheld) *withheld = h[1];
   return AGBNP_HIP_OK;
@@ -1278,7 +1344,7 @@ int agbnp_hip_poll(const agbnp_hip_context* c, int* evaluations_completed, int* 
 int agbnp_hip_wait_verdict(const agbnp_hip_context* c, int evaluations, double timeout_seconds, int* evaluations_completed, int* withheld) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
   if (!c->h_status) return AGBNP_HIP_ERR_DEVICE;
-  const int target = evaluations > 0 ? evaluations : c->enqueued;
+  const int target = evaluations > 0 ? evaluations + c->lazy_evals : c->enqueued;
   const volatile int* h = c->h_status;
   const auto t0 = std::chrono::steady_clock::now();
   int done = h[0];
@@ -1286,7 +1352,7 @@ int agbnp_hip_wait_verdict(const agbnp_hip_context* c, int evaluations, double t
     __builtin_ia32_pause();
     if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) break;
   }
-  if (evaluations_completed) *evaluations_completed = done;
+  if (evaluations_completed) *evaluations_completed = done - c->lazy_evals;
   if (withheld) *withheld = h[1];  // (written before the running number, behind a system-scope fence)
   return done >= target ? AGBNP_HIP_OK : AGBNP_HIP_ERR_TIMEOUT;
 }
@@ -1355,6 +1421,8 @@ void agbnp_hip_destroy(agbnp_hip_context* c) {
   }
   for (hipEvent_t e : c->timeline.events) (void)hipEventDestroy(e);
   if (c->h_status) (void)hipHostFree(c->h_status);
+  if (c->h_report) (void)hipHostFree(c->h_report);
+  if (c->h_xfer) (void)hipHostFree(c->h_xfer);
   delete c;
 }
 
