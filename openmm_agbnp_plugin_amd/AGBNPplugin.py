@@ -61,6 +61,7 @@ class AGBNPForce:
     def addParticle(self, radius, gamma, vdw_alpha, charge, ishydrogen):
         """radius nm, gamma kJ/mol/nm^2, vdw_alpha kJ/mol nm^3... (as the reference), charge e. Returns the index."""
         self._particles.append([_strip_units(radius), _strip_units(gamma), _strip_units(vdw_alpha), _strip_units(charge), bool(ishydrogen)])
+        self._cache = None
         return len(self._particles) - 1
 
     def _check_index(self, index):
@@ -69,7 +70,13 @@ class AGBNPForce:
 
     def setParticleParameters(self, index, radius, gamma, vdw_alpha, charge, ishydrogen):
         self._check_index(index)
-        self._particles[index] = [_strip_units(radius), _strip_units(gamma), _strip_units(vdw_alpha), _strip_units(charge), bool(ishydrogen)]
+        row = [_strip_units(radius), _strip_units(gamma), _strip_units(vdw_alpha), _strip_units(charge), bool(ishydrogen)]
+        self._particles[index] = row
+        cache = getattr(self, "_cache", None)
+        if cache is not None:  # the arrays that cross the boundary follow in place (updateParametersInContext after a sweep of these)
+            for k in range(4):
+                cache[k][index] = row[k]
+            cache[4][index] = 1 if row[4] else 0
 
     def getParticleParameters(self, index):
         """Returns the tuple (radius, gamma, vdw_alpha, charge, ishydrogen), as the SWIG wrapper does."""
@@ -111,9 +118,13 @@ class AGBNPForce:
 
     # helpers for the engine boundary
     def _arrays(self):
-        p = self._particles
-        f = lambda k: np.ascontiguousarray([x[k] for x in p], dtype=np.float64)
-        return f(0), f(1), f(2), f(3), np.ascontiguousarray([1 if x[4] else 0 for x in p], dtype=np.int32)
+        """The five parameter arrays as they cross the C ABI (built once, then kept up to date by setParticleParameters)."""
+        cache = getattr(self, "_cache", None)
+        if cache is None:
+            p = self._particles
+            f = lambda k: np.ascontiguousarray([x[k] for x in p], dtype=np.float64)
+            cache = self._cache = (f(0), f(1), f(2), f(3), np.ascontiguousarray([1 if x[4] else 0 for x in p], dtype=np.int32))
+        return cache
 
     @classmethod
     def from_arrays(cls, radius, gamma, vdw_alpha, charge, ishydrogen, version=1):

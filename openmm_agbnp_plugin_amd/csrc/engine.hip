@@ -211,8 +211,18 @@ double overlap_search_cutoff2(const std::vector<double>& a_large, const std::vec
   return best * (1.0 + 1e-6) + 1e-9;
 }
 
-int upload_parameters(agbnp_hip_context* c) {
+// changed_only: agbnp_hip_update_parameters -- gamma, alpha and charge are all that may change there (radii and the
+// hydrogen flags are refused before), so three arrays travel instead of nine
+int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
   const int n = c->n, nh = c->nh;
+  if (changed_only && c->d_heavy.p != nullptr) {
+    std::vector<double> gam_cav(nh);
+    for (int h = 0; h < nh; h++) gam_cav[h] = c->gamma[c->h2a[h]] / kRadiusIncrement;
+    HIP_TRY(c, c->d_charge.upload(c->charge));
+    HIP_TRY(c, c->d_alpha.upload(c->alpha));
+    if (nh > 0) HIP_TRY(c, hipMemcpy(c->hrow(kHvGam), gam_cav.data(), sizeof(double) * nh, hipMemcpyHostToDevice));
+    return AGBNP_HIP_OK;
+  }
   std::vector<double> inv_rvdw(n), inv_vol_h(nh), gam_cav(nh), a_large(nh), v_large(nh), a_vdw(nh), v_vdw(nh);
   const double roffset = kRadiusIncrement;  // versions 0 and 1 (ReferenceAGBNPKernels.cpp:67-70)
   for (int i = 0; i < n; i++) inv_rvdw[i] = 1. / c->r_vdw[i];
@@ -1020,7 +1030,7 @@ int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radiu
   if (!radius || !gamma || !vdw_alpha || !charge || !ishydrogen) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "null pointer");
   if (n != c->n) return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: The number of AGBNP particles has changed");
   for (int i = 0; i < n; i++) {
-    if (pow(c->r_vdw[i] - radius[i], 2) > 1.e-6)
+    if ((c->r_vdw[i] - radius[i]) * (c->r_vdw[i] - radius[i]) > 1.e-6)
       return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: AGBNP plugin does not support changing atomic radii.");
     if (ishydrogen[i] && c->ish[i] == 0)
       return c->fail(AGBNP_HIP_ERR_PARAMETERS, "updateParametersInContext: AGBNP plugin does not support changing heavy/hydrogen atoms.");
@@ -1037,7 +1047,7 @@ int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radiu
   // to learn about withheld evaluations.  (Not hipDeviceSynchronize: that would stall every other context of the device.)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (void* st : c->user_streams) HIP_TRY(c, hipStreamSynchronize((hipStream_t)st));
-  int rc = upload_parameters(c);
+  int rc = upload_parameters(c, true);
   if (rc != AGBNP_HIP_OK) return rc;
   wire_args(c);
   return AGBNP_HIP_OK;

@@ -21,3 +21,11 @@ for i in range(reps):
     k.execute(geoms[i % 32], f)
 dt = (time.perf_counter() - t0) / reps
 print(f"{name}: agbnp_hip_execute_host {1e3 * dt:.4f} ms per evaluation")
+from openmm_agbnp_plugin_amd import _lib
+from openmm_agbnp_plugin_amd.AGBNPplugin import _dp, _ip
+r, g, a, q, h = P.AGBNPForce.from_arrays(*s.params(), version=1)._arrays()
+lib = _lib.load()
+t0 = time.perf_counter()
+for i in range(200):
+    lib.agbnp_hip_update_parameters(k._h, len(r), _dp(r), _dp(g), _dp(a), _dp(q), _ip(h))
+print(f"{name}: agbnp_hip_update_parameters {1e3 * (time.perf_counter() - t0) / 200:.4f} ms per call (C ABI, arrays at hand)")
