@@ -47,6 +47,50 @@ def test_nve_energy_conservation_trpcage(gpu_required, systems):
     assert np.ptp(pot) > 10 * np.abs(total - total[0]).max()
 
 
+def test_fused_integrator_steps_are_the_torch_steps(gpu_required, systems):
+    """The two-launch integrator (csrc/md_kernels.hip) against the same step written in torch operations: velocity Verlet
+    is deterministic, so positions, velocities and the logged energies of twenty steps must agree to rounding."""
+    pytest.importorskip("torch")
+    from openmm_agbnp_plugin_amd.md import DeviceMD
+    s = systems("trpcage")
+    runs = []
+    for fused in (True, False):
+        k = P.HipCalcAGBNPForceKernel()
+        k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+        md = DeviceMD(s, k, k_tether=2.0e4, dt=0.001, temperature=300.0, seed=5, fused=fused)
+        md.settle()
+        md.x.add_(0.002 * md.torch.sin(md.x * 37.0))  # off the tether minimum
+        md.forces()
+        assert k.finish() == 0
+        e0 = float(md.ene)
+        assert md.run(20, "verlet", check_every=20) == 0
+        pot, kin = md.energies()
+        runs.append((e0, md.x.cpu().numpy(), md.v.cpu().numpy(), pot, kin))
+    (e0a, xa, va, pa, ka), (e0b, xb, vb, pb, kb) = runs
+    assert abs(e0a - e0b) < 1e-8 * abs(e0b)
+    assert np.abs(xa - xb).max() < 1e-11 and np.abs(va - vb).max() < 1e-9
+    assert np.abs(pa - pb).max() < 1e-7 and np.abs(ka - kb).max() < 1e-7
+
+
+def test_fused_langevin_holds_the_temperature(gpu_required, systems):
+    """The Philox / Box-Muller deviates of the fused Langevin step through the dynamics: 2 ps at 10 / ps friction from a
+    cold start must arrive at the bath's 300 K (816 degrees of freedom: 5 % instantaneous fluctuation, less on average)."""
+    pytest.importorskip("torch")
+    from openmm_agbnp_plugin_amd.md import DeviceMD, KB
+    s = systems("trpcage")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    md = DeviceMD(s, k, k_tether=2.0e4, dt=0.001, temperature=300.0, friction=10.0, seed=11)
+    md.settle()
+    md.v.zero_()
+    md.forces()
+    assert k.finish() == 0
+    assert md.run(2000, "langevin", check_every=1000) == 0
+    _, kin = md.energies(last=800)
+    temp = 2.0 * kin.mean() / (3 * s.n * KB)
+    assert 280.0 < temp < 320.0, f"temperature {temp:.1f} K"
+
+
 @pytest.mark.parametrize("script,args,expect", [
     ("examples/test_agbnp.py", ["trpcage", "1000", "200"], "Test energy conservation ..."),
     ("examples/1dwc_benchmark.py", ["1dwc", "1000"], "ns/day"),
