@@ -323,6 +323,32 @@ def openmm_entry(torch, name, device, dev_index, steps, warmup):
     return out
 
 
+def md_loop_entry(torch, name, dev_index, steps):
+    """ms per MD step of the loop behind examples/1dwc_benchmark.py (the py3 counterpart of the script the reference's
+    ns/day comes from, example/1dwc_benchmark.py:20,29-33): Langevin 300 K, 1 / ps, 1 fs, AGBNP1 + tethers, one step = two
+    integrator launches (csrc/md_kernels.hip) around one evaluation, captured once as a HIP graph and replayed; the host
+    reads the overflow log every 1000 steps.  Full-MD ns/day as far as this repository has a force field; the headline
+    `value` stays the force-limited figure."""
+    from openmm_agbnp_plugin_amd.md import DeviceMD
+    system = load_workload(name)
+    force = P.AGBNPForce.from_arrays(*system.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
+    kernel.initialize(force)
+    md = DeviceMD(system, kernel, k_tether=1.0e5, dt=0.001, temperature=300.0, friction=1.0, device=f"cuda:{dev_index}")
+    md.settle()
+    md.forces()
+    kernel.finish()
+    md.run(20, "langevin", check_every=20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    missed = md.run(steps, "langevin", check_every=1000)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {"workload": name, "script": "examples/1dwc_benchmark.py", "steps": steps, "ms_per_step": ms, "ns_day": 86.4 / ms,
+            "steps_without_agbnp_term": int(missed)}
+
+
 def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, warmup):
     """Aggregate throughput of several INDEPENDENT replicas sharing one GPU, each context on a stream of its own (multiple
     walkers / replica exchange on one device).  The evaluation is bound by dependent latency, not by throughput, so
@@ -623,6 +649,7 @@ def main():
                                  for m in ("fast", "fast+single", "deterministic")]
         result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(torch, "1dwc", device, dev_index, r, 200, 20) for r in (2, 4)]
         result["openmm_entry"] = openmm_entry(torch, "1dwc", device, dev_index, 200, 20)
+        result["md_loop"] = md_loop_entry(torch, "1dwc", dev_index, 3000)
 
     if rank == 0:
         print(json.dumps(result))

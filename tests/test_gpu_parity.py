@@ -1014,6 +1014,50 @@ def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
     assert k.poll() == (0, 0)
 
 
+def test_host_entry_short_cut_keeps_the_log_of_the_device_entry_points(gpu_required, systems):
+    """agbnp_hip_execute_host skips the reads of the device for an evaluation that the pinned status words call complete and
+    leaves the overflow log running; none of that may show through the device-resident protocol: poll / wait_verdict do not
+    count the host path's evaluations, diagnostics asked for afterwards are those of the last evaluation, the indices that
+    finish() reports start at the caller's own first evaluation, and a withheld host evaluation is still repeated."""
+    torch = pytest.importorskip("torch")
+    from oracle import Oracle
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    squeezed = centre + 0.85 * (s.pos - centre)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    o = Oracle(*s.params(), version=1)
+    f = np.zeros((s.n, 3))
+    for step in range(3):  # the short cut (after the first, which settles the packing)
+        f[:] = 0.0
+        e = k.execute(s.jittered(step), f)
+    eo, fo = o.execute(s.jittered(2))
+    assert_close(e, f, eo, fo)
+    assert k.poll() == (0, 0) and k.wait_verdict() == (0, 0)
+    assert k.scalar("total_nodes") > 200000  # a diagnostic of the LAST evaluation: caught up with on demand
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack([s.pos, squeezed]), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    f[:] = 0.0
+    k.execute(s.jittered(3), f)  # host path again, then straight into the device path
+    for i in (0, 1, 0):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.wait_verdict() == (3, 1)
+    assert k.finish(stream) == 1 and k.withheld() == [1]
+    # a host evaluation that overflows (the squeezed geometry on a fresh context) is repeated inside the call
+    k2 = P.HipCalcAGBNPForceKernel()
+    k2.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    f[:] = 0.0
+    k2.execute(s.pos, f)
+    f[:] = 0.0
+    e = k2.execute(squeezed, f)
+    eo, fo = o.execute(squeezed)
+    assert_close(e, f, eo, fo)
+
+
 def test_wait_verdict_judges_every_evaluation_without_draining_the_stream(gpu_required, systems):
     """agbnp_hip_wait_verdict blocks the HOST until the device has written its verdict on every evaluation enqueued since
     the last finish() -- no synchronisation call of ours in between -- and says how many were withheld: the strict
