@@ -100,7 +100,8 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* ctx, const void* d_posq, int pos
 int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
 
 /* Which evaluations the LAST agbnp_hip_finish() found withheld: writes up to `capacity` indices (0 = the first
- * evaluation enqueued after the finish before it; the log holds indices below 2048, later ones are only counted)
+ * evaluation enqueued through a device-resident entry point after the finish before it; the log names at least the first
+ * 1024 of them, later ones are only counted)
  * and returns their total number (-1: null context). */
 int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, int capacity);
 

@@ -167,7 +167,10 @@ struct agbnp_hip_context {
   // agbnp_hip_execute_host's short cut: an evaluation that the pinned status words call complete skips the reads of the
   // device (they are diagnostics) and leaves the log running; the reads are caught up with when somebody asks for a
   // diagnostic, when an evaluation is enqueued through a device-resident entry point, and every 1024 evaluations
-  int lazy_evals = 0;           // evaluations of execute_host since the log was last read and cleared
+  int lazy_evals = 0;           // evaluations of execute_host since the log was last read and cleared: the FIRST entries of the
+                                // running log (a device-resident entry point that follows counts on from there; nothing is
+                                // synchronised for the hand-over, so it is safe inside a graph capture)
+  int last_device_seq = 0;      // harvest(): evaluations of the device-resident entry points that the log just read held
   std::vector<void*> user_streams;  // streams the caller has enqueued on since the last finish (drained before parameters change)
   int last_rows[3] = {0, 0, 0};  // {stale flag, builds so far, entries per slice} of the row-form neighbour rows, as of the last harvest
   int row_slice = 0;           // AGBNP_HIP_ROW_SLICE: entries per slice, fixed (0: tuned on the device, see rows_close_evaluation)
@@ -495,7 +498,6 @@ int catch_up(agbnp_hip_context* c) {
 }
 
 void note_stream(agbnp_hip_context* c, void* stream) {  // a caller's stream with work of this context on it
-  (void)catch_up(c);  // (the log of the device-resident entry points starts at its evaluation 0)
   c->unfinished = true;
   if (stream && std::find(c->user_streams.begin(), c->user_streams.end(), stream) == c->user_streams.end()) c->user_streams.push_back(stream);
 }
@@ -878,11 +880,13 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   if (!c->h_report && (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0))  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
   if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
+  const int host_first = c->lazy_evals;  // the log's first entries are execute_host's own (every one of them complete)
+  c->last_device_seq = std::max(0, s[kStatEvalSeq] - host_first);
   c->enqueued = 0;  // (the device's running number starts over with the log)
   c->lazy_evals = 0;
   if (c->withheld_count == 0) return AGBNP_HIP_OK;
-  for (int k = 0; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
-    if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k);
+  for (int k = host_first; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
+    if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k - host_first);
   *repeat = c->withheld_count;
   // A repeat must not overflow for the same reason again: it runs one subtree per work slot (the packing of the
   // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last) ...
@@ -1126,7 +1130,7 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
     int pending = 0;
     int rc = harvest(c, &pending, c->stream);
     if (rc != AGBNP_HIP_OK) return rc;
-    const int seq = c->last_status[kStatEvalSeq];
+    const int seq = c->last_device_seq;
     for (int k : c->withheld) c->carried.push_back(k + c->carried_seq);
     c->carried_count += pending;
     c->carried_seq += seq;
