@@ -366,8 +366,11 @@ void wire_args(agbnp_hip_context* c) {
     // Row form (reference mode only: the fast mode cuts every stage at the cutoff and the deterministic mode fixes the
     // order of its sums through the tiles' quantized totals)
     const bool wanted = c->rows_policy != 0;  // (AGBNP_HIP_ROWS=0: the tile kernels everywhere)
-    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.det && !P.single && wanted ? 1 : 0;
-    P.gb_rows = P.rows_on && P.fast && c->d_nlg.p != nullptr && getenv("AGBNP_HIP_NO_GB_ROWS") == nullptr ? 1 : 0;
+    // (the single-precision option of the fast mode lives in the GB stage: in the GB rows where they can run, else in the
+    // packed-FP32 strips of the tile form)
+    const bool gb_rows_possible = P.fast && c->d_nlg.p != nullptr && getenv("AGBNP_HIP_NO_GB_ROWS") == nullptr;
+    P.rows_on = c->rows_capable && !c->rows_disabled && c->version == 1 && !P.det && (!P.single || gb_rows_possible) && wanted ? 1 : 0;
+    P.gb_rows = P.rows_on && gb_rows_possible ? 1 : 0;
     const double reach = sqrt(P.range2) + c->skin, gb_reach = c->cutoff + c->skin;  // (fast mode: the range-limited stages stop at the cutoff too)
     P.nl_build2 = reach * reach;
     P.nlg_build2 = gb_reach * gb_reach;

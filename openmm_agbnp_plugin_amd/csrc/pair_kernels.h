@@ -59,7 +59,7 @@ struct PairArgs {
   double gb_cut2;          // squared GB cutoff (fast mode) -- the GB kernel is compiled twice, this is read by the cut one
   int cull_first;          // range-limited stages: 1 = a tile tests its bounding boxes before it asks for its data (large systems)
   int fast;                // 1 = fast mode
-  int single;              // 1 = fast mode with the GB strips in packed single precision
+  int single;              // 1 = fast mode with the GB pair terms in single precision (GB rows; packed FP32 strips in the tile form)
   int det;                 // 1 = deterministic mode (device_math.h)
   // ---- tree accumulators / outputs
   double *gx, *gy, *gz;    // [nh] tree sums: gradient

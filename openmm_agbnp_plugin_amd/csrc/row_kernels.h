@@ -473,6 +473,55 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     PAIR_STAMP(1, 8);
     PAIR_STAMP_WAIT(1, 1, "vmcnt(0)");  // the first records are here
     ROWS_LOG_COUNTS(1, todo, nsteps);
+    if (P.single) {
+      // AGBNP_HIP_MODE_SINGLE: the pair terms in single precision, the default precision of the reference's GPU platform
+      // (hardware exp2 / rsqrt, a third of the instructions).  Positions are taken relative to the group's first row atom
+      // before they are rounded (1e-7 of a nanometre, not of the box); the sums of a slice run in single precision and
+      // leave in FP64 like the others; Born radii stay FP64.
+      float ox[R], oy[R], oz[R], qf[R], bf[R], cf[R], accf[4 * R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        ox[r] = (float)(A.x[r] - A.x[0]), oy[r] = (float)(A.y[r] - A.y[0]), oz[r] = (float)(A.z[r] - A.z[0]);
+        qf[r] = (float)qa[r], bf[r] = (float)ba[r], cf[r] = (float)ca_[r];
+      }
+#pragma unroll
+      for (int q = 0; q < 4 * R; q++) accf[q] = 0.0f;
+      float esumf = 0.0f;
+      for (int k = 0; k < nsteps; k++) {
+        const unsigned e = e1;
+        const double4 rb = r1;
+        const BornRadius bb_ = born_radius(v1, p1);
+        e1 = e2;
+        r1 = rec[e1 & 0xffffffu];
+        p1 = P.born_part[e1 & 0xffffffu], v1 = P.inv_rvdw[e1 & 0xffffffu];
+        e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
+        const int b = (int)(e & 0xffffffu);
+        const float cut2 = 64 * k + lane < todo ? (float)P.gb_cut2 : -1.0f;  // (a lane beyond the slice meets nobody)
+        const float nx = (float)(rb.x - A.x[0]), ny = (float)(rb.y - A.y[0]), nz = (float)(rb.z - A.z[0]);
+        const float qb = (float)rb.w, bj = (float)bb_.br, ibj = (float)bb_.inv_br;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float dx = nx - ox[r], dy = ny - oy[r], dz = nz - oz[r];
+          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          if (d2 < cut2 && b != A.self[r]) {
+            const float bb = bf[r] * bj;
+            const float et = __builtin_amdgcn_exp2f(d2 * (cf[r] * ibj));  // exp(-d^2 / (4 B_a B_b))
+            const float fgb = __builtin_amdgcn_rsqf(fmaf(bb, et, d2));
+            const float s1 = (qf[r] * qb) * fgb;
+            esumf += s1;
+            const float s3 = s1 * (fgb * fgb);
+            const float mw = fmaf(-0.25f, et, 1.0f) * s3;
+            accf[4 * r] = fmaf(fmaf(0.25f, d2, bb), et * s3, accf[4 * r]);  // Y
+            accf[4 * r + 1] = fmaf(dx, mw, accf[4 * r + 1]);
+            accf[4 * r + 2] = fmaf(dy, mw, accf[4 * r + 2]);
+            accf[4 * r + 3] = fmaf(dz, mw, accf[4 * r + 3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4 * R; q++) acc[q] = (double)accf[q];
+      esum = (double)esumf;
+    } else
     for (int k = 0; k < nsteps; k++) {
       const unsigned e = e1;
       const double4 rb = r1;
