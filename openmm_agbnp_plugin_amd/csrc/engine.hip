@@ -298,6 +298,7 @@ void wire_args(agbnp_hip_context* c) {
   PairArgs& P = c->P;
   P.n = c->n;
   P.nh = c->nh;
+  P.zero_out = nullptr;
   P.a2h = c->d_a2h.p;
   P.h2a = c->d_h2a.p;
   P.charge = c->d_charge.p;
@@ -1146,8 +1147,9 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
   if (h_in) std::memcpy(h_in, pos, bytes);
   for (int attempt = 0; attempt < 8; attempt++) {
     HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, h_in ? h_in : pos, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_force_tmp.p, 0, bytes + sizeof(double), c->stream));
+    c->P.zero_out = c->d_force_tmp.p;  // (cleared by k_prep: the kernel arguments are captured by value at launch)
     int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, d_energy, c->stream);
+    c->P.zero_out = nullptr;
     if (rc != AGBNP_HIP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(h_out, c->d_force_tmp.p, bytes + sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (c->h_status && c->h_report && !c->timeline.enabled && c->enqueued < 1024) {

@@ -24,6 +24,8 @@ struct PairArgs {
   int n, nh;
   // ---- per-evaluation input
   const double* pos;  // [3n] caller's positions (nm), atom order
+  double* zero_out;   // agbnp_hip_execute_host: its staging buffer for forces [3n] and energy [1], cleared by k_prep (one stream
+                      // operation less than a clearing launch of its own); nullptr otherwise
   // ---- static per-atom / per-heavy-atom parameters
   const int* a2h;      // [n] atom -> heavy index or -1
   const int* h2a;      // [nh]

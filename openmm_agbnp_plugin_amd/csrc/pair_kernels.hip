@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     if (i < 3) P.nl_nitems[2 * i + ((P.nl_flag[1] + 1) & 1)] = 0;  // the work-item buffers that the next rebuild fills
   }
   if (i >= P.n) return;
+  if (P.zero_out) {  // (the evaluation's own outputs are added much later: the tree launch lies in between)
+    P.zero_out[3 * i] = 0.0;
+    P.zero_out[3 * i + 1] = 0.0;
+    P.zero_out[3 * i + 2] = 0.0;
+    if (i == 0) P.zero_out[3 * (size_t)P.n] = 0.0;
+  }
   const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
   if (P.rows_on) {
