@@ -196,15 +196,16 @@ class DeviceMD:
                 raise RuntimeError("AGBNP capacity negotiation did not converge")
         torch.cuda.synchronize()
 
-    def _graph(self, kind):
+    def _graph(self, kind, steps=1):
+        """A HIP graph of `steps` consecutive MD steps of the given kind (captured once per kind, length and engine generation)."""
         torch = self.torch
         if self.generation != self.kernel.generation():  # first use, or the capacity variant was raised: kernels are stale
             self.graphs.clear()
             self.generation = self.kernel.generation()
-        if kind not in self.graphs:
+        if (kind, steps) not in self.graphs:
             step = {"verlet": self.step_verlet, "langevin": self.step_langevin, "descent": self.step_descent}[kind]
             counter0 = self.counter.clone()
-            state = (self.x.clone(), self.v.clone(), self.frc.clone(), self.ene.clone())
+            state = (self.x.clone(), self.v.clone(), self.frc.clone(), self.last.clone())
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):  # torch wants a few eager runs on a side stream before a capture
                 step()
@@ -212,26 +213,35 @@ class DeviceMD:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                step()
+                for _ in range(steps):
+                    step()
             torch.cuda.synchronize()
-            # the capture itself does not run the step, the warm-up did: put the state back
-            for dst, src in zip((self.x, self.v, self.frc, self.ene), state):
+            # the capture itself does not run the steps, the warm-up did: put the state back
+            for dst, src in zip((self.x, self.v, self.frc, self.last), state):
                 dst.copy_(src)
             self.counter.copy_(counter0)
-            self.graphs[kind] = g
-        return self.graphs[kind]
+            self.graphs[(kind, steps)] = g
+        return self.graphs[(kind, steps)]
 
-    def run(self, nsteps, kind="langevin", check_every=1000, on_report=None):
-        """Replays the captured step; every `check_every` steps synchronises and reads the engine's overflow log.  Returns
-        the number of steps whose AGBNP contribution was withheld (tree capacity exceeded): 0 in a healthy run."""
+    def run(self, nsteps, kind="langevin", check_every=1000, on_report=None, steps_per_graph=10):
+        """Replays the captured steps (`steps_per_graph` MD steps per graph launch: the host's share of a launch is paid once
+        for all of them); every `check_every` steps synchronises and reads the engine's overflow log.  Returns the number of
+        steps whose AGBNP contribution was withheld (tree capacity exceeded): 0 in a healthy run."""
         torch = self.torch
         missed = 0
         done = 0
         while done < nsteps:
             chunk = min(check_every, nsteps - done)
-            g = self._graph(kind)
-            for _ in range(chunk):
-                g.replay()
+            many = chunk // steps_per_graph if steps_per_graph > 1 else 0
+            if many:
+                g = self._graph(kind, steps_per_graph)
+                for _ in range(many):
+                    g.replay()
+            rest = chunk - many * steps_per_graph
+            if rest:
+                g = self._graph(kind)
+                for _ in range(rest):
+                    g.replay()
             done += chunk
             self.steps_done += chunk
             missed += self.kernel.finish(torch.cuda.current_stream().cuda_stream)
