@@ -1058,6 +1058,77 @@ def test_host_entry_short_cut_keeps_the_log_of_the_device_entry_points(gpu_requi
     assert_close(e, f, eo, fo)
 
 
+def test_entry_points_mixed_at_random_keep_their_books(gpu_required, systems, monkeypatch):
+    """A seeded random walk over the entry points of ONE context -- host-buffer evaluations (short cut or repeat inside the
+    call), batches of queued device-resident evaluations judged by wait_verdict and read by finish, diagnostics in between
+    -- on geometries that alternate between a swollen molecule and the real one, so that the forest packing planned on one
+    overflows on the other now and then.  Every host call must return the oracle's numbers; wait_verdict, finish and
+    withheld() must agree on how many and which evaluations of a batch were withheld; repeating exactly those must make the
+    device buffers the oracle's sum over everything that was asked for."""
+    torch = pytest.importorskip("torch")
+    from oracle import Oracle
+    s = systems("1dwc")
+    centre = s.pos.mean(axis=0)
+    pool = [centre + 1.3 * (s.jittered(j) - centre) for j in range(4)] + [s.jittered(10 + j) for j in range(4)]
+    o = Oracle(*s.params(), version=1)
+    want = [o.execute(g) for g in pool]
+    monkeypatch.setenv("AGBNP_HIP_ROUND_PERMILLE", "100")  # (eight subtrees per forest: a packing that mispredicts easily)
+    monkeypatch.setenv("AGBNP_HIP_REPLAN_EVERY", "1")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack(pool), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(20261004)
+    exp_e, exp_f = 0.0, np.zeros((s.n, 3))
+    asked = withheld_total = host_calls = 0
+    f = np.zeros((s.n, 3))
+    for round_ in range(60):
+        if round_ >= 6 and rng.random() < 0.4:
+            g = int(rng.integers(len(pool)))
+            f[:] = 0.0
+            e = k.execute(pool[g], f)
+            assert_close(e, f, *want[g])
+            assert k.poll() == (0, 0)
+            host_calls += 1
+        else:
+            batch = [int(g) for g in rng.integers(len(pool), size=int(rng.integers(1, 6)))]
+            if round_ < 6:  # the first batches cross from the swollen molecule to the real one for certain
+                batch = [int(rng.integers(4)), int(rng.integers(4)), 4 + int(rng.integers(4)), int(rng.integers(4))]
+            for g in batch:
+                k.execute_device(pos[g].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+            done, bad = k.wait_verdict()
+            assert done == len(batch)
+            assert k.finish(stream) == bad
+            idx = k.withheld()
+            assert len(idx) == bad and all(0 <= i < len(batch) for i in idx) and idx == sorted(set(idx))
+            asked += len(batch)
+            withheld_total += bad
+            for i, g in enumerate(batch):
+                if i not in idx:
+                    exp_e += want[g][0]
+                    exp_f += want[g][1]
+            for i in idx:  # exactly those, until they are in
+                for attempt in range(8):
+                    k.execute_device(pos[batch[i]].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+                    if k.finish(stream) == 0:
+                        break
+                else:
+                    raise AssertionError("a withheld evaluation did not complete in eight repeats")
+                exp_e += want[batch[i]][0]
+                exp_f += want[batch[i]][1]
+        if rng.random() < 0.15:
+            assert k.scalar("total_nodes") > 20000  # (a diagnostic: the reads that the host path's short cut put off)
+    torch.cuda.synchronize()
+    assert host_calls > 10 and asked > 60
+    assert withheld_total >= 1, "the walk was meant to cross at least one overflow"
+    assert abs(ene.item() - exp_e) < 1e-7 * max(1.0, abs(exp_e) * 1e-3) * 10
+    assert np.abs(frc.cpu().numpy() - exp_f).max() < 1e-7 * 10
+
+
 def test_wait_verdict_judges_every_evaluation_without_draining_the_stream(gpu_required, systems):
     """agbnp_hip_wait_verdict blocks the HOST until the device has written its verdict on every evaluation enqueued since
     the last finish() -- no synchronisation call of ours in between -- and says how many were withheld: the strict
