@@ -9,8 +9,9 @@ position, which keeps the geometry a protein.  Everything lives on the GPU (torc
 synchronises every `check_every` steps to read the engine's overflow log (agbnp_hip_finish).
 
 The integrator itself is two launches of libagbnp_md.so (csrc/md_kernels.hip: everything in front of the force
-evaluation, everything behind it; Philox normal deviates) around the six of the AGBNP evaluation; written in torch
-operations it is seventeen (`fused=False`, kept as the cross-check of the kernels): 0.163 -> 0.11 ms per step of 1dwc.
+evaluation, everything behind it -- between the steps of a run both in ONE launch; Philox normal deviates) around the six
+of the AGBNP evaluation; written in torch operations it is seventeen (`fused=False`, kept as the cross-check of the
+kernels): 0.163 -> 0.11 ms per step of 1dwc.
 
 PyTorch is plumbing here (device arrays, the graph capture API), not the product.
 """
@@ -39,6 +40,8 @@ def _md_lib():
         lib.agbnp_md_pre.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, dbl, dbl, dbl, C.c_ulonglong, vp, vp, vp]
         lib.agbnp_md_post.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_longlong, vp, vp]
         lib.agbnp_md_tethers.argtypes = [C.c_int, vp, vp, vp, dbl, vp, vp]
+        lib.agbnp_md_mid.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, dbl, dbl, dbl, C.c_ulonglong, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     C.c_longlong, vp, vp]
         _MD_LIB = lib
     return _MD_LIB
 
@@ -88,6 +91,7 @@ class DeviceMD:
             lib = _md_lib()
             self.e_agbnp = torch.zeros(1, **f64)
             self.tether_part = torch.zeros(lib.agbnp_md_blocks(self.n), **f64)
+            self.tether_part2 = torch.zeros_like(self.tether_part)  # (a run of steps alternates between the two: k_md_mid)
             self.acc = torch.zeros(2, **f64)
             self.done = torch.zeros(1, dtype=torch.int32, device=self.dev)
             self.hdt_m1 = self.hdt_m.reshape(-1).contiguous()
@@ -154,6 +158,29 @@ class DeviceMD:
                                       self.log_pe.data_ptr(), self.log_ke.data_ptr(), self.counter.data_ptr(), self.log_capacity,
                                       self.last.data_ptr(), st))
 
+    def _steps_fused(self, kind, steps):
+        """`steps` consecutive steps: front half, then (evaluation, back half + next front half in ONE launch) between the
+        steps, evaluation, back half: 7 launches per step instead of 8."""
+        lib, st = _md_lib(), self.torch.cuda.current_stream().cuda_stream
+        parts = (self.tether_part, self.tether_part2)
+        self._check(lib.agbnp_md_pre(self.n, kind, self.x.data_ptr(), self.v.data_ptr(), self.frc.data_ptr(), self.x0.data_ptr(),
+                                     self.hdt_m1.data_ptr(), self.c2_1.data_ptr(), self.c1, self.dt, self.k, self.seed, self.counter.data_ptr(),
+                                     parts[0].data_ptr(), st))
+        for j in range(steps):
+            self.kernel.execute_device(self.x.data_ptr(), self.frc.data_ptr(), self.e_agbnp.data_ptr(), st)
+            old = parts[j % 2]
+            if j + 1 < steps:
+                self._check(lib.agbnp_md_mid(self.n, kind, self.x.data_ptr(), self.v.data_ptr(), self.frc.data_ptr(), self.x0.data_ptr(),
+                                             self.hdt_m1.data_ptr(), self.mass1.data_ptr(), self.c2_1.data_ptr(), self.c1, self.dt, self.k, self.seed,
+                                             self.e_agbnp.data_ptr(), old.data_ptr(), parts[(j + 1) % 2].data_ptr(), self.acc.data_ptr(),
+                                             self.done.data_ptr(), self.log_pe.data_ptr(), self.log_ke.data_ptr(), self.counter.data_ptr(),
+                                             self.log_capacity, self.last.data_ptr(), st))
+            else:
+                self._check(lib.agbnp_md_post(self.n, self.v.data_ptr(), self.frc.data_ptr(), self.hdt_m1.data_ptr(), self.mass1.data_ptr(),
+                                              self.e_agbnp.data_ptr(), old.data_ptr(), self.acc.data_ptr(), self.done.data_ptr(),
+                                              self.log_pe.data_ptr(), self.log_ke.data_ptr(), self.counter.data_ptr(), self.log_capacity,
+                                              self.last.data_ptr(), st))
+
     def step_verlet(self):  # velocity Verlet (the reference's NVE check uses OpenMM's VerletIntegrator, test_agbnp.py:57)
         if self.fused:
             return self._step_fused(1)
@@ -213,8 +240,11 @@ class DeviceMD:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _ in range(steps):
-                    step()
+                if self.fused and steps > 1 and kind in ("langevin", "verlet"):
+                    self._steps_fused(0 if kind == "langevin" else 1, steps)
+                else:
+                    for _ in range(steps):
+                        step()
             torch.cuda.synchronize()
             # the capture itself does not run the steps, the warm-up did: put the state back
             for dst, src in zip((self.x, self.v, self.frc, self.last), state):
