@@ -85,8 +85,13 @@ int agbnp_hip_execute_device(agbnp_hip_context* ctx, const double* d_positions, 
  *                     padded_num_atoms words [x | y | z] in context order; forces are ADDED with integer atomics
  *   d_energy_buffer   the context's energy accumulator, double (energy_is_double) or float; the energy is ADDED to
  *                     element energy_slot; NULL = no energy output
- * Two adapter launches around the seven of agbnp_hip_execute_device; same asynchronous contract, same overflow
- * contract (a withheld evaluation adds nothing to the context's buffers), same agbnp_hip_finish(). */
+ * The same launches as agbnp_hip_execute_device: the engine's first kernel reads posq itself and its last writes the
+ * context's buffers.  For that the engine keeps maps of the context's atom order (particle -> slot), built by one small launch
+ * when a d_atom_index array is first seen.  OpenMM reorders its atoms now and then (same array, new contents): the first
+ * kernel checks the maps against d_atom_index in every evaluation, so the first evaluation after a reorder is WITHHELD
+ * like one that overflowed -- nothing of it reaches the context's buffers, agbnp_hip_finish() / agbnp_hip_wait_verdict()
+ * report it -- the maps are rebuilt in the next call, and the repeat is right.  Same asynchronous contract, same
+ * agbnp_hip_finish(). */
 int agbnp_hip_execute_openmm(agbnp_hip_context* ctx, const void* d_posq, int posq_is_double, const void* d_posq_correction,
                              const int* d_atom_index, int padded_num_atoms, long long* d_force_buffer, void* d_energy_buffer,
                              int energy_is_double, int energy_slot, void* stream);

@@ -40,6 +40,25 @@ __global__ __launch_bounds__(256) void k_adapt_positions(int n, const Real4* __r
   ctx_slot[i] = slot;  // the way back, for the output side (k_outputs adds the forces at the context's slot itself)
 }
 
+// The maps that let k_prep read an OpenMM context's posq itself (OpenmmSource, pair_kernels.h): particle -> slot and heavy
+// index -> slot.  Built when the context's atomIndex array is first seen and again after the engine has found it changed
+// (k_prep checks every particle's entry against atomIndex in every evaluation: kStatOrderStale).
+__global__ __launch_bounds__(256) void k_order_maps(int n, const int* __restrict__ atom_index, const int* __restrict__ a2h,
+                                                   int* __restrict__ ctx_slot, int* __restrict__ hslot) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const int i = atom_index ? atom_index[slot] : slot;
+  if (i < 0 || i >= n) return;  // (not a permutation: the check in k_prep will say so)
+  ctx_slot[i] = slot;
+  const int h = a2h[i];
+  if (h >= 0) hslot[h] = slot;
+}
+
+hipError_t launch_order_maps(int n, const int* atom_index, const int* a2h, int* ctx_slot, int* hslot, hipStream_t st) {
+  hipLaunchKernelGGL(k_order_maps, dim3((n + 255) / 256), dim3(256), 0, st, n, atom_index, a2h, ctx_slot, hslot);
+  return hipGetLastError();
+}
+
 hipError_t launch_adapt_positions(int n, const void* posq, int posq_is_double, const void* correction, const int* atom_index, double* xyz,
                                   int* ctx_slot, hipStream_t st) {
   const dim3 grid((n + 255) / 256), block(256);

@@ -66,6 +66,8 @@ enum StatusWord {
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
   kStatTreeDone = 10,      // tree workgroups of k_tree_cavity that have left (what the Born rows at the launch's tail wait for)
+  kStatOrderStale = 11,    // agbnp_hip_execute_openmm: the context's atom order is not the one the engine's particle -> slot map
+                           // was built for (OpenMM has reordered its atoms): evaluation void, the map is rebuilt, the host repeats
   kStatEvalWords = 12,     // ---- everything below is sticky
   kStatEvalSeq = 12,       // evaluations enqueued since the last agbnp_hip_finish
   kStatBadCount = 13,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
@@ -73,6 +75,7 @@ enum StatusWord {
   kStatStickyAtom = 15,
   kStatStickyPack = 16,
   kStatStickyRow = 17,
+  kStatStickyOrder = 18,
   kStatWords = 20,
   kStatBadBitmap = 20,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,

@@ -167,6 +167,14 @@ struct agbnp_hip_context {
   // agbnp_hip_execute_host's short cut: an evaluation that the pinned status words call complete skips the reads of the
   // device (they are diagnostics) and leaves the log running; the reads are caught up with when somebody asks for a
   // diagnostic, when an evaluation is enqueued through a device-resident entry point, and every 1024 evaluations
+  // agbnp_hip_execute_openmm without an adapter launch: k_prep reads the context's posq through the particle -> slot and heavy
+  // index -> slot maps (d_ctx_slot, d_hslot), built for the atomIndex array at order_ptr and checked on the device in every
+  // evaluation; a context that has reordered its atoms voids ONE evaluation (kStatOrderStale), the maps are rebuilt, the
+  // caller repeats (AGBNP_HIP_ADAPTER_LAUNCH=1: the adapter launch of rounds 1-2 instead)
+  DevBuf<int> d_hslot;
+  bool order_valid = false;
+  const int* order_ptr = nullptr;
+  bool adapter_launch = false;
   int lazy_evals = 0;           // evaluations of execute_host since the log was last read and cleared: the FIRST entries of the
                                 // running log (a device-resident entry point that follows counts on from there; nothing is
                                 // synchronised for the hand-over, so it is safe inside a graph capture)
@@ -739,6 +747,9 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_pos_in.alloc(3 * (size_t)n));
   HIP_TRY(c, c->d_ctx_slot.alloc(std::max(n, 1)));
   HIP_TRY(c, hipMemset(c->d_ctx_slot.p, 0, sizeof(int) * std::max(n, 1)));
+  HIP_TRY(c, c->d_hslot.alloc(std::max(c->nh, 1)));
+  HIP_TRY(c, hipMemset(c->d_hslot.p, 0, sizeof(int) * std::max(c->nh, 1)));
+  c->adapter_launch = getenv("AGBNP_HIP_ADAPTER_LAUNCH") != nullptr && atoi(getenv("AGBNP_HIP_ADAPTER_LAUNCH")) != 0;
   HIP_TRY(c, c->d_force_tmp.alloc(3 * (size_t)n + 1));  // (+ the energy of agbnp_hip_execute_host)
   HIP_TRY(c, c->d_energy_tmp.alloc(1));
   HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * (3 * (size_t)n + 1)));
@@ -880,7 +891,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
   // the last evaluation's own words say whether the diagnostics on the device are those of a complete evaluation
-  c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow]) : c->have_results;
+  c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow] | s[kStatOrderStale]) : c->have_results;
   if (!c->h_report && (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0))  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
   if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
@@ -896,6 +907,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last) ...
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
+  if (s[kStatStickyOrder]) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
   if (s[kStatStickyRow] && !c->rows_disabled) {
     // a neighbour list of the row-form pair stages outgrew what the launches walk of it: they walk twice as much from
     // here on -- or, if that already was the whole stride, the tile kernels take over (other launches either way: a
@@ -1082,8 +1094,25 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   HIP_TRY(c, hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   note_stream(c, stream);
-  // the staging buffers start as zeros (allocation) and every output adapter hands them back as zeros
-  HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, c->d_ctx_slot.p, st));
+  // Input side.  Normally k_prep reads the context's posq itself, through the engine's maps of the context's atom order
+  // (OpenmmSource): they are built when an atomIndex array is first seen (or seen again after the device has found it
+  // changed), one small launch that a steady run never repeats.  AGBNP_HIP_ADAPTER_LAUNCH=1: an adapter launch per
+  // evaluation instead (posq -> xyz in particle order, and the particle -> slot map for the output side).
+  const bool fused = !c->adapter_launch;
+  if (fused) {
+    if (!c->order_valid || c->order_ptr != d_atom_index) {
+      HIP_TRY(c, launch_order_maps(c->n, d_atom_index, c->d_a2h.p, c->d_ctx_slot.p, c->d_hslot.p, st));
+      c->order_valid = true;
+      c->order_ptr = d_atom_index;
+    }
+    c->P.in.posq = d_posq;
+    c->P.in.correction = static_cast<const float4*>(d_posq_correction);
+    c->P.in.is_double = posq_is_double;
+    c->P.in.atom_index = d_atom_index;
+    c->P.in.hslot = c->d_hslot.p;
+  } else {
+    HIP_TRY(c, launch_adapt_positions(c->n, d_posq, posq_is_double, d_posq_correction, d_atom_index, c->d_pos_in.p, c->d_ctx_slot.p, st));
+  }
   // the output side is the engine's own last kernel: forces as fixed point at the context's slots, energy into its
   // accumulator (the kernel arguments are captured by value at launch, so the targets are set for this evaluation only)
   c->P.omm.force_fixed = reinterpret_cast<unsigned long long*>(d_force_buffer);
@@ -1093,6 +1122,7 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   c->P.omm.energy_is_double = energy_is_double;
   c->P.omm.energy_slot = energy_slot;
   const int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, c->d_energy_tmp.p, st);
+  c->P.in = OpenmmSource();
   c->P.omm = OpenmmTargets();
   return rc;
 }

@@ -19,8 +19,19 @@ struct OpenmmTargets {
   int energy_is_double = 1, energy_slot = 0;
 };
 
+// Where an evaluation's positions come from when the caller is an OpenMM GPU context and the engine's particle -> slot maps
+// are in place (agbnp_hip_execute_openmm without an adapter launch): k_prep reads posq itself.  posq == nullptr: PairArgs::pos.
+struct OpenmmSource {
+  const void* posq = nullptr;          // real4 per SLOT of the context's atom order, double4 or float4
+  const float4* correction = nullptr;  // mixed precision: position = posq + correction
+  int is_double = 0;
+  const int* atom_index = nullptr;     // [padded] slot -> particle (the context's array): what the maps are checked against
+  const int* hslot = nullptr;          // [nh] heavy index -> slot (OpenmmTargets::ctx_slot is the particle -> slot map)
+};
+
 struct PairArgs {
   OpenmmTargets omm;
+  OpenmmSource in;
   int n, nh;
   // ---- per-evaluation input
   const double* pos;  // [3n] caller's positions (nm), atom order

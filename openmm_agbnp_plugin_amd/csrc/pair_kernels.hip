@@ -135,6 +135,32 @@ __device__ __forceinline__ void lut_copy_rest(double2* __restrict__ s_lut, const
   for (int base = 1024; base < lut_entries; base += 1024) lut_store(s_lut, lut_fetch(lut, lut_entries, base), lut_entries, base);
 }
 
+// ---- where a position comes from: the caller's [3n] array, or an OpenMM context's posq (OpenmmSource) ------------------
+struct Pos3 {
+  double x, y, z;
+};
+__device__ __forceinline__ Pos3 slot_position(const PairArgs& P, int slot) {  // as k_adapt_positions reads it (adapter_kernels.hip)
+  if (P.in.is_double) {
+    const double4 p = static_cast<const double4*>(P.in.posq)[slot];
+    return Pos3{p.x, p.y, p.z};
+  }
+  const float4 p = static_cast<const float4*>(P.in.posq)[slot];
+  Pos3 r{(double)p.x, (double)p.y, (double)p.z};
+  if (P.in.correction) {  // mixed precision: position = posq + posqCorrection, both float
+    const float4 c = P.in.correction[slot];
+    r.x += (double)c.x, r.y += (double)c.y, r.z += (double)c.z;
+  }
+  return r;
+}
+__device__ __forceinline__ Pos3 atom_position(const PairArgs& P, int a) {
+  if (P.in.posq) return slot_position(P, P.omm.ctx_slot[a]);
+  return Pos3{P.pos[3 * a], P.pos[3 * a + 1], P.pos[3 * a + 2]};
+}
+__device__ __forceinline__ Pos3 heavy_position(const PairArgs& P, int h) {
+  if (P.in.posq) return slot_position(P, P.in.hslot[h]);
+  return atom_position(P, P.h2a[h]);
+}
+
 // ---- geometry in, accumulators cleared -------------------------------------------------------------------
 // Level-2 neighbour search, one workgroup per 64x64 tile of heavy atoms (I <= J), riding in the k_prep launch (it
 // reads the caller's positions directly, so it does not depend on the rest of k_prep): lane i of every wave tests a
@@ -154,10 +180,10 @@ __device__ void neighbor_tile(const PairArgs& P, int tile) {
   const int J = I + (tile - (I * nhb - I * (I - 1) / 2));
   if (t < 128) {
     const int h = 64 * (t < 64 ? I : J) + (t & 63);
-    const int a = P.h2a[h < P.nh ? h : P.nh - 1];
-    s_x[t] = P.pos[3 * a];
-    s_y[t] = P.pos[3 * a + 1];
-    s_z[t] = P.pos[3 * a + 2];
+    const Pos3 r = heavy_position(P, h < P.nh ? h : P.nh - 1);
+    s_x[t] = r.x;
+    s_y[t] = r.y;
+    s_z[t] = r.z;
   }
   __syncthreads();
   const int li = t & 63, jq = t >> 6, hi = 64 * I + li;
@@ -192,7 +218,10 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     const int a = P.pslot[i];
     double sx = 0.0, sy = 0.0, sz = 0.0;
     int2 sm = make_int2(0, 0);
-    if (a >= 0) sx = P.pos[3 * a], sy = P.pos[3 * a + 1], sz = P.pos[3 * a + 2], sm = P.ameta[a];
+    if (a >= 0) {
+      const Pos3 r = atom_position(P, a);
+      sx = r.x, sy = r.y, sz = r.z, sm = P.ameta[a];
+    }
     // the slot's record for the range-limited stages (a padding slot keeps a harmless position and says so)
     P.prec[i] = make_double4(sx, sy, sz, __hiloint2double(a >= 0 ? 0 : -1, sm.x | ((sm.y & 0x7fff) << 16)));
     P.ys[i] = 0.0;  // GB Y sums arrive through atomics
@@ -215,9 +244,13 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   }
   if (P.fast && !P.gb_rows && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage
     double lo[3], hi[3];
-    for (int d = 0; d < 3; d++) {
-      lo[d] = i < P.n ? P.pos[3 * i + d] : 1e30;
-      hi[d] = i < P.n ? lo[d] : -1e30;
+    {
+      const Pos3 r = atom_position(P, i < P.n ? i : 0);
+      const double rr[3] = {r.x, r.y, r.z};
+      for (int d = 0; d < 3; d++) {
+        lo[d] = i < P.n ? rr[d] : 1e30;
+        hi[d] = i < P.n ? lo[d] : -1e30;
+      }
     }
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; d++) {
@@ -235,7 +268,8 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     // is further than half the skin from where it was then.  (NaN reference positions -- a fresh context -- fail the test.)
     bool moved = false;
     if (i < P.n) {
-      const double rx = P.pos[3 * i] - P.nl_ref[3 * i], ry = P.pos[3 * i + 1] - P.nl_ref[3 * i + 1], rz = P.pos[3 * i + 2] - P.nl_ref[3 * i + 2];
+      const Pos3 r = atom_position(P, i);
+      const double rx = r.x - P.nl_ref[3 * i], ry = r.y - P.nl_ref[3 * i + 1], rz = r.z - P.nl_ref[3 * i + 2];
       moved = !(fma(rz, rz, fma(ry, ry, rx * rx)) <= P.nl_move2);
     }
     if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&P.nl_flag[0], 1);
@@ -248,7 +282,9 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.zero_out[3 * i + 2] = 0.0;
     if (i == 0) P.zero_out[3 * (size_t)P.n] = 0.0;
   }
-  const double x = P.pos[3 * i], y = P.pos[3 * i + 1], z = P.pos[3 * i + 2];
+  if (P.in.posq && P.in.atom_index && P.in.atom_index[P.omm.ctx_slot[i]] != i) P.status[kStatOrderStale] = 1;  // (the context has reordered its atoms)
+  const Pos3 r_i = atom_position(P, i);
+  const double x = r_i.x, y = r_i.y, z = r_i.z;
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
   if (P.rows_on) {
     P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
@@ -359,7 +395,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         // role runs exactly once per evaluation, after the tree stage.
         const int node = P.status[kStatNodeOverflow], atom = P.status[kStatAtomOverflow], pack = P.status[kStatPackOverflow];
         const int rowo = P.status[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
-        if ((node | atom | pack | rowo) == 0) {
+        const int order = P.status[kStatOrderStale];
+        if ((node | atom | pack | rowo | order) == 0) {
           const double e = o0 + o1 + o2 + o3;
           if (P.omm.force_fixed == nullptr)
             energy_out[0] += e;
@@ -374,6 +411,7 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyAtom] |= atom;
           P.status[kStatStickyPack] |= pack;
           P.status[kStatStickyRow] |= rowo;
+          P.status[kStatStickyOrder] |= order;
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
         if (P.host_status) {  // the host's window on the log (agbnp_hip_poll): the withheld count first, then the running number
@@ -385,7 +423,7 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
 }
 
 __device__ __forceinline__ bool evaluation_overflowed(const int* __restrict__ status) {
-  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow]) != 0;
+  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow] | status[kStatOrderStale]) != 0;
 }
 
 // Bookkeeping for the NEXT evaluation (geometry changes little between MD steps, so this step's subtree shapes

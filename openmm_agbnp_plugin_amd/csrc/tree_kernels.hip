@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
 
 // ---- the forces leave with the last tree launch (TreeOutputs) ------------------------------------------------------
 __device__ __forceinline__ bool evaluation_void(const int* __restrict__ status) {  // an overflowed evaluation adds nothing
-  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow]) != 0;
+  return (status[kStatNodeOverflow] | status[kStatAtomOverflow] | status[kStatPackOverflow] | status[kStatRowOverflow] | status[kStatOrderStale]) != 0;
 }
 __device__ __forceinline__ void add_force(const TreeOutputs& O, int atom, double fx, double fy, double fz) {
   if (O.force_fixed) {

@@ -372,6 +372,72 @@ def test_openmm_context_data_conventions(gpu_required, systems, precision):
     assert abs(e[7] / reps - eo) < (TIGHT if energy_is_double else 2e-3)  # a float accumulator holds 7 digits of 2e3 kJ/mol
 
 
+@pytest.mark.parametrize("adapter_launch", [False, True])
+def test_openmm_context_reorders_its_atoms(gpu_required, systems, monkeypatch, adapter_launch):
+    """OpenMM reorders its atoms now and then: the atomIndex array keeps its address and changes its contents (and posq
+    with it).  agbnp_hip_execute_openmm reads posq through maps of the order it last saw; k_prep checks them against
+    atomIndex in every evaluation, so the first evaluation after a reorder is WITHHELD (nothing reaches the context's
+    buffers), finish() reports it, the maps are rebuilt and the repeat is right.  With AGBNP_HIP_ADAPTER_LAUNCH=1 (an adapter
+    launch per evaluation, rounds 1-2) nothing is withheld."""
+    torch = pytest.importorskip("torch")
+    if adapter_launch:
+        monkeypatch.setenv("AGBNP_HIP_ADAPTER_LAUNCH", "1")
+    s = systems("trpcage")
+    n, padded = s.n, 288
+    rng = np.random.default_rng(9)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    eo, fo = Oracle(*s.params(), version=1).execute(s.pos)
+    dev = torch.device("cuda:0")
+    index = torch.zeros(padded, dtype=torch.int32, device=dev)
+    posq = torch.zeros((padded, 4), dtype=torch.float64, device=dev)
+    fixed = torch.zeros(3 * padded, dtype=torch.int64, device=dev)
+    ebuf = torch.zeros(8, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def reorder():
+        order = rng.permutation(n).astype(np.int32)
+        full = np.concatenate([order, np.arange(n, padded, dtype=np.int32)])
+        index.copy_(torch.tensor(full))  # same address, new contents
+        host = np.zeros((padded, 4))
+        host[:n, :3] = s.pos[order]
+        posq.copy_(torch.tensor(host))
+        return order
+
+    def run():
+        k.execute_openmm(posq.data_ptr(), True, 0, index.data_ptr(), padded, fixed.data_ptr(), ebuf.data_ptr(), True, 0, stream)
+
+    def check(order, evaluations):
+        torch.cuda.synchronize()
+        got = fixed.cpu().numpy().reshape(3, padded).astype(np.float64) / 2.0 ** 32 / evaluations
+        assert np.abs(got[:, :n].T - fo[order]).max() < 1e-6
+        assert abs(ebuf.cpu().numpy()[0] / evaluations - eo) < TIGHT
+        fixed.zero_()
+        ebuf.zero_()
+
+    order = reorder()
+    torch.cuda.synchronize()
+    run()
+    run()
+    assert k.finish(stream) == 0
+    check(order, 2)
+    order = reorder()  # OpenMM's reorderAtoms()
+    torch.cuda.synchronize()
+    run()
+    withheld = k.finish(stream)
+    if adapter_launch:
+        assert withheld == 0
+        check(order, 1)
+    else:
+        assert withheld == 1 and k.withheld() == [0]
+        torch.cuda.synchronize()
+        assert not fixed.cpu().numpy().any() and not ebuf.cpu().numpy().any()  # nothing of the stale evaluation arrived
+    run()
+    run()
+    assert k.finish(stream) == 0
+    check(order, 2)
+
+
 def test_evaluation_is_graph_capturable(gpu_required, systems):
     """One evaluation = seven kernel launches on the caller's stream, no host synchronisation, no allocation after
     the first call: it can be captured into a HIP graph and replayed on new positions (MD inner loops)."""
