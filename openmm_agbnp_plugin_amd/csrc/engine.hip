@@ -227,6 +227,16 @@ double overlap_search_cutoff2(const std::vector<double>& a_large, const std::vec
 int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
   const int n = c->n, nh = c->nh;
   if (changed_only && c->d_heavy.p != nullptr) {
+    if (c->h_xfer) {  // through the pinned staging of the host-facing paths: three copies in front of one wait
+      double* q = c->h_xfer, *a = q + n, *g = a + n;
+      for (int i = 0; i < n; i++) q[i] = c->charge[i], a[i] = c->alpha[i];
+      for (int h = 0; h < nh; h++) g[h] = c->gamma[c->h2a[h]] / kRadiusIncrement;
+      HIP_TRY(c, hipMemcpyAsync(c->d_charge.p, q, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->d_alpha.p, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+      if (nh > 0) HIP_TRY(c, hipMemcpyAsync(c->hrow(kHvGam), g, sizeof(double) * nh, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return AGBNP_HIP_OK;
+    }
     std::vector<double> gam_cav(nh);
     for (int h = 0; h < nh; h++) gam_cav[h] = c->gamma[c->h2a[h]] / kRadiusIncrement;
     HIP_TRY(c, c->d_charge.upload(c->charge));
@@ -1067,10 +1077,7 @@ int agbnp_hip_update_parameters(agbnp_hip_context* c, int n, const double* radiu
   // to learn about withheld evaluations.  (Not hipDeviceSynchronize: that would stall every other context of the device.)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (void* st : c->user_streams) HIP_TRY(c, hipStreamSynchronize((hipStream_t)st));
-  int rc = upload_parameters(c, true);
-  if (rc != AGBNP_HIP_OK) return rc;
-  wire_args(c);
-  return AGBNP_HIP_OK;
+  return upload_parameters(c, true);  // (the arrays are rewritten in place: no kernel argument changes)
 }
 
 int agbnp_hip_execute_device(agbnp_hip_context* c, const double* d_pos, double* d_force, double* d_energy, void* stream) {
