@@ -96,6 +96,11 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* ctx, const void* d_posq, int pos
                              const int* d_atom_index, int padded_num_atoms, long long* d_force_buffer, void* d_energy_buffer,
                              int energy_is_double, int energy_slot, void* stream);
 
+/* Tells the engine that the contents of the d_atom_index array it last saw have changed (OpenMM has reordered its atoms):
+ * the next agbnp_hip_execute_openmm() rebuilds its maps first, and no evaluation is lost to the check.  Optional -- without
+ * it the first evaluation after a reorder is withheld and repeated, see above. */
+int agbnp_hip_atom_order_changed(agbnp_hip_context* ctx);
+
 /* Waits for `stream`, then reads and clears the overflow log.  *must_repeat = the number of evaluations enqueued
  * since the previous agbnp_hip_finish() whose outputs were withheld (0: every one is complete and in the caller's
  * buffers).  If it is not 0 the context has already prepared the repeat (one subtree per workgroup, and the next

@@ -223,6 +223,12 @@ class HipCalcAGBNPForceKernel:
         if rc != _lib.OK:
             raise OpenMMException(_lib.last_error(self._h))
 
+    def atom_order_changed(self):
+        """The context has reordered its atoms (same atomIndex array, new contents): the next execute_openmm() rebuilds the
+        engine's maps first instead of losing one evaluation to the check on the device."""
+        self._need()
+        _lib.load().agbnp_hip_atom_order_changed(self._h)
+
     def finish(self, stream=None):
         """Synchronise and read the device's overflow log: returns the number of evaluations enqueued since the
         previous finish() whose forces and energy were WITHHELD on the device (0 = all complete).  Those must be

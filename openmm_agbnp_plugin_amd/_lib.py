@@ -13,7 +13,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_PARAMETERS, ERR_DEVICE, ERR_CAPACITY, ERR_TIMEOUT 
 # every symbol include/agbnp_hip.h declares
 SYMBOLS = [
     "agbnp_hip_create", "agbnp_hip_update_parameters", "agbnp_hip_execute_host", "agbnp_hip_execute_device",
-    "agbnp_hip_execute_openmm", "agbnp_hip_finish", "agbnp_hip_poll", "agbnp_hip_wait_verdict", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
+    "agbnp_hip_execute_openmm", "agbnp_hip_atom_order_changed", "agbnp_hip_finish", "agbnp_hip_poll", "agbnp_hip_wait_verdict", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
     "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
     "agbnp_hip_set_mode", "agbnp_hip_get_mode", "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
@@ -57,6 +57,7 @@ def load():
     lib.agbnp_hip_execute_host.argtypes = [vp, dp, dp, dp]
     lib.agbnp_hip_execute_device.argtypes = [vp, vp, vp, vp, vp]
     lib.agbnp_hip_execute_openmm.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]
+    lib.agbnp_hip_atom_order_changed.argtypes = [vp]
     lib.agbnp_hip_finish.argtypes = [vp, vp, ip]
     lib.agbnp_hip_poll.argtypes = [vp, ip, ip]
     lib.agbnp_hip_wait_verdict.argtypes = [vp, C.c_int, C.c_double, ip, ip]

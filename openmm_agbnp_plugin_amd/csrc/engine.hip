@@ -1134,6 +1134,12 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   return rc;
 }
 
+int agbnp_hip_atom_order_changed(agbnp_hip_context* c) {
+  if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
+  c->order_valid = false;
+  return AGBNP_HIP_OK;
+}
+
 int agbnp_hip_finish(agbnp_hip_context* c, void* stream, int* must_repeat) {
   if (!c) return AGBNP_HIP_ERR_INVALID_ARGUMENT;
   int dummy = 0;

@@ -95,6 +95,13 @@ void HipCalcAGBNPForceKernel::initialize(const System& system, const AGBNPForce&
 
 void HipCalcAGBNPForceKernel::enqueue() {
   const bool dbl = cu.getUseDoublePrecision(), mixed = cu.getUseMixedPrecision();
+  // OpenMM reorders its atoms now and then (ComputeContext::reorderAtoms: same arrays, new contents).  The engine would find
+  // out by itself -- and repeat one evaluation; the host copy of the order is at hand, so it is told beforehand.
+  const std::vector<int>& order = cu.getAtomIndex();
+  if (order != lastOrder) {
+    if (!lastOrder.empty()) agbnp_hip_atom_order_changed(engine);
+    lastOrder = order;
+  }
   if (agbnp_hip_execute_openmm(engine, cu.getPosq().getDevicePointer(), dbl ? 1 : 0,
                                mixed ? cu.getPosqCorrection().getDevicePointer() : nullptr,
                                static_cast<const int*>(cu.getAtomIndexArray().getDevicePointer()), cu.getPaddedNumAtoms(),

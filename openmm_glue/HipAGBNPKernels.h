@@ -50,6 +50,7 @@ class HipCalcAGBNPForceKernel : public CalcAGBNPForceKernel {
   agbnp_hip_context* engine;
   int checkInterval, sinceCheck;
   bool pollMode = false;
+  std::vector<int> lastOrder;  // the context's atom order at the last enqueue (host copy)
   bool verdictMode = true;
   int sinceFinish = 0;  // verdict mode: evaluations since the last agbnp_hip_finish (one every 1024 keeps the device's log bounded)
   int lateWithheld = 0;

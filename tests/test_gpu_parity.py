@@ -436,6 +436,12 @@ def test_openmm_context_reorders_its_atoms(gpu_required, systems, monkeypatch, a
     run()
     assert k.finish(stream) == 0
     check(order, 2)
+    order = reorder()
+    torch.cuda.synchronize()
+    k.atom_order_changed()  # told beforehand (the glue compares the context's host copy of the order): nothing is lost
+    run()
+    assert k.finish(stream) == 0
+    check(order, 1)
 
 
 def test_evaluation_is_graph_capturable(gpu_required, systems):
