@@ -620,6 +620,7 @@ def main():
                                        "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3)}
         result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
         result["kernel_sum_us"] = round(sum(avg_us.values()), 2)
+        result["launches_per_evaluation"] = len(avg_us)
         result["kernel_event_us"] = {k: round(v, 2) for k, v in raw_us.items()}
         result["event_overhead_us"] = round(event_overhead_us, 2)
 
