@@ -765,8 +765,9 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, hipMemset(c->d_force_tmp.p, 0, sizeof(double) * (3 * (size_t)n + 1)));
   HIP_TRY(c, hipMemset(c->d_energy_tmp.p, 0, sizeof(double)));
   c->h_force_tmp.resize(3 * (size_t)n + 1);
-  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_report), sizeof(agbnp_hip_context::HostReport), hipHostMallocDefault) != hipSuccess) c->h_report = nullptr;
-  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_xfer), sizeof(double) * (6 * (size_t)n + 8), hipHostMallocDefault) != hipSuccess) c->h_xfer = nullptr;
+  const bool pinned = getenv("AGBNP_HIP_NO_PINNED_STAGING") == nullptr;  // (tests: the pageable fall-back of the host-facing paths)
+  if (!pinned || hipHostMalloc(reinterpret_cast<void**>(&c->h_report), sizeof(agbnp_hip_context::HostReport), hipHostMallocDefault) != hipSuccess) c->h_report = nullptr;
+  if (!pinned || hipHostMalloc(reinterpret_cast<void**>(&c->h_xfer), sizeof(double) * (6 * (size_t)n + 8), hipHostMallocDefault) != hipSuccess) c->h_xfer = nullptr;
   (void)hipGetLastError();  // (without pinned memory the host-facing paths fall back to pageable transfers)
   return AGBNP_HIP_OK;
 }

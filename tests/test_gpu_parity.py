@@ -1201,6 +1201,30 @@ def test_entry_points_mixed_at_random_keep_their_books(gpu_required, systems, mo
     assert np.abs(frc.cpu().numpy() - exp_f).max() < 1e-7 * 10
 
 
+def test_host_facing_paths_without_pinned_staging(gpu_required, systems, monkeypatch):
+    """The host-buffer entry point, finish() and update_parameters() fall back to pageable transfers and blocking reads when
+    pinned staging cannot be had (AGBNP_HIP_NO_PINNED_STAGING forces it): same numbers, same overflow protocol."""
+    from oracle import Oracle
+    monkeypatch.setenv("AGBNP_HIP_NO_PINNED_STAGING", "1")
+    s = systems("trpcage")
+    centre = s.pos.mean(axis=0)
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(force)
+    o = Oracle(*s.params(), version=1)
+    f = np.zeros((s.n, 3))
+    for geometry in (s.pos, s.jittered(1), centre + 0.7 * (s.pos - centre), s.jittered(2)):  # (the third outgrows the smallest store)
+        f[:] = 0.0
+        e = k.execute(geometry, f)
+        assert_close(e, f, *o.execute(geometry))
+    r, g, a, q, h = s.params()
+    force2 = P.AGBNPForce.from_arrays(r, g, a, 0.5 * np.asarray(q), h, version=1)
+    k.copyParametersToContext(force2)
+    f[:] = 0.0
+    e = k.execute(s.pos, f)
+    assert_close(e, f, *Oracle(r, g, a, 0.5 * np.asarray(q), h, version=1).execute(s.pos))
+
+
 def test_wait_verdict_judges_every_evaluation_without_draining_the_stream(gpu_required, systems):
     """agbnp_hip_wait_verdict blocks the HOST until the device has written its verdict on every evaluation enqueued since
     the last finish() -- no synchronisation call of ours in between -- and says how many were withheld: the strict
