@@ -8,29 +8,50 @@ the overlap tree is rebuilt from a different geometry every step, as in MD).
 metric / value : aggregate AGBNP-force-limited ns/day over all replicas at the 1 fs step of the
                  reference's example/1dwc_benchmark.py:20  ( ns/day = 86.4 / ms_per_eval per replica ).
 multi-GPU      : replicas only (the force evaluation does not shard).  One process per
-                 GPU, independent geometries, no data-path collective; RCCL carries only the timing
-                 reduction (MAX of the elapsed time) and the gather of the per-rank records.
+                 GPU, independent geometries, no data-path collective; RCCL carries only the job's
+                 decisions (MAX of {failed, withheld, elapsed}) and the gather of the per-rank records.
 secondary      : on one GPU the same JSON line also carries BASELINE.json's other configurations (trpcage
                  GaussVol, trpcage AGBNP1 with CutoffNonPeriodic 1.2 nm, the 16 608-atom HIV-RT stand-in),
-                 each with its own parity-on-sample figure, and under "other_modes" the timings of the fast
-                 (OpenCL-semantics), fast+single and deterministic modes on the headline workload.  --secondary 0 skips them.
+                 each with its own parity-on-sample figure, under "other_modes" the timings of the fast
+                 (OpenCL-semantics), fast+single and deterministic modes on the headline workload, and what the
+                 headline's protocol never contains: a rebuild evaluation of the neighbour rows and a
+                 2000-step random walk ("drift").  --secondary 0 skips them.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N --steps K --warmup W          # no launcher: this process starts the N ranks itself
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+
+Only the standard library is imported at module level: the self-launching parent of `--gpus N` must never touch the
+GPU (it starts N fresh python processes; nothing that has initialised HIP is ever re-exec'ed), so numpy, torch and the
+engine load on first use, in the worker.
 """
 import argparse
+import importlib
 import json
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 
-import openmm_agbnp_plugin_amd as P  # noqa: E402  (loads the HIP runtime shared with torch)
+class _Lazy:
+    """A module that is imported when somebody first asks it for something."""
+
+    def __init__(self, name):
+        self.__dict__["_name"], self.__dict__["_mod"] = name, None
+
+    def __getattr__(self, attr):
+        if self.__dict__["_mod"] is None:
+            self.__dict__["_mod"] = importlib.import_module(self.__dict__["_name"])
+        return getattr(self.__dict__["_mod"], attr)
+
+
+np = _Lazy("numpy")
+P = _Lazy("openmm_agbnp_plugin_amd")  # (loads the HIP runtime shared with torch)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 SIMDS = 1024           # 256 CUs x 4
@@ -178,21 +199,77 @@ def load_workload(name):
     return P.load_system(name)
 
 
+class HipBackend:
+    """What a worker asks of torch.cuda and of the engine, in one place: one GPU of the node (LOCAL_RANK), device buffers,
+    the stream, the engine's kernel object.  The CPU tests of the multi-process path swap it for a double of the same shape
+    (AGBNP_BENCH_BACKEND_MODULE=<module with a Backend class>): everything else of the worker -- the collectives, the
+    retry / abort decisions, the JSON line -- runs as it does on GPUs."""
+
+    name = "hip"
+
+    def __init__(self, torch, local_rank, collective_backend):
+        self.torch = torch
+        # one process per GPU.  AGBNP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks then
+        # share devices (local rank modulo the device count) and the collectives run on CPU tensors.
+        self.index = local_rank % max(torch.cuda.device_count(), 1) if collective_backend != "nccl" else local_rank
+        torch.cuda.set_device(self.index)
+        self.device = torch.device("cuda", self.index)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def current_stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def stream_scope(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def tensor(self, array, dtype):
+        return self.torch.tensor(array, dtype=dtype, device=self.device).contiguous()
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def random_walk(self, start, steps, sigma, seed):
+        """[steps, n, 3] positions of a cumulative random walk from `start` (independent N(0, sigma) steps per coordinate),
+        made on the device."""
+        torch = self.torch
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        inc = torch.randn((steps,) + tuple(start.shape), dtype=torch.float64, device=self.device, generator=g) * sigma
+        return (torch.cumsum(inc, dim=0) + self.tensor(start, torch.float64)).contiguous()
+
+    def identity(self):
+        props = self.torch.cuda.get_device_properties(self.index)
+        return {"device_index": self.index, "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": int(getattr(props, "pci_bus_id", -1))}
+
+    def kernel(self, mode=None):
+        return P.HipCalcAGBNPForceKernel(device=self.index, mode=mode) if mode else P.HipCalcAGBNPForceKernel(device=self.index)
+
+
 class Replica:
     """One context + its device-resident geometries, forces and energy."""
 
-    def __init__(self, torch, system, version, device, dev_index, steps, seed0, method=None, cutoff=1.0, mode=None, stream=None):
-        self.torch, self.system, self.n = torch, system, system.n
+    def __init__(self, dev, system, version, steps, seed0, method=None, cutoff=1.0, mode=None, stream=None, geometries=None):
+        torch = dev.torch
+        self.dev, self.system, self.n = dev, system, system.n
         force = P.AGBNPForce.from_arrays(*system.params(), version=version)
         force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic if method is None else method)  # example/1dwc_benchmark.py:10
         force.setCutoffDistance(cutoff)
-        self.kernel = P.HipCalcAGBNPForceKernel(device=dev_index, mode=mode) if mode else P.HipCalcAGBNPForceKernel(device=dev_index)
+        self.kernel = dev.kernel(mode)
         self.kernel.initialize(force)
-        self.geoms = np.stack([system.jittered(seed0 + s) for s in range(steps)])
-        self.d_pos = torch.tensor(self.geoms, dtype=torch.float64, device=device).contiguous()
-        self.d_force = torch.zeros((self.n, 3), dtype=torch.float64, device=device)
-        self.d_energy = torch.zeros((1,), dtype=torch.float64, device=device)
-        self.stream = torch.cuda.current_stream().cuda_stream if stream is None else stream.cuda_stream
+        if geometries is None:
+            self.geoms = np.stack([system.jittered(seed0 + s) for s in range(steps)])
+            self.d_pos = dev.tensor(self.geoms, torch.float64)
+        else:  # (device-resident already: the random walk of the drift record)
+            self.geoms, self.d_pos = None, geometries
+        self.d_force = dev.zeros((self.n, 3), torch.float64)
+        self.d_energy = dev.zeros((1,), torch.float64)
+        self.stream = dev.current_stream() if stream is None else stream.cuda_stream
         self.step_bytes = self.n * 3 * 8
 
     def run(self, first, count):
@@ -214,11 +291,11 @@ class Replica:
         """Evaluations until the device has been busy for `seconds`: the first milliseconds after an idle period run at a
         lower clock (the driver's 20-step / 5-warm-up invocation measured 0.1216 ms where 200 steps measured 0.1147).
         Untimed; returns the number of evaluations."""
-        torch, done = self.torch, 0
+        done = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             self.run(0, max(batch, 1))
-            torch.cuda.synchronize()
+            self.dev.synchronize()
             done += max(batch, 1)
         self.kernel.finish(self.stream)  # (a withheld one here is caught by the timed pass's own check)
         return done
@@ -227,19 +304,18 @@ class Replica:
         """Seconds for `count` evaluations, or None if they would not settle.  `agree` (multi-rank runs): the MAX over the
         ranks of the withheld count, a collective that EVERY rank enters after every try -- a rank whose own evaluations were
         all complete repeats with the others instead of walking on to the next collective alone."""
-        torch = self.torch
         agree = agree or (lambda withheld: withheld)
         self.tries = 0
         for _ in range(3):
             self.tries += 1
             self.d_force.zero_()
             self.d_energy.zero_()
-            torch.cuda.synchronize()
+            self.dev.synchronize()
             barrier()
-            torch.cuda.synchronize()
+            self.dev.synchronize()
             t0 = time.perf_counter()
             self.run(first, count)
-            torch.cuda.synchronize()
+            self.dev.synchronize()
             barrier()
             t1 = time.perf_counter()
             # finish() reads the device's sticky overflow log: EVERY one of the timed evaluations is accounted for, not
@@ -257,10 +333,10 @@ class Replica:
         return out
 
 
-def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_evals, method=None, cutoff=1.0, mode=None, **oracle_kw):
+def secondary_entry(dev, name, version, steps, warmup, cpu_evals, method=None, cutoff=1.0, mode=None, **oracle_kw):
     """ms/eval, ns/day and parity-on-sample of another configuration (rank 0, one GPU)."""
     system = load_workload(name)
-    r = Replica(torch, system, version, device, dev_index, steps + warmup, 7000, method=method, cutoff=cutoff, mode=mode)
+    r = Replica(dev, system, version, steps + warmup, 7000, method=method, cutoff=cutoff, mode=mode)
     if not r.settle(warmup):
         raise SystemExit(f"bench: tree capacity did not settle ({name})")
     seconds = r.timed(warmup, steps)
@@ -274,19 +350,97 @@ def secondary_entry(torch, name, version, device, dev_index, steps, warmup, cpu_
     return entry
 
 
-def openmm_entry(torch, name, device, dev_index, steps, warmup):
+def _with_env(overrides, fn):
+    """fn() under environment overrides (the engine reads its knobs when a context is created)."""
+    saved = {k: os.environ.get(k) for k in overrides}
+    os.environ.update(overrides)
+    try:
+        return fn()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def rebuild_entry(dev, name, steps, warmup):
+    """What the headline's protocol never contains: an evaluation that REBUILDS the neighbour rows of the row-form pair
+    stages.  The rows carry a 0.1 nm skin and are rebuilt (on the device, inside the evaluation) when an atom has moved more
+    than half of it; the headline's jittered geometries never do.  Here the same workload runs in a context whose move
+    threshold is zero (AGBNP_HIP_ROW_MOVE=0: same skin, same list lengths, a rebuild at every new geometry) next to a plain
+    context on the same box; the difference is the price of one rebuild."""
+    system = load_workload(name)
+
+    def timed(env):
+        def go():
+            r = Replica(dev, system, 1, steps + warmup, 8000)
+            if not r.settle(warmup):
+                raise SystemExit("bench: tree capacity did not settle (rebuild record)")
+            b0 = int(r.kernel.scalar("row_builds"))
+            seconds = r.timed(warmup, steps)
+            if seconds is None:
+                raise SystemExit("bench: tree capacity did not settle (rebuild record)")
+            return 1e3 * seconds / steps, int(r.kernel.scalar("row_builds")) - b0, int(r.kernel.scalar("rows_on"))
+        return _with_env(env, go)
+
+    plain_ms, plain_builds, rows_on = timed({})
+    if not rows_on:
+        return {"workload": name, "rows_on": 0}
+    rebuild_ms, builds, _ = timed({"AGBNP_HIP_ROW_MOVE": "0"})
+    return {"workload": name, "steps": steps, "plain_eval_ms": plain_ms, "builds_in_plain_timed_region": plain_builds,
+            "rebuild_eval_ms": rebuild_ms, "builds_in_rebuild_timed_region": builds, "rebuild_cost_ms": rebuild_ms - plain_ms,
+            "note": "AGBNP_HIP_ROW_MOVE=0 (rows rebuilt at every new geometry, default skin) against the default context, same box, same geometries"}
+
+
+def drift_entry(dev, name, steps, sigma, warmup=20):
+    """ms per evaluation along a CUMULATIVE random walk (every coordinate of every atom moves by N(0, sigma) per step, no
+    tethers, no force field): atoms drift out of the neighbour rows' skin, so rebuild evaluations -- and the extra
+    slice-tuning rebuild, and the forest re-plans -- fall INSIDE the timed region and are counted.  A random walk drifts
+    faster than thermal motion (which oscillates): an upper bound on the rebuild rate of real MD at that step length."""
+    system = load_workload(name)
+    torch = dev.torch
+    walk = dev.random_walk(system.pos, steps + warmup, sigma, 20261004)
+    r = Replica(dev, system, 1, steps + warmup, 0, geometries=walk)
+    if not r.settle(warmup):
+        raise SystemExit("bench: tree capacity did not settle (drift record)")
+    k = r.kernel
+    b0, p0 = int(k.scalar("row_builds")), int(k.scalar("pack_plans"))
+    # ONE pass, withheld evaluations counted rather than repeated (a walk cannot be re-run from the middle: what a withheld
+    # evaluation costs an MD driver is its repeat, reported beside the time)
+    r.d_force.zero_()
+    r.d_energy.zero_()
+    dev.synchronize()
+    t0 = time.perf_counter()
+    withheld, chunk = 0, 500  # (the overflow log names 2048 evaluations: read it every 500)
+    for first in range(warmup, warmup + steps, chunk):
+        r.run(first, min(chunk, warmup + steps - first))
+        withheld += r.kernel.finish(r.stream)
+    dev.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    disp = (walk[-1] - walk[warmup]).norm(dim=1)
+    return {"workload": name, "steps": steps, "sigma_step_nm": sigma, "ms_per_eval": ms, "ns_day": 86.4 / ms,
+            "builds_in_timed_region": int(k.scalar("row_builds")) - b0, "forest_plans_in_timed_region": int(k.scalar("pack_plans")) - p0,
+            "withheld_evaluations": int(withheld), "rms_displacement_nm": float(torch.sqrt((disp ** 2).mean())),
+            "max_displacement_nm": float(disp.max()), "kernel_variant_at_end": int(k.scalar("variant")),
+            "note": "cumulative random walk from the file coordinates, no tethers; rows rebuilt on the device when an atom has moved "
+                    "more than half the 0.1 nm skin; finish() every 500 evaluations inside the timed region"}
+
+
+def openmm_entry(dev, name, steps, warmup):
     """ms per evaluation through agbnp_hip_execute_openmm (an OpenMM GPU context's conventions: posq in the context's atom
     order + atomIndex, fixed-point force planes, energy buffer) under the host protocols of the glue: a blocking finish()
     after every evaluation (the reference's own protocol: the stream is drained), wait_verdict() after every evaluation
     (as strict -- the host learns whether THIS evaluation was withheld before it goes on -- but it waits for a pinned word
     the device writes when the tree stage has ended, not for the stream), a non-blocking poll() after every evaluation
     (finish only on demand; a withheld evaluation is found late), and a finish every 64 evaluations."""
+    torch = dev.torch
     system = load_workload(name)
     n = system.n
     padded = (n + 31) // 32 * 32
     force = P.AGBNPForce.from_arrays(*system.params(), version=1)
     force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
-    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
+    kernel = dev.kernel()
     kernel.initialize(force)
     rng = np.random.default_rng(3)
     perm = rng.permutation(n)  # context slot -> particle
@@ -294,11 +448,11 @@ def openmm_entry(torch, name, device, dev_index, steps, warmup):
     posq = np.zeros((len(geoms), padded, 4))
     for k, g in enumerate(geoms):
         posq[k, :n, :3] = g[perm]
-    d_posq = torch.tensor(posq, dtype=torch.float64, device=device).contiguous()
-    d_index = torch.tensor(np.concatenate([perm, np.arange(n, padded)]), dtype=torch.int32, device=device)
-    d_force = torch.zeros((3 * padded,), dtype=torch.int64, device=device)
-    d_energy = torch.zeros((64,), dtype=torch.float64, device=device)
-    stream = torch.cuda.current_stream().cuda_stream
+    d_posq = dev.tensor(posq, torch.float64)
+    d_index = dev.tensor(np.concatenate([perm, np.arange(n, padded)]), torch.int32)
+    d_force = dev.zeros((3 * padded,), torch.int64)
+    d_energy = dev.zeros((64,), torch.float64)
+    stream = dev.current_stream()
     step_bytes = padded * 4 * 8
 
     def run(k):
@@ -312,63 +466,63 @@ def openmm_entry(torch, name, device, dev_index, steps, warmup):
                          ("wait_verdict_every_evaluation", lambda k: kernel.wait_verdict()[1] and kernel.finish(stream)),
                          ("poll_every_evaluation", lambda k: kernel.poll()[1] and kernel.finish(stream)),
                          ("finish_every_64", lambda k: (k % 64 == 63) and kernel.finish(stream))):
-        torch.cuda.synchronize()
+        dev.synchronize()
         t0 = time.perf_counter()
         for k in range(warmup, warmup + steps):
             run(k)
             after(k)
-        torch.cuda.synchronize()
+        dev.synchronize()
         out["ms_per_eval_" + label] = 1e3 * (time.perf_counter() - t0) / steps
         kernel.finish(stream)
     return out
 
 
-def md_loop_entry(torch, name, dev_index, steps):
+def md_loop_entry(dev, name, steps):
     """ms per MD step of the loop behind examples/1dwc_benchmark.py (the py3 counterpart of the script the reference's
     ns/day comes from, example/1dwc_benchmark.py:20,29-33): Langevin 300 K, 1 / ps, 1 fs, AGBNP1 + tethers, one step = two
     integrator launches (csrc/md_kernels.hip) around one evaluation, captured once as a HIP graph and replayed; the host
-    reads the overflow log every 1000 steps.  Full-MD ns/day as far as this repository has a force field; the headline
-    `value` stays the force-limited figure."""
+    reads the overflow log every 1000 steps.  Example support, NOT a full force field (no bonded or nonbonded terms): the
+    figure is comparable to nothing the reference produces; the headline `value` stays the force-limited figure."""
     from openmm_agbnp_plugin_amd.md import DeviceMD
     system = load_workload(name)
     force = P.AGBNPForce.from_arrays(*system.params(), version=1)
     force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
-    kernel = P.HipCalcAGBNPForceKernel(device=dev_index)
+    kernel = dev.kernel()
     kernel.initialize(force)
-    md = DeviceMD(system, kernel, k_tether=1.0e5, dt=0.001, temperature=300.0, friction=1.0, device=f"cuda:{dev_index}")
+    md = DeviceMD(system, kernel, k_tether=1.0e5, dt=0.001, temperature=300.0, friction=1.0, device=f"cuda:{dev.index}")
     md.settle()
     md.forces()
     kernel.finish()
     md.run(20, "langevin", check_every=20)
-    torch.cuda.synchronize()
+    dev.synchronize()
     t0 = time.perf_counter()
     missed = md.run(steps, "langevin", check_every=1000)
-    torch.cuda.synchronize()
+    dev.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     return {"workload": name, "script": "examples/1dwc_benchmark.py", "steps": steps, "ms_per_step": ms, "ns_day": 86.4 / ms,
             "steps_without_agbnp_term": int(missed)}
 
 
-def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, warmup):
+def concurrent_replicas_entry(dev, name, replicas, steps, warmup):
     """Aggregate throughput of several INDEPENDENT replicas sharing one GPU, each context on a stream of its own (multiple
     walkers / replica exchange on one device).  The evaluation is bound by dependent latency, not by throughput, so
     kernels of different replicas overlap; this is NOT the headline metric (one replica per GPU), it shows the headroom."""
     system = load_workload(name)
-    streams = [torch.cuda.Stream(device=device) for _ in range(replicas)]
+    streams = [dev.new_stream() for _ in range(replicas)]
     reps = []
     for r, st in enumerate(streams):
-        with torch.cuda.stream(st):
-            rep = Replica(torch, system, 1, device, dev_index, steps + warmup, 9000 + 977 * r, stream=st)
+        with dev.stream_scope(st):
+            rep = Replica(dev, system, 1, steps + warmup, 9000 + 977 * r, stream=st)
             if not rep.settle(warmup):
                 raise SystemExit("bench: tree capacity did not settle (concurrent replicas)")
             reps.append(rep)
-    torch.cuda.synchronize()
+    dev.synchronize()
     for attempt in range(3):
         t0 = time.perf_counter()
         for s in range(warmup, warmup + steps):  # round-robin enqueue: one evaluation of every replica per turn
             for rep in reps:
                 rep.run(s, 1)
-        torch.cuda.synchronize()
+        dev.synchronize()
         t1 = time.perf_counter()
         if not any([rep.kernel.finish(rep.stream) for rep in reps]):  # (a list: every replica's log is read and reset)
             break
@@ -379,131 +533,127 @@ def concurrent_replicas_entry(torch, name, device, dev_index, replicas, steps, w
             "aggregate_ns_day": replicas * 86.4 / ms}
 
 
-def job_max(dist, value, device):
-    """MAX over the ranks of a small non-negative integer (1 rank: the value itself).  THE collective behind every decision
-    that must be the same on all ranks: repeat a timed pass, give up, go on."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return int(value)
-    import torch
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t[0])
+class JobAborted(SystemExit):
+    """Raised by Job.abort: the job has ended on every rank (never caught by Job.run)."""
 
 
-class Phases:
-    """Multi-rank discipline: the ranks run different geometries, so anything can go wrong on one rank alone (an evaluation
-    withheld, a capacity that does not settle, a HIP error).  Every phase runs under `run`, which catches the local failure;
-    `agree_all_ok` is entered by EVERY rank at the same point of the program and returns the job-wide verdict, so either all
-    ranks go on or all leave through `abort` -- no rank is left waiting in a collective that the others never enter."""
+class Job:
+    """Multi-rank discipline.  The ranks run different geometries, so anything can go wrong on one rank alone: an evaluation
+    withheld, a capacity that does not settle, a HIP error.  EVERY collective of the job is therefore the SAME operation --
+    `sync`: the MAX-all-reduce of the three doubles {failed, withheld, seconds} -- entered by every rank at the same points
+    of the program (the barriers around the timed region, the verdict after every try, the end of every phase), and every
+    one of them carries the failure flag.  A rank that fails anywhere (its phase runs under `run`, which catches the
+    exception) raises the flag in the NEXT collective it enters, which is the next collective every other rank enters, of
+    whatever purpose; every rank that sees the flag leaves at once through `abort` without entering another one.  So the
+    k-th collective of one rank always meets the k-th of every other, and nobody waits in a collective that the others never
+    enter.  (Round 3 had a barrier, a withheld vote and a failure vote as three different operations: a failure vote could
+    be consumed as a withheld vote.)  One rank: the same calls, no communication."""
 
     def __init__(self, dist, device, rank):
         self.dist, self.device, self.rank, self.error = dist, device, rank, None
+        self.multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
 
-    def run(self, fn, *a, **kw):
+    def sync(self, withheld=0, seconds=0.0):
+        """-> (MAX withheld, MAX seconds) over the ranks; leaves through abort() if any rank has failed."""
+        vec = [1.0 if self.error is not None else 0.0, float(withheld), float(seconds)]
+        if self.multi:
+            import torch
+            t = torch.tensor(vec, dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            vec = [float(v) for v in t.tolist()]
+        if vec[0] > 0.0:
+            self.abort()
+        return int(vec[1]), vec[2]
+
+    def barrier(self):
+        self.sync()
+
+    def agree(self, withheld):
+        """The job's verdict on a try: how many evaluations the worst rank had withheld."""
+        return self.sync(withheld=1 if withheld else 0)[0]
+
+    def run(self, what, fn, *a, **kw):
+        """fn() of one phase; a failure is kept for the next collective (which ends the job on every rank)."""
         if self.error is not None:
             return None
         try:
             return fn(*a, **kw)
+        except JobAborted:  # (a collective inside the phase saw another rank's failure: the job is over, no more collectives)
+            raise
         except (SystemExit, Exception) as exc:  # noqa: BLE001 -- the failure is reported, then every rank leaves together
-            self.error = f"{type(exc).__name__}: {exc}"
+            self.error = f"{what}: {type(exc).__name__}: {exc}"
             return None
 
-    def agree_all_ok(self, what):
-        failed = job_max(self.dist, 0 if self.error is None else 1, self.device)
-        if failed:
-            self.abort(what)
-        return True
-
-    def abort(self, what):
+    def abort(self):
         if self.rank == 0 or self.error is not None:
-            print(f"bench: rank {self.rank}: {what} failed" + (f" here: {self.error}" if self.error else " on another rank"), file=sys.stderr)
+            print(f"bench: rank {self.rank}: " + (f"failed: {self.error}" if self.error else "another rank failed") + "; the job ends on every rank",
+                  file=sys.stderr, flush=True)
         if self.dist is not None and self.dist.is_initialized():
             self.dist.destroy_process_group()
-        raise SystemExit(1)
+        raise JobAborted(1)
 
 
-def headline_pass(rep, dist, device, W, K, preheat_seconds, phases):
-    """Settle, pre-heat and time the K steps of this rank's replica; every repeat decision is the job's (job_max), so all
+def headline_pass(rep, job, W, K, preheat_seconds):
+    """Settle, pre-heat and time the K steps of this rank's replica; every repeat decision is the job's (Job.agree), so all
     ranks make the same number of tries.  Returns (seconds of this rank, evaluations spent on the pre-heat)."""
-    agree = lambda withheld: job_max(dist, 1 if withheld else 0, device)  # noqa: E731
-
-    def barrier():
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.barrier()
 
     def settle():
-        if not rep.settle(W, agree):
+        if not rep.settle(W, job.agree):
             raise SystemExit("tree capacity did not settle in the warm-up")
         return rep.preheat(preheat_seconds, max(W, 5))
 
-    warm = phases.run(settle)
-    phases.agree_all_ok("warm-up")
+    warm = job.run("warm-up", settle)
+    job.sync()
 
     def timed():
-        seconds = rep.timed(W, K, barrier, agree)
+        seconds = rep.timed(W, K, job.barrier, job.agree)
         if seconds is None:
             raise SystemExit("tree capacity did not settle in the timed pass")
         return seconds
 
-    seconds = phases.run(timed)
-    phases.agree_all_ok("timed pass")
+    seconds = job.run("timed pass", timed)
+    job.sync()
     return seconds, warm
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--system", default="1dwc")
-    ap.add_argument("--cpu-evals", type=int, default=20, help="size of the CPU-baseline sample (0 disables the leg)")
-    ap.add_argument("--secondary", type=int, default=1, help="also time BASELINE.json's other configurations (one GPU only)")
-    ap.add_argument("--mode", default="reference", choices=["reference", "fast", "fast+single", "deterministic"],
-                    help="fast = the OpenCL platform's semantics (cutoff on every pair stage); deterministic = bit-reproducible "
-                         "sums (Reference semantics); each printed as its own line")
-    ap.add_argument("--preheat-ms", type=float, default=150.0,
-                    help="untimed evaluations before the timed region until the device has been busy this long (clock ramp)")
-    ap.add_argument("--replicas-per-gpu", type=int, default=1,
-                    help="also report the aggregate of R concurrent replicas per GPU (streams of one process); the headline stays 1")
-    args = ap.parse_args()
+def make_backend(torch, local_rank, collective_backend):
+    module = os.environ.get("AGBNP_BENCH_BACKEND_MODULE")  # (CPU tests of the multi-process path: a double of HipBackend)
+    if module:
+        return importlib.import_module(module).Backend(torch, local_rank, collective_backend)
+    return HipBackend(torch, local_rank, collective_backend)
 
+
+def worker(args):
+    """One rank = one replica on one GPU (the whole job when --gpus 1)."""
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and env_world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} ranks (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={env_world}")
-    # one process per GPU.  AGBNP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks:
-    # ranks then share devices (local_rank modulo the device count) and the two tiny collectives run on CPU tensors.
     backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    coll_device = device if backend == "nccl" else torch.device("cpu")
+    dev = make_backend(torch, local_rank, backend)
+    coll_device = dev.device if backend == "nccl" else torch.device("cpu")
     if env_world > 1:
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=dev.device)
         else:
             dist.init_process_group(backend=backend)
     world = dist.get_world_size() if dist.is_initialized() else 1  # what took part, not what the environment promised
     mdist = dist if world > 1 else None
-    phases = Phases(mdist, coll_device, rank)
+    job = Job(mdist, coll_device, rank)
 
     K, W = args.steps, args.warmup
     mode = None if args.mode == "reference" else args.mode
-    system = phases.run(load_workload, args.system)
-    rep = phases.run(lambda: Replica(torch, system, 1, device, dev_index, K + W, 1000 * rank, mode=mode))
-    phases.agree_all_ok("context creation")
+    system = job.run("workload", load_workload, args.system)
+    rep = job.run("context creation", lambda: Replica(dev, system, 1, K + W, 1000 * rank, mode=mode))
+    job.sync()
     n = system.n
     kernel = rep.kernel
-    elapsed_local, warm_evals = headline_pass(rep, mdist, coll_device, W, K, args.preheat_ms * 1e-3, phases)
-    elapsed = max_over_ranks(mdist, elapsed_local, coll_device)
+    elapsed_local, warm_evals = headline_pass(rep, job, W, K, args.preheat_ms * 1e-3)
+    _, elapsed = job.sync(seconds=elapsed_local)  # the job's time is its slowest rank's
     ms_per_step = 1e3 * elapsed / K
-    props = torch.cuda.get_device_properties(dev_index)
-    record = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
-              "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)),
+    record = {"rank": rank, "local_rank": local_rank, **dev.identity(),
               "ms_per_eval": 1e3 * elapsed_local / K, "ns_day": 86.4 / (1e3 * elapsed_local / K), "pid": os.getpid(),
               "timed_tries": rep.tries, "clock_warm_evals": warm_evals}
     per_rank = gather_records(mdist, record, coll_device)
@@ -512,152 +662,273 @@ def main():
     # ---- secondary aggregate: R concurrent replicas per GPU (every rank, same R; the job's time is the slowest rank's)
     per_gpu = None
     if args.replicas_per_gpu > 1:
-        local = phases.run(concurrent_replicas_entry, torch, args.system, device, dev_index, args.replicas_per_gpu, K, W)
-        phases.agree_all_ok("concurrent replicas per GPU")
-        ms_round = max_over_ranks(mdist, local["ms_per_round"], coll_device)
+        local = job.run("concurrent replicas per GPU", concurrent_replicas_entry, dev, args.system, args.replicas_per_gpu, K, W)
+        _, ms_round = job.sync(seconds=local["ms_per_round"] if local else 0.0)
         per_gpu = {"replicas_per_gpu": args.replicas_per_gpu, "ms_per_round_max_over_ranks": ms_round,
                    "aggregate_ns_day": world * args.replicas_per_gpu * 86.4 / ms_round,
                    "note": "R independent contexts per GPU on R streams of one process; NOT the headline (one replica per GPU)"}
 
-    result = None
-    if rank == 0:
-        slots = int(kernel.scalar("total_nodes")) + (n - system.nheavy) + 1  # + hydrogen slots + root, as the reference counts
-        b_eval, b_kernel = algorithmic_bytes(n, slots)
-        semantics = {None: "Reference semantics: all pairs",
-                     "fast": "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff",
-                     "fast+single": "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff; GB pair terms in packed FP32",
-                     "deterministic": "Reference semantics: all pairs; DETERMINISTIC mode: quantized order-dependent sums"}[mode]
-        result = {
-            "metric": "AGBNP1 force-eval-limited ns/day (1 fs step), thrombin 1dwc, independent replicas",
-            "value": value, "unit": "ns/day", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": ms_per_step, "force_eval_ms": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 (GB pair terms f32)" if mode == "fast+single" else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.system} (thrombin, {n} atoms, {system.nheavy} heavy) AGBNP1 version=1, "
-                                   f"CutoffNonPeriodic 1.0 nm ({semantics}), one jittered geometry per step "
-                                   "(sigma 0.002 nm), positions/forces/energy resident in HBM",
-                       "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode,
-                       "pair_stage_form": "rows" if int(kernel.scalar("rows_on")) else "tiles"},
-            "clock_warm_evals": warm_evals,
-            "per_replica_ns_day": [round(r["ns_day"], 4) for r in per_rank],
-            "ranks": per_rank,
-            "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in per_rank}),
-            "algorithmic_bytes_per_eval": b_eval,
-            "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
-        }
-        if per_gpu is not None:
-            result["replicas_per_gpu"] = per_gpu
-        if int(kernel.scalar("rows_on")):
-            result["neighbour_rows"] = {"builds_so_far": int(kernel.scalar("row_builds")),
-                                        "entries_per_slice": int(kernel.scalar("row_slice")),
-                                        "note": "rows built with a skin and rebuilt on the device when an atom has moved more than half of it; "
-                                                "the jittered geometries of this protocol stay within it"}
+    # ---- the closing collectives: from here on rank 0 works alone (per-kernel pass, CPU baseline, secondary records) and
+    #      the other ranks are done -- nobody sits in a collective while rank 0 runs twenty seconds of CPU oracle
+    if world > 1:
+        job.sync()
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
+
+    slots = int(kernel.scalar("total_nodes")) + (n - system.nheavy) + 1  # + hydrogen slots + root, as the reference counts
+    b_eval, b_kernel = algorithmic_bytes(n, slots)
+    semantics = {None: "Reference semantics: all pairs",
+                 "fast": "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff",
+                 "fast+single": "FAST mode: OpenCL-platform semantics, every pair stage truncated at the cutoff; GB pair terms in packed FP32",
+                 "deterministic": "Reference semantics: all pairs; DETERMINISTIC mode: quantized order-dependent sums"}[mode]
+    result = {
+        "metric": "AGBNP1 force-eval-limited ns/day (1 fs step), thrombin 1dwc, independent replicas",
+        "value": value, "unit": "ns/day", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": ms_per_step, "force_eval_ms": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64 (GB pair terms f32)" if mode == "fast+single" else "f64", "data": "synthetic",
+        "config": {"workload": f"{args.system} ({'thrombin, ' if args.system == '1dwc' else ''}{n} atoms, {system.nheavy} heavy) AGBNP1 version=1, "
+                               f"CutoffNonPeriodic 1.0 nm ({semantics}), one jittered geometry per step "
+                               "(sigma 0.002 nm), positions/forces/energy resident in HBM",
+                   "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode,
+                   "pair_stage_form": "rows" if int(kernel.scalar("rows_on")) else "tiles"},
+        "clock_warm_evals": warm_evals,
+        "per_replica_ns_day": [round(r["ns_day"], 4) for r in per_rank],
+        "ranks": per_rank,
+        "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in per_rank}),
+        "launcher": os.environ.get("AGBNP_BENCH_LAUNCHER", "torch.distributed.run" if env_world > 1 else "none"),
+        "algorithmic_bytes_per_eval": b_eval,
+        "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
+    }
+    if per_gpu is not None:
+        result["replicas_per_gpu"] = per_gpu
+    if int(kernel.scalar("rows_on")):
+        result["neighbour_rows"] = {"builds_so_far": int(kernel.scalar("row_builds")),
+                                    "entries_per_slice": int(kernel.scalar("row_slice")),
+                                    "note": "rows built with a skin and rebuilt on the device when an atom has moved more than half of it; "
+                                            "the jittered geometries of the headline protocol stay within it (no rebuild inside its timed "
+                                            "region): rebuild_eval_ms and the drift record price what it leaves out"}
 
     # ---- per-kernel durations: same K steps again with a hipEvent in front of every kernel (separate pass so
     #      that the events do not sit inside the timed region above)
-    if rank == 0:
-        kernel.set_profiling(True)
-        rep.run(W, K)
-        if kernel.finish(rep.stream):
-            print("bench: an evaluation of the profiling pass overflowed after the timed pass had settled", file=sys.stderr)
-        times = kernel.kernel_times()
-        kernel.set_profiling(False)
-        raw_us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in times.items() if v[1] > 0}
-        # An interval between two event records holds one kernel plus the cost of the event pair (~2.5 us here).
-        # Without the events the launches run back to back (rocprofv3 trace: < 0.1 us between kernels), so the timed
-        # step is the sum of the kernel durations: the same per-interval overhead is taken off every kernel such that
-        # the sum closes on the measured step time.  (The raw figures are kept in kernel_event_us.)
-        event_overhead_us = max(0.0, (sum(raw_us.values()) - 1e3 * ms_per_step) / max(len(raw_us), 1))
-        avg_us = {k: max(v - event_overhead_us, 0.0) for k, v in raw_us.items()}
-        dominant = max(avg_us, key=avg_us.get)
-        traffic, eval_traffic = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic_pmc.json")
-        if os.path.exists(tfile):
-            try:
-                rec = json.load(open(tfile))
-                if rec.get("system") == args.system:
-                    eval_traffic = rec.get("all_kernels_bytes_per_eval")
-                    if rec.get("kernel") == dominant:
-                        traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        achieved = b_kernel.get(dominant, 0) / (avg_us[dominant] * 1e-6) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                              "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
-        if eval_traffic:  # what really crosses the HBM interface, by the PMC counters of the committed profile
-            result["eval_hbm_fraction_counter_bytes"] = (eval_traffic / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9)
-            if traffic:
-                result["roofline"]["frac_counter_bytes"] = traffic / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS
-        # The roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave holds
-        # its SIMD for 4 cycles at FP64 rate).  Instruction counts: SQ_INSTS_VALU of the committed counter pass where there
-        # is one for this workload, else the hand-read table x the wave-steps this geometry makes the kernels execute.
-        counters, counter_file = counter_valu_instructions(args.system, mode)
-        steps_by_kernel = pair_wave_steps(system, rep.geoms[W])
-        issue = []
-        for kname in ISSUE_BOUND_KERNELS:
-            if kname not in avg_us:
-                continue
-            if counters and kname in counters:
-                valu, source = counters[kname]["valu"], counter_file + ": SQ_INSTS_VALU"
-            elif kname in PAIR_STEP_VALU:
-                valu = sum(steps_by_kernel[kname][kind] * v for kind, (v, _) in PAIR_STEP_VALU[kname].items())
-                source = "hand-read instruction table x wave-steps of this geometry"
-            else:
-                continue
-            bound_us = valu * 4 / SIMDS / (CLOCK_GHZ * 1e3)
-            entry = {"bound": "fp64_issue", "kernel": kname, "valu_instructions": int(valu), "source": source, "cycles_per_instruction": 4,
-                     "bound_us": round(bound_us, 2), "avg_launch_us": round(avg_us[kname], 2),
-                     "frac": round(bound_us / avg_us[kname], 3) if avg_us[kname] > 0 else None}
-            if counters and kname in counters:
-                entry["lds_bank_conflict_share"] = counters[kname]["lds_conflict_share"]
-            issue.append(entry)
-        result["rooflines_issue"] = issue
-        # speed of light of the evaluation as launched: per kernel the roof that binds it -- vector issue for the pair
-        # kernels, the modelled bytes at the HBM peak for the rest (tree kernels: latency-bound far above that)
-        issue_by_kernel = {e["kernel"]: e["bound_us"] for e in issue}
-        sol = {k: issue_by_kernel.get(k, b_kernel.get(k, 0) / (HBM_PEAK_GBS * 1e9) * 1e6) for k in avg_us}
-        result["speed_of_light_us"] = {"sum": round(sum(sol.values()), 2), "per_kernel": {k: round(v, 2) for k, v in sol.items()},
-                                       "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3)}
-        result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
-        result["kernel_sum_us"] = round(sum(avg_us.values()), 2)
-        result["launches_per_evaluation"] = len(avg_us)
-        result["kernel_event_us"] = {k: round(v, 2) for k, v in raw_us.items()}
-        result["event_overhead_us"] = round(event_overhead_us, 2)
+    kernel.set_profiling(True)
+    rep.run(W, K)
+    if kernel.finish(rep.stream):
+        print("bench: an evaluation of the profiling pass overflowed after the timed pass had settled", file=sys.stderr)
+    times = kernel.kernel_times()
+    kernel.set_profiling(False)
+    raw_us = {k: 1e3 * v[0] / max(v[1], 1) for k, v in times.items() if v[1] > 0}
+    # An interval between two event records holds one kernel plus the cost of the event pair (~2.5 us here).
+    # Without the events the launches run back to back (rocprofv3 trace: < 0.1 us between kernels), so the timed
+    # step is the sum of the kernel durations: the same per-interval overhead is taken off every kernel such that
+    # the sum closes on the measured step time.  (The raw figures are kept in kernel_event_us; the independent check of
+    # the split is the rocprofv3 summary of the same command under profiles/.)
+    event_overhead_us = max(0.0, (sum(raw_us.values()) - 1e3 * ms_per_step) / max(len(raw_us), 1))
+    avg_us = {k: max(v - event_overhead_us, 0.0) for k, v in raw_us.items()}
+    dominant = max(avg_us, key=avg_us.get)
+    traffic, eval_traffic = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic_pmc.json")
+    if os.path.exists(tfile):
+        try:
+            rec = json.load(open(tfile))
+            if rec.get("system") == args.system:
+                eval_traffic = rec.get("all_kernels_bytes_per_eval")
+                if rec.get("kernel") == dominant:
+                    traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    achieved = b_kernel.get(dominant, 0) / (avg_us[dominant] * 1e-6) / 1e9
+    result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                          "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
+    if eval_traffic:  # what really crosses the HBM interface, by the PMC counters of the committed profile
+        result["eval_hbm_fraction_counter_bytes"] = (eval_traffic / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9)
+        if traffic:
+            result["roofline"]["frac_counter_bytes"] = traffic / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    # The roofs that actually bind the pair kernels: vector-instruction issue (every VALU instruction of a wave holds
+    # its SIMD for 4 cycles at FP64 rate).  Instruction counts: SQ_INSTS_VALU of the committed counter pass where there
+    # is one for this workload, else the hand-read table x the wave-steps this geometry makes the kernels execute.
+    counters, counter_file = counter_valu_instructions(args.system, mode)
+    issue = []
+    steps_by_kernel = pair_wave_steps(system, rep.geoms[W]) if any(k in PAIR_STEP_VALU for k in avg_us) else {}
+    for kname in ISSUE_BOUND_KERNELS:
+        if kname not in avg_us:
+            continue
+        if counters and kname in counters:
+            valu, source = counters[kname]["valu"], counter_file + ": SQ_INSTS_VALU"
+        elif kname in PAIR_STEP_VALU:
+            valu = sum(steps_by_kernel[kname][kind] * v for kind, (v, _) in PAIR_STEP_VALU[kname].items())
+            source = "hand-read instruction table x wave-steps of this geometry"
+        else:
+            continue
+        bound_us = valu * 4 / SIMDS / (CLOCK_GHZ * 1e3)
+        entry = {"bound": "fp64_issue", "kernel": kname, "valu_instructions": int(valu), "source": source, "cycles_per_instruction": 4,
+                 "bound_us": round(bound_us, 2), "avg_launch_us": round(avg_us[kname], 2),
+                 "frac": round(bound_us / avg_us[kname], 3) if avg_us[kname] > 0 else None}
+        if counters and kname in counters:
+            entry["lds_bank_conflict_share"] = counters[kname]["lds_conflict_share"]
+        issue.append(entry)
+    result["rooflines_issue"] = issue
+    # speed of light of the evaluation as launched: per kernel the roof that binds it -- vector issue for the pair
+    # kernels, the modelled bytes at the HBM peak for the rest (tree kernels: latency-bound far above that)
+    issue_by_kernel = {e["kernel"]: e["bound_us"] for e in issue}
+    sol = {k: issue_by_kernel.get(k, b_kernel.get(k, 0) / (HBM_PEAK_GBS * 1e9) * 1e6) for k in avg_us}
+    result["speed_of_light_us"] = {"sum": round(sum(sol.values()), 2), "per_kernel": {k: round(v, 2) for k, v in sol.items()},
+                                   "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3)}
+    result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
+    result["kernel_avg_us_note"] = ("hipEvent intervals of a second pass minus one uniform event overhead chosen so that the kernels sum to the "
+                                    "measured step (they do by construction: this is a SPLIT of ms_per_step, not a check of it; the independent "
+                                    "per-kernel durations are the rocprofv3 summary under profiles/)")
+    result["launches_per_evaluation"] = len(avg_us)
+    result["kernel_event_us"] = {k: round(v, 2) for k, v in raw_us.items()}
+    result["event_overhead_us"] = round(event_overhead_us, 2)
 
-    # ---- CPU baseline (rank 0, single replica only)
-    if rank == 0 and world == 1 and args.cpu_evals > 0:
-        evals = min(args.cpu_evals, K)
+    # ---- CPU baseline (rank 0, on a bounded sample of the timed geometries; a smaller one when other replicas ran too)
+    if args.cpu_evals > 0:
+        evals = min(args.cpu_evals if world == 1 else min(args.cpu_evals, 5), K)
         oracle_kw = {"cutoff": 1.0} if mode in ("fast", "fast+single") else {}
         cpu_ms, de, df = cpu_baseline_leg(system, rep.geoms[W:], rep.host_results(W, evals), evals, **oracle_kw)
         result["cpu_baseline"] = {"value": 86.4 / cpu_ms, "unit": "ns/day", "ms_per_eval": cpu_ms, "cores": 1, "kind": "port",
-                                  "sample": f"first {evals} of the {K} timed geometries, single-threaded FP64 oracle (oracle/agbnp_oracle.cpp, g++ -O2)"}
+                                  "sample": f"first {evals} of the {K} timed geometries of rank 0, single-threaded FP64 oracle (oracle/agbnp_oracle.cpp, g++ -O2)"}
         result["parity_on_sample"] = {"max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df,
                                       "tolerance": "single-precision pair terms: no parity bar" if mode == "fast+single" else 1e-4}
 
-    # ---- BASELINE.json's other configurations, bounded (rank 0, one GPU, Reference-semantics run only)
-    if rank == 0 and world == 1 and args.secondary and mode is None and args.system == "1dwc":
+    # ---- BASELINE.json's other configurations, bounded (one GPU, Reference-semantics run only)
+    if world == 1 and args.secondary and mode is None and args.system == "1dwc":
         del rep
+        # what the timed region above never contains: a rebuild evaluation, and the amortised cost of
+        # rebuilds and re-plans along a walk that drifts
+        rb = rebuild_entry(dev, "1dwc", 200, 20)
+        if "neighbour_rows" in result and "rebuild_eval_ms" in rb:
+            result["neighbour_rows"].update({"rebuild_eval_ms": rb["rebuild_eval_ms"], "plain_eval_ms_same_box": rb["plain_eval_ms"],
+                                             "rebuild_cost_ms": rb["rebuild_cost_ms"], "builds_in_rebuild_timed_region": rb["builds_in_rebuild_timed_region"],
+                                             "builds_in_headline_timed_region": rb["builds_in_plain_timed_region"], "rebuild_note": rb["note"]})
+        result["drift"] = drift_entry(dev, "1dwc", args.drift_steps, args.drift_sigma)
         sec = []
         sec.append(dict(config="1: trpcage GaussVol (version 0), NoCutoff",
-                        **secondary_entry(torch, "trpcage", 0, device, dev_index, 200, 20, 20, method=P.AGBNPForce.NoCutoff)))
+                        **secondary_entry(dev, "trpcage", 0, 200, 20, 20, method=P.AGBNPForce.NoCutoff)))
         sec.append(dict(config="2: trpcage AGBNP1 (version 1), CutoffNonPeriodic 1.2 nm",
-                        **secondary_entry(torch, "trpcage", 1, device, dev_index, 200, 20, 20, cutoff=1.2)))
+                        **secondary_entry(dev, "trpcage", 1, 200, 20, 20, cutoff=1.2)))
         sec.append(dict(config="4: HIV-RT stand-in = 2x2x1 lattice of 1dwc (synthetic), AGBNP1",
-                        **secondary_entry(torch, "1dwc_x4", 1, device, dev_index, 40, 6, 1)))
+                        **secondary_entry(dev, "1dwc_x4", 1, 40, 6, 1)))
         result["secondary"] = sec
         # the other evaluation modes on the headline workload (each has a line of its own with --mode; here for the record)
-        result["other_modes"] = [dict(mode=m, **secondary_entry(torch, "1dwc", 1, device, dev_index, 200, 20, 0, cutoff=1.0, mode=m))
+        result["other_modes"] = [dict(mode=m, **secondary_entry(dev, "1dwc", 1, 200, 20, 0, cutoff=1.0, mode=m))
                                  for m in ("fast", "fast+single", "deterministic")]
-        result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(torch, "1dwc", device, dev_index, r, 200, 20) for r in (2, 4)]
-        result["openmm_entry"] = openmm_entry(torch, "1dwc", device, dev_index, 200, 20)
-        result["md_loop"] = md_loop_entry(torch, "1dwc", dev_index, 3000)
+        result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(dev, "1dwc", r, 200, 20) for r in (2, 4)]
+        result["openmm_entry"] = openmm_entry(dev, "1dwc", 200, 20)
+        result["md_loop"] = md_loop_entry(dev, "1dwc", 3000)
 
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    print(json.dumps(result), flush=True)
+    return 0
+
+
+def launch_replicas(args, argv):
+    """`python3 bench.py --gpus N` with no launcher around it: THIS process -- which has imported neither torch nor the
+    engine and never touches a GPU -- starts N fresh python processes, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them; every rank takes device LOCAL_RANK), relays rank 0's
+    standard output (the JSON line), sends the other ranks' to standard error, and returns the worst exit code.  A rank that
+    dies takes the job with it: the others get a grace period to leave by themselves (they do, through Job.abort, if the
+    dead rank reached a collective) and are then terminated.  Nothing that has initialised HIP is ever exec'ed: the
+    children are new processes started from a parent that never loaded the runtime."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                 "AGBNP_BENCH_LAUNCHER": "bench.py self-launch (subprocess per rank)"})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (this pool's driver only supports dmabuf IPC: RCCL needs it)
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def relay(pipe):  # rank 0's JSON line goes to standard output; whatever else a library prints there, to standard error
+        for line in iter(pipe.readline, b""):
+            out = sys.stdout.buffer if line.lstrip().startswith(b"{") else sys.stderr.buffer
+            out.write(line)
+            out.flush()
+
+    relay_thread = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    relay_thread.start()
+
+    def stop(sig, _frame):  # the driver's timeout / Ctrl-C: the ranks go with the parent
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit(128 + sig)
+
+    signal.signal(signal.SIGTERM, stop)
+    signal.signal(signal.SIGINT, stop)
+
+    grace, failed_at = float(os.environ.get("AGBNP_BENCH_GRACE_SECONDS", "30")), None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            print(f"bench: rank(s) {bad} failed; the others have {grace:.0f} s to leave", file=sys.stderr, flush=True)
+        if failed_at is not None and time.monotonic() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    relay_thread.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    worst = max((c if c >= 0 else 128 - c) for c in codes)  # (a rank killed by signal s counts as 128 + s)
+    if worst:
+        print(f"bench: exit codes by rank {codes}", file=sys.stderr, flush=True)
+    return worst
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--system", default="1dwc")
+    ap.add_argument("--cpu-evals", type=int, default=20, help="size of the CPU-baseline sample (0 disables the leg; at most 5 when N > 1)")
+    ap.add_argument("--secondary", type=int, default=1, help="also time BASELINE.json's other configurations (one GPU only)")
+    ap.add_argument("--mode", default="reference", choices=["reference", "fast", "fast+single", "deterministic"],
+                    help="fast = the OpenCL platform's semantics (cutoff on every pair stage); deterministic = bit-reproducible "
+                         "sums (Reference semantics); each printed as its own line")
+    ap.add_argument("--preheat-ms", type=float, default=150.0,
+                    help="untimed evaluations before the timed region until the device has been busy this long (clock ramp)")
+    ap.add_argument("--replicas-per-gpu", type=int, default=1,
+                    help="also report the aggregate of R concurrent replicas per GPU (streams of one process); the headline stays 1")
+    ap.add_argument("--drift-steps", type=int, default=2000, help="evaluations of the random-walk (drift) record")
+    ap.add_argument("--drift-sigma", type=float, default=0.001, help="nm per coordinate and step of that walk")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_replicas(args, argv)  # no launcher around this process: it becomes the launcher (and only that)
+    if args.gpus > 1 and env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} inside a launcher needs WORLD_SIZE={args.gpus} (torch.distributed.run --nproc-per-node {args.gpus}); WORLD_SIZE={env_world}")
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -18,41 +18,47 @@ import openmm_agbnp_plugin_amd as P
 from AGBNPplugin import AGBNPForce, HipCalcAGBNPForceKernel
 from openmm_agbnp_plugin_amd.md import DeviceMD, KB
 
-name = sys.argv[1] if len(sys.argv) > 1 else "1dwc"
-nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-system = P.load_dms(name) if name.endswith(".dms") else P.load_system(name)
 
-force = AGBNPForce()
-force.setNonbondedMethod(AGBNPForce.CutoffNonPeriodic)  # example/1dwc_benchmark.py:10
-force.setCutoffDistance(1.0)
-force.setVersion(1)
-for r, g, a, q, h in zip(*system.params()):
-    force.addParticle(r, g, a, q, bool(h))
-kernel = HipCalcAGBNPForceKernel()
-kernel.initialize(force)
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "1dwc"
+    nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    system = P.load_dms(name) if name.endswith(".dms") else P.load_system(name)
 
-md = DeviceMD(system, kernel, k_tether=1.0e5, dt=0.001, temperature=300.0, friction=1.0)
-md.settle()
-md.forces()
-kernel.finish()
-print(f"{system.name}: {system.n} atoms, AGBNP1 + tethers, Langevin 300 K, 1 fs, engine on {torch.cuda.get_device_name(0)}")
-print('#"Step","Potential Energy (kJ/mole)","Temperature (K)"')
+    force = AGBNPForce()
+    force.setNonbondedMethod(AGBNPForce.CutoffNonPeriodic)  # example/1dwc_benchmark.py:10
+    force.setCutoffDistance(1.0)
+    force.setVersion(1)
+    for r, g, a, q, h in zip(*system.params()):
+        force.addParticle(r, g, a, q, bool(h))
+    kernel = HipCalcAGBNPForceKernel()
+    kernel.initialize(force)
 
-
-def report(m):
-    pot, kin = m.energies(last=1)
-    print(f"{m.steps_done},{pot[0]:.4f},{2.0 * kin[0] / (3 * system.n * KB):.2f}")
+    md = DeviceMD(system, kernel, k_tether=1.0e5, dt=0.001, temperature=300.0, friction=1.0)
+    md.settle()
+    md.forces()
+    kernel.finish()
+    print(f"{system.name}: {system.n} atoms, AGBNP1 + tethers, Langevin 300 K, 1 fs, engine on {torch.cuda.get_device_name(0)}")
+    print('#"Step","Potential Energy (kJ/mole)","Temperature (K)"')
 
 
-md.run(20, "langevin", check_every=20)  # capture + first replays outside the timed region
-torch.cuda.synchronize()
-start = time.perf_counter()
-# every 1000 steps the host reads the engine's overflow log: a replayed step whose trees outgrew their store got NO
-# AGBNP force (outputs are withheld, never partial) and is counted; a production driver would roll back to a checkpoint.
-# (DeviceMD re-captures the graph by itself when the engine raises its capacity variant.)
-missed = md.run(nsteps, "langevin", check_every=1000, on_report=report)
-torch.cuda.synchronize()
-elapsed = time.perf_counter() - start
-if missed:
-    print(f"WARNING: {missed} step(s) ran without the AGBNP term (tree capacity exceeded)")
-print(f"elapsed time={elapsed:.3f}s   {1e3 * elapsed / nsteps:.4f} ms/step   {86.4 * nsteps / (elapsed * 1e3):.1f} ns/day (1 fs steps)")
+    def report(m):
+        pot, kin = m.energies(last=1)
+        print(f"{m.steps_done},{pot[0]:.4f},{2.0 * kin[0] / (3 * system.n * KB):.2f}")
+
+
+    md.run(20, "langevin", check_every=20)  # capture + first replays outside the timed region
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    # every 1000 steps the host reads the engine's overflow log: a replayed step whose trees outgrew their store got NO
+    # AGBNP force (outputs are withheld, never partial) and is counted; a production driver would roll back to a checkpoint.
+    # (DeviceMD re-captures the graph by itself when the engine raises its capacity variant.)
+    missed = md.run(nsteps, "langevin", check_every=1000, on_report=report)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - start
+    if missed:
+        print(f"WARNING: {missed} step(s) ran without the AGBNP term (tree capacity exceeded)")
+    print(f"elapsed time={elapsed:.3f}s   {1e3 * elapsed / nsteps:.4f} ms/step   {86.4 * nsteps / (elapsed * 1e3):.1f} ns/day (1 fs steps)")
+
+
+if __name__ == "__main__":  # (importing the script -- a test collector, say -- runs nothing)
+    main()

@@ -48,7 +48,9 @@ int agbnp_hip_create(agbnp_hip_context** out, int num_particles, const double* r
 /* Replaces ReferenceCalcAGBNPForceKernel::copyParametersToContext (ReferenceAGBNPKernels.cpp:1796-1815):
  * gamma, alpha and charge may change; a changed particle count, radius (squared difference > 1e-6) or
  * heavy->hydrogen flip fails with AGBNP_HIP_ERR_PARAMETERS and the reference's message.
- * Synchronises the device (nothing of this context may be in flight) and rewrites the device copies in place. */
+ * Drains this context's own stream and every caller stream it has enqueued on since the last agbnp_hip_finish() -- not the
+ * device: other contexts keep running -- and rewrites the device copies in place, at unchanged addresses (a captured HIP
+ * graph of this context stays valid). */
 int agbnp_hip_update_parameters(agbnp_hip_context* ctx, int num_particles, const double* radius, const double* gamma,
                                 const double* vdw_alpha, const double* charge, const int* ishydrogen);
 
@@ -62,7 +64,8 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556: forces and energy are ADDED to device
  * buffers, nothing is returned).  d_positions[3N], d_forces[3N], d_energy[1] are FP64 device
  * pointers on the context's device; `stream` is a hipStream_t (NULL = the context's own stream).
- * Asynchronous: seven kernel launches, no host synchronisation, no allocation once the context has run on its
+ * Asynchronous: six kernel launches for version 1 (seven on systems with more heavy atoms than two rounds of resident tree
+ * workgroups, three for version 0), no host synchronisation, no allocation once the context has run on its
  * current capacity variant -- any number of evaluations may be queued, or captured into a HIP graph and replayed,
  * before agbnp_hip_finish().
  *
@@ -110,8 +113,9 @@ int agbnp_hip_atom_order_changed(agbnp_hip_context* ctx);
 int agbnp_hip_finish(agbnp_hip_context* ctx, void* stream, int* must_repeat);
 
 /* Which evaluations the LAST agbnp_hip_finish() found withheld: writes up to `capacity` indices (0 = the first
- * evaluation enqueued through a device-resident entry point after the finish before it; the log names at least the first
- * 1024 of them, later ones are only counted)
+ * evaluation enqueued through a device-resident entry point after the finish before it; the log's bitmap names the first
+ * 2048 evaluations since that finish -- fewer by the agbnp_hip_execute_host calls in between, whose evaluations take the first
+ * entries -- later ones are only counted)
  * and returns their total number (-1: null context). */
 int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, int capacity);
 
@@ -119,7 +123,7 @@ int agbnp_hip_withheld_evaluations(const agbnp_hip_context* ctx, int* indices, i
  * the last agbnp_hip_finish() have COMPLETED on the device and how many of those were withheld, read from pinned host
  * memory that the device writes at the end of every evaluation.  A caller that must not stall its stream every step (an MD
  * loop) polls this after each enqueue and calls agbnp_hip_finish() only when *withheld is non-zero (or now and then: the
- * log names at most 2048 evaluations).  What it learns is at least one evaluation old.  The reference's GPU platform does a
+ * log names the first 2048 evaluations since the last finish, see agbnp_hip_withheld_evaluations).  What it learns is at least one evaluation old.  The reference's GPU platform does a
  * blocking read every step instead (OpenCLAGBNPKernels.cpp:3599-3634).  AGBNP_HIP_ERR_DEVICE: no pinned memory. */
 int agbnp_hip_poll(const agbnp_hip_context* ctx, int* evaluations_completed, int* withheld);
 
@@ -181,6 +185,8 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *            atom has moved more than half the skin; Reference mode, version 1)  10 builds of those rows so far
  *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; every overflow of a packed forest
  *             adds one step of 15 %, sixteen clean plans in a row give one back)  12 evaluations since the packing was planned
+ *          13 entries per slice of a neighbour row (one wave of a row launch walks one slice; tuned on the device)
+ *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation)
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii)
  *          4 / 5 nodes / local atoms of the overlap subtree rooted at the atom (tree shape, capacity planning) */

@@ -65,7 +65,7 @@ enum StatusWord {
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
-  kStatTreeDone = 10,      // tree workgroups of k_tree_cavity that have left (what the Born rows at the launch's tail wait for)
+  kStatSpare = 10,         // (unused)
   kStatOrderStale = 11,    // agbnp_hip_execute_openmm: the context's atom order is not the one the engine's particle -> slot map
                            // was built for (OpenMM has reordered its atoms): evaluation void, the map is rebuilt, the host repeats
   kStatEvalWords = 12,     // ---- everything below is sticky

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -33,7 +34,7 @@ size_t tree_variant_scratch_bytes(int variant);
 int tree_variant_node_cap(int variant);
 int tree_variant_atom_cap(int variant);
 int tree_variant_wgs_per_cu(int variant);
-hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st, int tail_blocks);
+hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 }  // namespace agbnp
 
@@ -119,8 +120,6 @@ struct agbnp_hip_context {
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
   bool fused_outputs = true;   // version 1: the pseudo-volume launch adds the forces itself (AGBNP_HIP_OUTPUT_LAUNCH=1: k_outputs does)
-  bool born_tail = false;      // row form: the Born rows ride at the tail of the cavity launch (AGBNP_HIP_BORN_TAIL=1; experiment)
-  DevBuf<PairArgs> d_pair_args;  // the pair stages' argument block in device memory (what the tail reads)
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
   double skin = 0.1;           // nm; AGBNP_HIP_SKIN
@@ -152,7 +151,7 @@ struct agbnp_hip_context {
   int carried_count = 0, carried_seq = 0;
   bool unfinished = false;      // evaluations enqueued by execute_device / execute_openmm since the last finish
   int enqueued = 0;             // ... how many: what agbnp_hip_wait_verdict waits for (the device numbers them the same way)
-  int last_pack[3] = {0, 0, 0};  // {level, age, clean replans} of the forest packing as of the last harvest
+  int last_pack[4] = {0, 0, 0, 0};  // {level, age, clean replans in a row, plans so far} of the forest packing as of the last harvest
   int* h_status = nullptr;      // pinned, mapped: {evaluations completed, withheld} since the last finish (agbnp_hip_poll)
   // pinned staging of the host-facing paths: what harvest() reads of the device arrives by asynchronous copies in front of
   // ONE stream synchronisation (four blocking reads before); execute_host's positions, forces and energy travel through
@@ -418,7 +417,11 @@ void wire_args(agbnp_hip_context* c) {
       P.egb_part = c->d_egb_part.p;
       P.egb_parts = (int)c->d_egb_part.count;
     }
-    P.nl_move2 = 0.25 * c->skin * c->skin;
+    // an atom further than this from where it was at the last build makes the lists stale: half the skin -- or
+    // AGBNP_HIP_ROW_MOVE (nm; measurement only: 0 rebuilds the lists at every new geometry at the default skin, which is how
+    // bench.py prices a rebuild evaluation)
+    const double move = getenv("AGBNP_HIP_ROW_MOVE") ? std::min(std::max(atof(getenv("AGBNP_HIP_ROW_MOVE")), 0.0), 0.5 * c->skin) : 0.5 * c->skin;
+    P.nl_move2 = move * move;
     P.nl_flag = c->d_nl_flag.p;
     P.row_target = c->row_slice > 0 ? 0 : 2 * c->cus;
     P.nl_ref = c->d_nl_ref.p;
@@ -498,13 +501,6 @@ void wire_args(agbnp_hip_context* c) {
     T.slot_cap = c->slot_cap;
   }
   T.status = c->d_status.p;
-  if (c->rows_capable) {  // the tail of the cavity launch reads the pair stages' arguments from device memory
-    if (c->d_pair_args.p == nullptr) (void)c->d_pair_args.alloc(1);
-    if (c->d_pair_args.p) (void)hipMemcpy(c->d_pair_args.p, &c->P, sizeof(PairArgs), hipMemcpyHostToDevice);
-  }
-  T.pair_dev = c->d_pair_args.p;
-  T.born_tail = 0;
-  T.tree_blocks = 0;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
 }
@@ -718,7 +714,7 @@ int allocate_work(agbnp_hip_context* c) {
   }
   HIP_TRY(c, c->d_status.alloc(kStatTotalWords));
   HIP_TRY(c, hipMemset(c->d_status.p, 0, sizeof(int) * kStatTotalWords));
-  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess)
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)  // (fine-grained: the host sees the device's writes mid-stream)
     c->h_status[0] = c->h_status[1] = c->h_status[2] = c->h_status[3] = 0;
   else
     c->h_status = nullptr;  // (agbnp_hip_poll then reports "unknown")
@@ -786,15 +782,7 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   // workgroups of the tree launches: what the device keeps resident for this variant (they take forests from a queue);
   // fewer if there cannot be that many forests
   const int tree_grid = std::max(1, std::min(c->slot_cap, c->tree_slots[c->variant]));
-  // Born rows at the tail of the cavity launch (TreeArgs): the row form's Born launch is then not launched
-  int tail_blocks = 0;
-  c->P.born_in_tail = 0;
-  if (c->version == 1 && c->P.rows_on && c->born_tail && c->variant <= 3 &&
-      (size_t)2 * c->P.nti * c->P.ntj * (kI4Nodes - 1) * sizeof(double2) <= tree_variant_lds_bytes(c->variant)) {
-    tail_blocks = born_tail_blocks(c->P);
-    c->P.born_in_tail = 1;
-  }
-  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st, tail_blocks));
+  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
@@ -854,6 +842,7 @@ int upload_identity_packing(agbnp_hip_context* c) {
     forest.push_back(0);
     forest.push_back(no_plan);
     forest.push_back(0);  // [slots+5] clean plans in a row since the assumed capacity was last tightened
+    forest.push_back(0);  // [slots+6] packings planned so far (diagnostic: bench.py counts the plans inside a timed region)
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
@@ -871,7 +860,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
     HIP_TRY(c, hipMemcpyAsync(r->status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(r->components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     if (c->rows_capable) HIP_TRY(c, hipMemcpyAsync(r->rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(r->pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(r->pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     // ... and a new log starts behind the reads, in front of the same wait (an empty log is cleared to what it is)
     HIP_TRY(c, hipMemsetAsync(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq), st));
   }
@@ -891,18 +880,18 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
     std::memcpy(c->last_status, c->h_report->status, sizeof(int) * kStatTotalWords);
     std::memcpy(c->last_components, c->h_report->components, sizeof(double) * 4);
     if (c->rows_capable) std::memcpy(c->last_rows, c->h_report->rows, sizeof(int) * 3);
-    std::memcpy(c->last_pack, c->h_report->pack, sizeof(int) * 3);
+    std::memcpy(c->last_pack, c->h_report->pack, sizeof(int) * 4);
   } else {
     HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
     if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 3, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost));
   }
   const int* s = c->last_status;
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
   // the last evaluation's own words say whether the diagnostics on the device are those of a complete evaluation
-  c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow] | s[kStatOrderStale]) : c->have_results;
+  c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow] | s[kStatOrderStale] | s[kStatRowOverflow]) : c->have_results;
   if (!c->h_report && (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0))  // start a new log
     HIP_TRY(c, hipMemset(c->d_status.p + kStatEvalSeq, 0, sizeof(int) * (kStatTotalWords - kStatEvalSeq)));
   if (c->h_status) c->h_status[0] = c->h_status[1] = 0;  // (the stream is idle: nothing writes it now)
@@ -980,10 +969,6 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   c->cutoff = cutoff;
   c->device = device;
   c->fused_outputs = getenv("AGBNP_HIP_OUTPUT_LAUNCH") == nullptr;
-  // (measured on 1dwc, row form: cavity + Born 45.4 + 15.3 us as two launches, 70.7 us as one -- the Born workgroups'
-  // table copies and the three-wave workgroups they inherit from the tree launch cost more than the boundary saves: off
-  // unless asked for)
-  c->born_tail = getenv("AGBNP_HIP_BORN_TAIL") != nullptr && atoi(getenv("AGBNP_HIP_BORN_TAIL")) != 0;
   c->r_vdw.assign(radius, radius + n);
   c->gamma.resize(n);
   c->alpha.assign(vdw_alpha, vdw_alpha + n);
@@ -1205,7 +1190,9 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
           break;
         }
       const volatile int* h = c->h_status;
-      if (h[0] == c->enqueued && h[1] == 0) {
+      const int judged = h[0];
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (judged == c->enqueued && h[1] == 0) {
         c->lazy_evals++;
         for (size_t k = 0; k < n3; k++) forces[k] += h_out[k];
         *energy = h_out[n3];
@@ -1246,6 +1233,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 13: *value = c->last_rows[2]; break;    // entries per slice of a neighbour row (one wave walks a slice)
     case 11: *value = c->last_pack[0]; break;    // forest packing: how far the assumed store capacity is tightened (0 = not)
     case 12: *value = c->last_pack[1]; break;    // ... evaluations since the packing in use was planned
+    case 14: *value = c->last_pack[3]; break;    // ... packings planned so far
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;
@@ -1404,6 +1392,7 @@ int agbnp_hip_poll(const agbnp_hip_context* c, int* evaluations_completed, int* 
   if (!c->h_status) return AGBNP_HIP_ERR_DEVICE;
   const volatile int* h = c->h_status;
   const int done = h[0] - c->lazy_evals;  // (written after the withheld count, behind a system-scope fence; execute_host's own are not the caller's)
+  std::atomic_thread_fence(std::memory_order_acquire);
   if (evaluations_completed) *evaluations_completed = done;
   if (withheld) *withheld = h[1];
   return AGBNP_HIP_OK;
@@ -1420,6 +1409,7 @@ int agbnp_hip_wait_verdict(const agbnp_hip_context* c, int evaluations, double t
     __builtin_ia32_pause();
     if ((++spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds) break;
   }
+  std::atomic_thread_fence(std::memory_order_acquire);  // (the withheld count is read AFTER the running number that vouches for it)
   if (evaluations_completed) *evaluations_completed = done - c->lazy_evals;
   if (withheld) *withheld = h[1];  // (written before the running number, behind a system-scope fence)
   return done >= target ? AGBNP_HIP_OK : AGBNP_HIP_ERR_TIMEOUT;

@@ -82,7 +82,7 @@ struct PairArgs {
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
-  int* pack_state;         // [3] persistent: how often a packed forest has overflowed (tightens the packing; relaxes again after
+  int* pack_state;         // [4] persistent ([3]: packings planned so far, a diagnostic): how often a packed forest has overflowed (tightens the packing; relaxes again after
                            // clean plans: word [2] counts them); evaluations since
                            // the packing in use was planned (huge = it is no plan: one subtree per slot)
   int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 4)
@@ -132,7 +132,6 @@ struct PairArgs {
   unsigned* nla;           // [groups of 4 heavy atoms x kChainParts][nla_stride] neighbours of any kind, entries as in aperm
   int* nla_count;          // [groups x kChainParts]
   int nla_stride;
-  int born_in_tail;        // 1: the Born rows (and the list builders) ride at the tail of the cavity launch (tree_kernels.hip)
   int gb_rows;             // 1: the GB stage runs in row form too (fast mode: only pairs inside the cutoff are met)
   unsigned* nlg;           // [groups of 4 atoms x kGbParts][nlg_stride] neighbours of any kind within the GB cutoff + skin
   int* nlg_count;          // [groups x kGbParts]
@@ -194,7 +193,6 @@ struct Timeline {
 };
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
-int born_tail_blocks(const PairArgs& P);  // workgroups of three waves that the Born rows + list builders take at the tail of the cavity launch
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl);
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl);

@@ -553,6 +553,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     // (after an overflow the one-subtree-per-slot fallback written below is no plan: the next clean evaluation plans anew)
     if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
     if (plan) P.pack_state[2] = (overflow || relax) ? 0 : P.pack_state[2] + 1;
+    if (plan) P.pack_state[3] += 1;  // (plans so far: a diagnostic)
     if (!plan) {
       P.status[kStatForests] = P.nforests[0];       // (the packing stays)
       P.forest_time[P.tree_slot_cap] = 2;           // tells dealing_role that there is nothing to deal
@@ -1553,7 +1554,7 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
     blk -= 1;
   }
   __shared__ int s_busy;
-  rows_workgroup<KIND, row_waves(KIND), false>(P, blk, s_dyn, &s_busy, 0);
+  rows_workgroup<KIND, row_waves(KIND)>(P, blk, s_dyn, &s_busy);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1643,15 +1644,6 @@ hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   return hipGetLastError();
 }
 
-// Born rows at the tail of the cavity launch: that launch's workgroups are AGBNP_TREE_BLOCK / 64 = 3 waves wide
-constexpr int kTailWaves = AGBNP_TREE_BLOCK / 64;
-int born_tail_blocks(const PairArgs& P) {
-  const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
-  const int walk = (born_groups * kBornParts + kTailWaves - 1) / kTailWaves * ((P.nlh_cap + kRowSlice - 1) / kRowSlice);
-  const int build = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kTailWaves - 1) / kTailWaves;
-  return walk + build;
-}
-
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl) {
   const size_t lds = (size_t)P.lut_entries * sizeof(double2);
   if (lds > 32 * 1024) {  // beyond the default workgroup allowance (k_dborn_tiles adds 22 KB of static tile records and sums)
@@ -1670,11 +1662,9 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     const int build_blocks = (chain_groups * kChainParts + (P.gb_rows ? born_groups * kGbParts : 0) + kRowWaves - 1) / kRowWaves;
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
-    if (!P.born_in_tail) {
-      AGBNP_MARK(kKBornRows);
-      hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
-      AGBNP_CHECK_LAUNCH();
-    }
+    AGBNP_MARK(kKBornRows);
+    hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    AGBNP_CHECK_LAUNCH();
     if (P.gb_rows) {
       AGBNP_MARK(kKGbRows);
       hipLaunchKernelGGL(k_rows<kGbRows>, dim3(1 + gb_blocks), dim3(64 * kGbRowWaves), sizeof(StripSums), st, P, (double*)nullptr, (double*)nullptr, (int)sizeof(StripSums));

@@ -1,5 +1,5 @@
-// Row form of the pair stages (device code shared by k_rows in pair_kernels.hip and, for the Born rows that start at
-// the tail of the tree launch, k_tree_cavity in tree_kernels.hip).  See DESIGN.md s.4e.
+// Row form of the pair stages (device code of k_rows in pair_kernels.hip; rows_close_evaluation is shared with the output
+// side of k_tree_pseudo in tree_kernels.hip).  See DESIGN.md s.4e.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -233,40 +233,21 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
   const int cnt = row_build(A, P.aperm, P.aperm_n, part, L.parts, static_cast<const double4*>(P.aposq), KIND == kGbRows ? P.nlg_build2 : P.nl_build2,
                             L.list + (size_t)sub * L.stride, L.stride, lane);
   if (lane == 0) {
-    L.count[sub] = min(cnt, L.stride);
+    // the length is stored UNtruncated (it may exceed the stride) and clamped where it bounds a walk: every later evaluation
+    // queued before the host reacts sees count > cap above and is withheld too, not just the one that rebuilt the list
+    L.count[sub] = cnt;
     if (cnt > L.cap) P.status[kStatRowOverflow] = 1;
     // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
     append_items<KIND>(P, sub, min(cnt, L.cap), KIND == kGbRows && part == 0);
   }
 }
 
-// Born rows at the tail of the tree launch: their workgroups are dispatched as the tree workgroups leave, do everything
-// that does not need the trees' results (list, table, records) and then wait here until every tree workgroup has
-// counted itself out (kStatTreeDone: one add per workgroup, behind its last atomic).  One lane polls (sc1 load, s_sleep),
-// the workgroup's other waves sit at the barrier.  The wait is bounded: a launch that never gets there withholds the
-// evaluation instead of hanging the device.
-__device__ __forceinline__ void wait_for_producers(const PairArgs& P, int expected) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(&P.status[kStatTreeDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-      __builtin_amdgcn_s_sleep(127);  // (~4 us: a thousand pollers on one word must not crowd the producers' own add)
-      if (++spins > (1 << 19)) {  // (~seconds)
-        P.status[kStatRowOverflow] = 1;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-
 // The work of one workgroup of WAVES waves of a row launch of kind KIND (blk: its number among the launch's row
-// workgroups).  TAIL: the workgroup runs at the tail of the tree launch (Born rows only) and waits for tail_expected tree
-// workgroups before it reads a self volume.
-template <int KIND, int WAVES, bool TAIL>
-__device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, double2* s_dyn, int* s_busy_word, int tail_expected) {
+// workgroups).
+template <int KIND, int WAVES>
+__device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, double2* s_dyn, int* s_busy_word) {
   constexpr int R = kRowGroup;
   static_assert(R == 4, "the butterfly below folds 16 sums");
-  static_assert(!TAIL || KIND == kBornRows, "only the Born rows follow the tree launch");
   int& s_busy = *s_busy_word;  // (a word of the caller's LDS)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const RowLists L = row_lists<KIND>(P);
@@ -318,7 +299,8 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   const int first = rs * slice;
   // Everything that does not depend on anything is asked for at once: the length of the list, the first two steps of the
   // slice (the lists start out zeroed: an entry beyond the length is a valid index), the row atoms and their types, the table.
-  const int listed = L.count[sub];
+  const int listed_raw = L.count[sub];  // (untruncated: beyond the stride for a list that did not fit)
+  const int listed = min(listed_raw, stride);
   unsigned e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   const unsigned types = KIND == kGbRows ? 0u : (KIND == kChainRows ? P.cslice : P.bslice)[group];  // one byte per row
   const RowAtoms A = row_atoms<KIND>(P, group);
@@ -367,7 +349,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     // no wave waits for another workgroup's
     count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
     if (lane == 0 && slice == 0) {
-      P.nlh_count[sub] = min(count, stride);
+      P.nlh_count[sub] = count;  // (untruncated, see build_list)
       if (count > L.cap) P.status[kStatRowOverflow] = 1;
       append_items<kBornRows>(P, sub, min(count, L.cap), false);
     }
@@ -380,7 +362,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
-  if (KIND == kBornRows && active && slice == 0 && lane == 0 && count > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
+  if (KIND == kBornRows && active && slice == 0 && lane == 0 && !stale && listed_raw > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
   const int todo = active ? max(0, min(count - first, rs)) : 0;  // entries of this slice
   const int nsteps = (todo + 63) >> 6;
   double acc[4 * R];
@@ -395,8 +377,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
     // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
     double4 r1 = rec[e1 & 0xffffffu];
-    if (TAIL) wait_for_producers(P, tail_expected);  // (Born rows at the tail of the tree launch: the self volumes must be final)
-    double w1 = TAIL ? __hip_atomic_load(&wsrc[e1 & 0xffffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wsrc[e1 & 0xffffffu];
+    double w1 = wsrc[e1 & 0xffffffu];
     __syncthreads();  // the table is in LDS
     PAIR_STAMP((KIND == kChainRows ? 2 : 0), 8);
     PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
@@ -407,7 +388,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
       const double wb = w1;
       e1 = e2;
       r1 = rec[e1 & 0xffffffu];
-      w1 = TAIL ? __hip_atomic_load(&wsrc[e1 & 0xffffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wsrc[e1 & 0xffffffu];
+      w1 = wsrc[e1 & 0xffffffu];
       e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
       const int b = (int)(e & 0xffffffu);
       const int tent = (int)(e >> 24) * kRowIntervals;

@@ -81,12 +81,6 @@ struct PairArgs;  // (pair_kernels.h)
 
 struct TreeArgs {
   TreeOutputs out;
-  // Born rows at the tail of the cavity launch (row_kernels.h): workgroups behind the tree_blocks forest workgroups walk
-  // the Born rows (and build the later launches' neighbour lists) -- dispatched as the forest workgroups leave, they are
-  // through their loads when the last tree has counted itself out: one launch and one cold start less per evaluation
-  const PairArgs* pair_dev;    // the pair stages' argument block, in device memory (static fields only are read)
-  int born_tail;               // 1: k_tree_cavity carries them
-  int tree_blocks;             // forest workgroups of the cavity launch
   int nh;                      // heavy atoms
   unsigned hstride;            // row stride of the heavy-atom table
   double* hv;                  // [kHvRows][hstride]

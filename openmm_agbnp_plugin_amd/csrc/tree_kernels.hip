@@ -114,10 +114,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;  // hand-off word of the work queue (in LDS for every variant)
   const int tid = threadIdx.x;
-  // forest workgroups of the launch; behind them the Born rows of the pair stages, if the launch carries them (TreeArgs)
-  const int tree_blocks = (!GLOBAL && A.born_tail) ? A.tree_blocks : (int)gridDim.x;
-  if (!GLOBAL && (int)blockIdx.x >= tree_blocks)
-    return rows_workgroup<kBornRows, BS / 64, true>(*A.pair_dev, (int)blockIdx.x - tree_blocks, reinterpret_cast<double2*>(smem), &s_next, tree_blocks);
+  const int tree_blocks = (int)gridDim.x;  // forest workgroups of the launch
   // the row of the workgroup's own work slot is requested before anything is waited for (blockIdx.x < slot_cap: the
   // row exists whether or not the slot is in use)
   int first_item = -1;
@@ -275,13 +272,6 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     } while (false);
     if (!queued) break;
     slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, tree_blocks));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
-  }
-  if (!GLOBAL && A.born_tail) {
-    // count the workgroup out for the Born rows that wait at the launch's tail: behind the last of its atomics (every
-    // wave waits for its own, then the workgroup meets)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&A.status[kStatTreeDone], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -550,12 +540,8 @@ static hipError_t launch_tree(K kernel, int grid, size_t lds, const TreeArgs& A,
 }
 
 // slots: workgroups to launch = min(work slots that may be planned, workgroups the device keeps resident)
-hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A0, hipStream_t st, int tail_blocks) {
-  if (A0.nh <= 0) return hipSuccess;
-  TreeArgs A = A0;
-  A.born_tail = (variant <= 3 && tail_blocks > 0) ? 1 : 0;
-  A.tree_blocks = slots;
-  slots += A.born_tail ? tail_blocks : 0;
+hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st) {
+  if (A.nh <= 0) return hipSuccess;
 #ifdef AGBNP_STAMPS  // diagnostic build only: time the largest subtrees alone (results are incomplete)
   if (const char* env = getenv("AGBNP_DIAG_TREE_GRID"))
     return launch_tree(k_tree_cavity<AGBNP_SMALL_STORE, kBS, false>, std::min(A.nh, atoi(env)), TreeStore<AGBNP_SMALL_STORE>::kBytes, A, st);

@@ -1407,3 +1407,123 @@ def test_two_contexts_on_two_streams_do_not_stall_or_disturb_each_other(gpu_requ
     for w, want in ((0, want_a), (1, want_b)):
         assert abs(ene[w].item() - sum(x[0] for x in want)) < 6 * TIGHT * 10
         assert np.abs(frc[w].cpu().numpy() - sum(x[1] for x in want)).max() < 6 * TIGHT
+
+
+# ---- round 4: what a timed region of jittered geometries never contains ------------------------------------------------
+def _walk(start, steps, sigma, seed):
+    rng = np.random.default_rng(seed)
+    return start[None] + np.cumsum(rng.normal(0.0, sigma, (steps,) + start.shape), axis=0)
+
+
+def _predicted_rebuilds(walk, half_skin=0.05):
+    """Steps at which k_prep finds an atom further than half the skin from where it was at the last build (the first
+    evaluation builds)."""
+    ref, out = None, []
+    for k, pos in enumerate(walk):
+        if ref is None or np.sqrt(((pos - ref) ** 2).sum(axis=1)).max() > half_skin:
+            out.append(k)
+            ref = pos
+    return out
+
+
+def test_random_walk_on_the_device_path_matches_the_oracle_across_rebuilds(gpu_required, systems, monkeypatch):
+    """The drift record of bench.py, checked: evaluations queued through agbnp_hip_execute_device along a cumulative
+    random walk (no tethers), the neighbour rows rebuilt on the device whenever an atom has drifted out of half the skin.
+    Sampled steps -- the first, every kind of rebuild step, the step after a rebuild, a plain one in between, the last --
+    must match the oracle, nothing may be withheld, and the rows must have been rebuilt exactly when predicted."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROW_SLICE", "256")  # (a fixed slice length: no extra build while it is being tuned)
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    steps = 160
+    walk = _walk(s.pos, steps, 0.002, 41)
+    rebuilds = _predicted_rebuilds(walk)
+    assert len(rebuilds) >= 3 and rebuilds[0] == 0, rebuilds
+    sample = sorted({0, 1, rebuilds[1], rebuilds[1] + 1, (rebuilds[1] + rebuilds[2]) // 2, rebuilds[-1], min(rebuilds[-1] + 1, steps - 1), steps - 1})
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(walk, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((len(sample), s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((len(sample), 1), dtype=torch.float64, device=dev)
+    scratch_f = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    scratch_e = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    f0 = np.zeros((s.n, 3))
+    k.execute(walk[0], f0)  # (settles the forest packing; builds the rows at walk[0]: the walk's own step 0 does not rebuild)
+    b0 = int(k.scalar("row_builds"))
+    for step in range(steps):  # ALL queued before one finish, as an MD driver would
+        if step in sample:
+            i = sample.index(step)
+            k.execute_device(pos[step].data_ptr(), frc[i].data_ptr(), ene[i].data_ptr(), stream)
+        else:
+            k.execute_device(pos[step].data_ptr(), scratch_f.data_ptr(), scratch_e.data_ptr(), stream)
+    assert k.finish(stream) == 0, k.withheld()
+    assert k.scalar("rows_on") == 1
+    assert int(k.scalar("row_builds")) - b0 == len(rebuilds) - 1, (rebuilds, b0, k.scalar("row_builds"))
+    got_f, got_e = frc.cpu().numpy(), ene.cpu().numpy()
+    for i, step in enumerate(sample):
+        eo, fo = oracle.execute(walk[step])
+        assert_close(float(got_e[i, 0]), got_f[i], eo, fo)
+
+
+def test_random_walk_small_system_every_step(gpu_required, systems):
+    """trpcage, 300 steps of a faster walk (sigma 0.003 nm), EVERY step against the oracle through the host entry point:
+    rebuild steps, the extra slice-tuning rebuild and forest re-plans included."""
+    s = systems("trpcage")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    oracle = Oracle(*s.params(), version=1)
+    walk = _walk(s.pos, 300, 0.003, 7)
+    worst = 0.0
+    for pos in walk:
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+        worst = max(worst, np.abs(f - fo).max())
+    assert int(k.scalar("row_builds")) >= len(_predicted_rebuilds(walk))
+    assert int(k.scalar("pack_plans")) >= 300 // 4 - 2  # (a healthy packing is planned anew every fourth evaluation)
+
+
+def test_every_queued_evaluation_behind_a_truncated_row_is_withheld(gpu_required, systems, monkeypatch):
+    """a neighbour row that does not fit its stride used to be flagged only in the evaluation that rebuilt it
+    (the stored length was clamped to the stride, so later evaluations saw 'count == cap' and summed a truncated list into
+    the caller's buffers).  The length is now stored untruncated: EVERY evaluation queued before the host reacts is
+    withheld, the buffers stay untouched, and the repeat (on the tile kernels) completes the sums."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
+    monkeypatch.setenv("AGBNP_HIP_ROW_STRIDE", "128")
+    k = P.HipCalcAGBNPForceKernel()
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    monkeypatch.delenv("AGBNP_HIP_ROW_STRIDE")
+    oracle = Oracle(*s.params(), version=1)
+    geoms = [s.jittered(k_) for k_ in range(3)]
+    want = [oracle.execute(g) for g in geoms]
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(3):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 3  # all three, not just the one that rebuilt the rows
+    assert k.withheld() == [0, 1, 2]
+    assert float(frc.abs().max()) == 0.0 and float(ene.abs().max()) == 0.0  # nothing of a truncated list reached the caller
+    with pytest.raises(P.OpenMMException, match="no completed evaluation"):
+        k.vector("born")  # (diagnostics of a void evaluation are not handed out either)
+    for attempt in range(4):
+        for i in range(3):
+            k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+        if k.finish(stream) == 0:
+            break
+        frc.zero_()
+        ene.zero_()
+    else:
+        raise AssertionError("the repeat did not converge")
+    assert k.scalar("rows_on") == 0  # the whole stride was walked already: the tile kernels took over
+    assert abs(ene.item() - sum(w[0] for w in want)) < 3 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 3 * TIGHT

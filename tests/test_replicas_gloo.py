@@ -80,23 +80,27 @@ class _FakeKernel:
         return self.script.pop(0) if self.script else 0
 
 
-def _fake_replica(bench, torch, script):
-    class _Cuda:
+def _fake_replica(bench, torch, script, raise_at=0):
+    class _Dev:
         @staticmethod
         def synchronize():
             pass
 
-    class _Torch:
-        cuda = _Cuda
-
     rep = bench.Replica.__new__(bench.Replica)  # the real settle / preheat / timed logic, no device
-    rep.torch, rep.kernel, rep.stream = _Torch, _FakeKernel(script), None
+    rep.dev, rep.kernel, rep.stream = _Dev, _FakeKernel(script), None
     rep.d_force, rep.d_energy = torch.zeros(3), torch.zeros(1)
-    rep.run = lambda first, count: None
+    rep.runs = 0
+
+    def run(first, count):
+        rep.runs += 1
+        if raise_at and rep.runs == raise_at:
+            raise RuntimeError("scripted HIP error")
+
+    rep.run = run
     return rep
 
 
-def _retry_worker(rank, world, port, out, scripts):
+def _retry_worker(rank, world, port, out, scripts, raise_at):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -105,26 +109,26 @@ def _retry_worker(rank, world, port, out, scripts):
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     dev = torch.device("cpu")
-    rep = _fake_replica(bench, torch, scripts[rank])
-    phases = bench.Phases(dist, dev, rank)
+    rep = _fake_replica(bench, torch, scripts[rank], raise_at.get(rank, 0))
+    job = bench.Job(dist, dev, rank)
     try:
-        seconds, warm = bench.headline_pass(rep, dist, dev, 2, 4, 0.0, phases)
-        elapsed = bench.max_over_ranks(dist, seconds, dev)  # the collective that used to be entered by the fast rank alone
-        dist.barrier()
+        seconds, warm = bench.headline_pass(rep, job, 2, 4, 0.0)
+        _, elapsed = job.sync(seconds=seconds)  # the collective that used to be entered by the fast rank alone
+        job.sync()
         dist.destroy_process_group()
         out.put((rank, "ok", rep.tries, rep.kernel.calls, elapsed > 0))
     except SystemExit as exc:
         out.put((rank, "exit", int(exc.code), rep.kernel.calls, dist.is_initialized()))
 
 
-def _run_world(scripts):
+def _run_world(scripts, raise_at=None):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_retry_worker, args=(r, 2, port, q, scripts)) for r in range(2)]
+    procs = [ctx.Process(target=_retry_worker, args=(r, 2, port, q, scripts, raise_at or {})) for r in range(2)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=120) for _ in procs)
@@ -145,9 +149,79 @@ def test_one_rank_withheld_makes_every_rank_repeat():
 
 
 def test_a_rank_that_never_settles_ends_the_job_on_every_rank():
-    """Rank 1's capacity never settles: its failure is all-reduced, every rank destroys the process group and exits 1 --
-    nobody is left waiting."""
+    """Rank 1's capacity never settles: its failure travels in the next collective, every rank destroys the process group
+    and exits 1 -- nobody is left waiting."""
     results = _run_world({0: [], 1: [1] * 64})
     assert [r[1] for r in results] == ["exit", "exit"], results
     assert [r[2] for r in results] == [1, 1], results
     assert [r[4] for r in results] == [False, False], results  # process group destroyed on both
+
+
+def test_a_rank_that_raises_inside_the_timed_pass_ends_the_job_on_every_rank():
+    """rank 1 fails INSIDE its timed pass (a HIP error between the two barriers) while rank 0 sits in the barrier
+    behind the timed region.  Every collective of the job is the same operation and carries the failure flag, so rank 1's
+    next collective (the end of its phase) meets rank 0's barrier, rank 0 sees the flag there and both leave with exit
+    code 1 -- the vote is not mistaken for a 'withheld' count and nobody enters another collective."""
+    # run() calls of a rank: 1 = settle, 2 = the timed try (the pre-heat of 0 s runs none)
+    results = _run_world({0: [], 1: []}, raise_at={1: 2})
+    assert [r[1] for r in results] == ["exit", "exit"], results
+    assert [r[2] for r in results] == [1, 1], results
+    assert [r[4] for r in results] == [False, False], results
+
+
+# ---- bench.main end to end: `python3 bench.py --gpus 2` with no launcher around it --------------------------------------------
+def _self_launch(extra_env, *flags, timeout=300):
+    import json
+    import subprocess
+
+    env = dict(os.environ, AGBNP_BENCH_BACKEND="gloo", AGBNP_BENCH_BACKEND_MODULE="tests.fake_bench_backend",
+               AGBNP_BENCH_GRACE_SECONDS="20", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--system", "trpcage", "--steps", "6", "--warmup", "2",
+                        "--preheat-ms", "0", *flags], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, [json.loads(ln) for ln in lines]
+
+
+def test_bench_main_self_launches_two_ranks_end_to_end():
+    """The driver's invocation for N > 1 -- `python3 bench.py --gpus N`, no torch.distributed.run -- must work: the parent
+    (which imports neither torch nor the engine) starts the ranks, rank 0's ONE JSON line comes back through it, and the
+    line carries roofline and cpu_baseline like the one-GPU line.  Rank 1 has one evaluation withheld in its first timed try:
+    both ranks repeat."""
+    pytest.importorskip("torch")
+    p, lines = _self_launch({"AGBNP_FAKE_WITHHELD_1": "0,0,1"}, "--cpu-evals", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    r = lines[0]
+    assert r["n_gpus"] == 2 and len(r["ranks"]) == 2 and r["distinct_devices"] == 2
+    assert [x["rank"] for x in r["ranks"]] == [0, 1] and len({x["pid"] for x in r["ranks"]}) == 2
+    assert [x["timed_tries"] for x in r["ranks"]] == [2, 2]
+    assert r["launcher"].startswith("bench.py self-launch")
+    assert r["scaling"] == "weak" and r["unit"] == "ns/day" and r["steps"] == 6 and r["warmup"] == 2
+    assert abs(r["value"] - 2 * 86.4 / r["ms_per_step"]) < 1e-9 * r["value"]
+    assert r["ms_per_step"] >= max(x["ms_per_eval"] for x in r["ranks"]) * (1 - 1e-9)  # the job's time is its slowest rank's
+    assert r["roofline"]["kernel"] == "k_tree_pseudo" and r["roofline"]["bound"] == "hbm"  # (the fake's slowest kernel)
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["ms_per_eval"] > 0
+    assert r["parity_on_sample"]["max_abs_dF_kJmolnm"] == 0.0  # (the fake answers with the oracle itself)
+    assert "secondary" not in r
+
+
+def test_bench_main_a_failing_rank_ends_the_self_launched_job():
+    """A rank that dies mid-pass: the parent returns a non-zero exit code, prints no JSON line and leaves no rank behind."""
+    pytest.importorskip("torch")
+    t0 = __import__("time").time()
+    p, lines = _self_launch({"AGBNP_FAKE_RAISE_1": "4"}, "--cpu-evals", "0")
+    assert p.returncode == 1, (p.returncode, p.stderr[-2000:])
+    assert lines == []
+    assert "fake HIP error" in p.stderr
+    assert __import__("time").time() - t0 < 120
+
+
+def test_the_launching_parent_never_loads_the_gpu_stack():
+    """The self-launcher must not touch the GPU: it imports neither torch nor numpy nor the engine."""
+    import subprocess
+    code = ("import sys; sys.argv = ['bench.py']; import bench; "
+            "print([m for m in ('torch', 'numpy', 'openmm_agbnp_plugin_amd') if m in sys.modules])")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.strip() == "[]", (out.stdout, out.stderr)
