@@ -186,6 +186,9 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; every overflow of a packed forest
  *             adds one step of 15 %, sixteen clean plans in a row give one back)  12 evaluations since the packing was planned
  *          13 entries per slice of a neighbour row (one wave of a row launch walks one slice; tuned on the device)
+ *          15 why the last agbnp_hip_finish() withheld evaluations: 1 a subtree outgrew the store's nodes, 2 its local atoms,
+ *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms;
+ *             bits 8.. the part count of a lone work item that asked for its subtree to be shared further
  *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation)
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii)

@@ -65,7 +65,9 @@ enum StatusWord {
   kStatTotalNodes = 7,     // total nodes (all subtrees)
   kStatPackOverflow = 8,   // a forest of several subtrees did not fit: the packing mispredicted (repeat unpacked)
   kStatForests = 9,        // forests of the evaluation (diagnostic)
-  kStatSpare = 10,         // (unused)
+  kStatSplitWanted = 10,   // a work item that was ALONE in its store outgrew it while its subtree was shared by fewer than four
+                           // items: the largest such part count (0: none).  Counted as a packing overflow: the repeat shares
+                           // the subtree among more items instead of moving the whole system to a larger store
   kStatOrderStale = 11,    // agbnp_hip_execute_openmm: the context's atom order is not the one the engine's particle -> slot map
                            // was built for (OpenMM has reordered its atoms): evaluation void, the map is rebuilt, the host repeats
   kStatEvalWords = 12,     // ---- everything below is sticky
@@ -76,6 +78,7 @@ enum StatusWord {
   kStatStickyPack = 16,
   kStatStickyRow = 17,
   kStatStickyOrder = 18,
+  kStatStickySplit = 19,   // MAX of kStatSplitWanted over those evaluations
   kStatWords = 20,
   kStatBadBitmap = 20,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,

@@ -144,6 +144,9 @@ struct agbnp_hip_context {
   std::vector<int> withheld;   // evaluations (numbered from the previous finish) that the last finish found withheld
   int withheld_count = 0;
   unsigned generation = 1;     // bumped whenever kernel arguments a captured graph has frozen go stale
+  int fallback_parts = 1;      // the packing an overflowed evaluation is repeated on: every subtree shared among this many work items, each
+                               // alone in its slot (1, or 4 once a lone item has outgrown the store; never lowered)
+  bool split_fit = true;       // AGBNP_HIP_SPLIT_FIT=0: a lone subtree that outgrows the store moves the system to the next variant at once
   int tree_slots[5] = {1280, 1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
   int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
   double last_components[4] = {0, 0, 0, 0};
@@ -497,6 +500,9 @@ void wire_args(agbnp_hip_context* c) {
     P.split_big = std::min(std::min(4, c->slot_cap / std::max(c->nh, 1)), std::max(1, split_big));
     P.split_big = std::max(1, P.split_big);
     P.split_permille = std::max(50, split_permille);
+    c->split_fit = !(getenv("AGBNP_HIP_SPLIT_FIT") && atoi(getenv("AGBNP_HIP_SPLIT_FIT")) == 0) && c->slot_cap >= 4 * std::max(c->nh, 1);
+    P.split_fit = c->split_fit ? 1 : 0;
+    T.split_fit = P.split_fit;
     T.packing = c->d_forest.p;
     T.slot_cap = c->slot_cap;
   }
@@ -822,11 +828,17 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   return AGBNP_HIP_OK;
 }
 
-// one subtree per work slot (what a context starts with, and what an overflowed evaluation is repeated on)
+// one work item per work slot (what a context starts with, and what an overflowed evaluation is repeated on): every subtree
+// whole, or -- once a lone subtree has outgrown the store (fallback_parts) -- shared among two or four items
 int upload_identity_packing(agbnp_hip_context* c) {
-  const size_t nhp = std::max(c->nh, 1), nslots = (size_t)c->slot_cap;
-  std::vector<int> ident((size_t)kRowStride * nslots, -1);  // slot s: its one work item (subtree s), -1 = no item, and the number 1
-  for (size_t k = 0; k < nslots; k++) ident[(size_t)kRowStride * k] = (int)std::min(k, nhp - 1), ident[(size_t)kRowStride * k + kMaxItems] = 1;
+  const size_t parts = (size_t)std::max(1, std::min(c->fallback_parts, std::max(1, c->slot_cap / std::max(c->nh, 1))));
+  const size_t nhp = (size_t)std::max(c->nh, 1) * parts, nslots = (size_t)c->slot_cap;
+  std::vector<int> ident((size_t)kRowStride * nslots, -1);  // slot s: its one work item, -1 = no item, and the number 1
+  for (size_t k = 0; k < nslots; k++) {
+    const size_t item = std::min(k, nhp - 1);
+    ident[(size_t)kRowStride * k] = (int)(item / parts) | (int)((item % parts) << 24) | (int)((parts - 1) << 26);  // (work_item_root / _part / _parts)
+    ident[(size_t)kRowStride * k + kMaxItems] = 1;
+  }
   HIP_TRY(c, c->d_rows.upload(ident));
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
   HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
@@ -834,9 +846,10 @@ int upload_identity_packing(agbnp_hip_context* c) {
   // [slots+3] how often a packed forest has overflowed so far (kept), [slots+4] the age of the packing in evaluations
   // (huge: this one is no plan, the next evaluation's bookkeeping plans at once)
   std::vector<int> forest(nslots + 3);  // (+ three persistent words behind it, see below)
-  for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, nhp);
-  forest[nslots + 1] = c->nh;
-  forest[nslots + 2] = c->nh;
+  const int nitems = c->nh > 0 ? (int)nhp : 0;
+  for (size_t k = 0; k <= nslots; k++) forest[k] = (int)std::min(k, (size_t)nitems);
+  forest[nslots + 1] = nitems;
+  forest[nslots + 2] = nitems;
   const int no_plan = 1 << 20;
   if (c->d_forest.p == nullptr) {
     forest.push_back(0);
@@ -903,8 +916,11 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   for (int k = host_first; k < kStatBadBits && k < s[kStatEvalSeq]; k++)
     if (s[kStatBadBitmap + (k >> 5)] & (1 << (k & 31))) c->withheld.push_back(k - host_first);
   *repeat = c->withheld_count;
-  // A repeat must not overflow for the same reason again: it runs one subtree per work slot (the packing of the
-  // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last) ...
+  // A repeat must not overflow for the same reason again: it runs one work item per work slot (the packing of the
+  // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last), and if a lone item
+  // outgrew the store while its subtree was shared by fewer than four, every subtree is shared four ways from here on
+  // (straight to four: one repeat instead of a ladder of them; the fallback only ever runs repeats) ...
+  if (s[kStatStickySplit] > 0) c->fallback_parts = 4;
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
   if (s[kStatStickyOrder]) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
@@ -1174,7 +1190,7 @@ int agbnp_hip_execute_host(agbnp_hip_context* c, const double* pos, double* forc
   double* const h_in = c->h_xfer ? c->h_xfer : nullptr;
   double* const h_out = c->h_xfer ? c->h_xfer + n3 : c->h_force_tmp.data();
   if (h_in) std::memcpy(h_in, pos, bytes);
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < 10; attempt++) {
     HIP_TRY(c, hipMemcpyAsync(c->d_pos_in.p, h_in ? h_in : pos, bytes, hipMemcpyHostToDevice, c->stream));
     c->P.zero_out = c->d_force_tmp.p;  // (cleared by k_prep: the kernel arguments are captured by value at launch)
     int rc = enqueue(c, c->d_pos_in.p, c->d_force_tmp.p, d_energy, c->stream);
@@ -1216,6 +1232,12 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     HIP_TRY(c, hipSetDevice(c->device));
     const int rc_ = catch_up(c);
     if (rc_ != AGBNP_HIP_OK) return rc_;
+  }
+  if (which == 15) {  // why the last agbnp_hip_finish withheld evaluations (valid whether or not an evaluation has completed)
+    const int* s = c->last_status;
+    *value = (s[kStatStickyNode] ? 1 : 0) | (s[kStatStickyAtom] ? 2 : 0) | (s[kStatStickyPack] ? 4 : 0) | (s[kStatStickyRow] ? 8 : 0) |
+             (s[kStatStickyOrder] ? 16 : 0) | (s[kStatStickySplit] << 8);
+    return AGBNP_HIP_OK;
   }
   if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");
   switch (which) {

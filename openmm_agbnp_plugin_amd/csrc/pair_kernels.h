@@ -96,6 +96,7 @@ struct PairArgs {
   int tree_node_cap, tree_atom_cap, pack_enabled;  // capacity of the current tree variant; packing switch
   int tree_slots;          // tree workgroups resident on the device at once (a 'round')
   int split_big, split_permille;  // tuning knobs: parts and node threshold (share of the capacity) for sharing on a full device
+  int split_fit;           // 1: subtrees whose items would not fit the store are shared among up to four items (AGBNP_HIP_SPLIT_FIT=0: off)
   int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 1000: every resident slot)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
   int* status;

@@ -412,6 +412,7 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyPack] |= pack;
           P.status[kStatStickyRow] |= rowo;
           P.status[kStatStickyOrder] |= order;
+          P.status[kStatStickySplit] = max(P.status[kStatStickySplit], P.status[kStatSplitWanted]);
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
         if (P.host_status) {  // the host's window on the log (agbnp_hip_poll): the withheld count first, then the running number
@@ -498,10 +499,25 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const bool roomy = 2 * P.nh <= P.tree_slots;
   const int max_parts = !pack ? 1 : (roomy ? min(4, max(1, P.tree_slot_cap / max(P.nh, 1))) : min(P.split_big, 4));
   const int split_nodes = roomy ? 48 : (int)((float)P.split_permille * 0.001f * share * (float)P.tree_node_cap);
-  auto parts_of = [&](int2 sz) {  // min(max_parts, 1 + nodes / split_nodes), max_parts <= 4
-    return min(max_parts, 1 + (sz.x >= split_nodes ? 1 : 0) + (sz.x >= 2 * split_nodes ? 1 : 0) + (sz.x >= 3 * split_nodes ? 1 : 0));
-  };
   auto inv_parts = [&](int parts) { return parts == 1 ? 1.0f : parts == 2 ? 0.5f : parts == 3 ? (1.0f / 3.0f) : 0.25f; };
+  // Two reasons to share a subtree among several work items.  Speed: min(max_parts, 1 + nodes / split_nodes) (see above).
+  // Fit (whatever the packing mode, also on the fallback after an overflow): an item holds the root, every level-2 node
+  // and its share of the deeper ones; the parts go up, to at most four, until that prediction stays under 85 % of the
+  // store -- so that a system with a few subtrees beyond the smallest store (2clr: 479 nodes) stays on it
+  // instead of moving every forest to the next larger one (four workgroups per CU instead of five).
+  // (the heaviest item of a shared subtree is taken to hold 1.35 x its even share of the deeper nodes; the bound tightens with
+  // the level like everything else here, so repeated mispredictions walk the parts up to four -- beyond which the tree
+  // kernel asks for the next capacity variant)
+  const float fit_nodes = 0.85f * (share * (1.0f / 0.9f)) * (float)P.tree_node_cap;
+  auto parts_of = [&](int2 sz) {
+    int p = min(max_parts, 1 + (sz.x >= split_nodes ? 1 : 0) + (sz.x >= 2 * split_nodes ? 1 : 0) + (sz.x >= 3 * split_nodes ? 1 : 0));
+    if (P.split_fit) {
+      const int l2 = max(sz.y - 1, 0);
+      const float deep = (float)max(sz.x - 1 - l2, 0);
+      while (p < 4 && (float)(1 + l2) + 1.35f * deep * inv_parts(p) > fit_nodes) p++;
+    }
+    return p;
+  };
   auto weight = [&](int2 sz, int parts) -> unsigned {  // of one work item of the subtree, 128..2047
     const int l2 = max(sz.y - 1, 0);
     const float nodes = (float)(1 + l2) + (float)(max(sz.x - 1 - l2, 0) + parts - 1) * inv_parts(parts);

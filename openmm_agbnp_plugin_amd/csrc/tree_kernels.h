@@ -86,6 +86,7 @@ struct TreeArgs {
   double* hv;                  // [kHvRows][hstride]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
+  int split_fit;               // 1: a lone work item that outgrows the store asks for its subtree to be shared (kStatSplitWanted)
   const int* rows;             // [kRowStride * slots] work items: item k of work slot s at kRowStride * s + k, their number at + kMaxItems
   const int* packing;          // [slot_cap + 1] forest_start (bookkeeping's own),
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's
@@ -133,6 +134,14 @@ enum RootWord {
 __host__ __device__ inline int work_item_root(int e) { return e & 0xffffff; }
 __host__ __device__ inline int work_item_part(int e) { return (e >> 24) & 3; }
 __host__ __device__ inline int work_item_parts(int e) { return ((e >> 26) & 3) + 1; }
+// Which work item of a subtree shared `parts` ways expands the level-2 node of sorted rank r: the parts in serpentine order
+// (0, 1, .., p-1, p-1, .., 1, 0, 0, 1, ..).  A level-2 node pairs with its YOUNGER siblings only, so the branch under rank r
+// shrinks quickly with r; plain residue classes (r mod p) give item 0 the largest branch of every group of p, the serpentine
+// evens that out (what matters when a subtree is shared so that its items FIT the store, round 4).
+__host__ __device__ inline int level2_owner(int r, int parts) {
+  const int m2 = r % (2 * parts);
+  return m2 < parts ? m2 : 2 * parts - 1 - m2;
+}
 
 
 // ---- LDS / scratch carve-out -----------------------------------------------------------------
@@ -669,7 +678,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     auto owned_level2 = [&](int k) {
       if (L != 2) return true;
       const int q = S.npar[k], pp = S.rt[kRtPart + q];
-      return ((k - S.rt[kRtBase + q]) % (pp >> 8)) == (pp & 0xff);
+      return level2_owner(k - S.rt[kRtBase + q], pp >> 8) == (pp & 0xff);
     };
     for (int nb = lb; nb < le;) {
       // phase 0: one node per lane -> number of younger siblings = tasks, their prefix sum, the task -> node byte
@@ -888,7 +897,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
         const int par = S.npar[n];
         if (par < m) {
           const int pp = S.rt[kRtPart + par];
-          if (((n - S.rt[kRtBase + par]) % (pp >> 8)) != (pp & 0xff)) {
+          if (level2_owner(n - S.rt[kRtBase + par], pp >> 8) != (pp & 0xff)) {
             path[n] = (unsigned long long)par << 56;
             S.nd[3][n] = 0.0;
             S.wrow[n] = 0.0;

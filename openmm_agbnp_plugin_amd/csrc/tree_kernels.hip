@@ -169,9 +169,14 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
       rc = kBuildNodeOverflow;  // the membership list does not fit: same protocol as a node overflow
     if (rc != kBuildOk) {
       if (tid == 0) {
-        // a forest that does not fit is a packing misprediction (repeat unpacked); a single subtree that does not fit
-        // needs the next capacity variant
-        atomicAdd(&A.status[m > 1 ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
+        // a forest that does not fit is a packing misprediction (repeat unpacked), and so is a lone work item whose nodes
+        // do not fit while its subtree can still be shared among more items (each expands a residue class of the level-2
+        // branches; every item holds all level-2 atoms, so an ATOM overflow is not helped by sharing); a lone item of a
+        // subtree that is shared four ways already needs the next capacity variant
+        const int parts0 = work_item_parts(items[0]);
+        const bool splittable = m == 1 && rc == kBuildNodeOverflow && parts0 < 4 && A.split_fit != 0;
+        atomicAdd(&A.status[(m > 1 || splittable) ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
+        if (splittable) atomicMax(&A.status[kStatSplitWanted], parts0);
         A.hdr[slot].nnodes = 0;
         A.hdr[slot].natoms = 0;
       }

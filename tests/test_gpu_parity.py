@@ -261,13 +261,16 @@ def test_jittered_geometries(gpu_required, systems, name, version, steps):
 
 def test_second_larger_protein(gpu_required, systems):
     """2clr (5983 atoms): its largest subtree (479 nodes) is beyond the 432-node store that five workgroups per CU
-    share, so the engine settles on the (512, 64) variant -- and stays exact on jittered geometries with the forests on."""
+    share.  Round 4: the few subtrees that big are SHARED among several work items (each expands a residue class of the
+    level-2 branches) instead of moving every forest of the system to the (512, 64) store: the engine stays on the
+    smallest variant -- and stays exact on jittered geometries with the forests on."""
     s = systems("2clr")
     e, f, ctx = gpu_eval(s, 1)
     oracle = Oracle(*s.params(), version=1)
     eo, fo = oracle.execute(s.pos)
     assert_close(e, f, eo, fo)
-    assert int(ctx.kernel.scalar("variant")) == 1
+    assert int(ctx.kernel.scalar("variant")) == 0
+    assert int(ctx.kernel.scalar("max_subtree_nodes")) > 432  # (the subtree IS larger than the store)
     for step in range(2):
         pos = s.jittered(step, sigma=0.004)
         ctx.setPositions(pos)
@@ -684,10 +687,12 @@ def test_far_apart_atoms_have_no_overlaps(gpu_required):
     assert int(ctx.kernel.scalar("total_nodes")) == n
 
 
-def test_capacity_escalation_on_dense_fixture(gpu_required, systems):
+def test_capacity_escalation_on_dense_fixture(gpu_required, systems, monkeypatch):
     """platforms/opencl/tests/gaussvol.dat carries radii already enlarged by 0.5 A: subtrees reach 6577 nodes
     and level 8 is populated, far beyond the LDS variants -> the engine must climb to the global-scratch
-    variant on its own (the analogue of the reference OpenCL platform's PanicButton/re-init protocol)."""
+    variant on its own (the analogue of the reference OpenCL platform's PanicButton/re-init protocol).
+    (AGBNP_HIP_SPLIT_FIT=0: without sharing big subtrees, which would stop the climb one variant earlier.)"""
+    monkeypatch.setenv("AGBNP_HIP_SPLIT_FIT", "0")
     s = systems("fixture264_ocl")
     for version in (0, 1):
         e, f, ctx = gpu_eval(s, version)
@@ -820,9 +825,11 @@ def _lattice_cluster(n, spacing, seed, radii, hydrogen_fraction=0.3):
     (180, 0.18, 2, 4, 65),   # 19425 nodes and a subtree with 68 local atoms (a node with more than 63 younger
                              # siblings: the survivor masks of the expansion span several words) -> HBM-scratch variant
 ])
-def test_every_capacity_variant_is_exact(gpu_required, n, spacing, seed, variant, min_local_atoms):
+def test_every_capacity_variant_is_exact(gpu_required, monkeypatch, n, spacing, seed, variant, min_local_atoms):
     """Denser-than-protein clusters land on the larger tree variants; each must give the oracle's numbers, not
-    just be a stepping stone of the capacity negotiation."""
+    just be a stepping stone of the capacity negotiation.  (AGBNP_HIP_SPLIT_FIT=0: every subtree whole, so that each
+    variant's kernels are the ones that run; the sharing of big subtrees has the test below.)"""
+    monkeypatch.setenv("AGBNP_HIP_SPLIT_FIT", "0")
     sysm = _lattice_cluster(n, spacing, seed, [0.17, 0.18, 0.19, 0.2])
     e, f, ctx = gpu_eval(sysm, 1)
     eo, fo = Oracle(*sysm.params(), version=1).execute(sysm.pos)
@@ -834,6 +841,35 @@ def test_every_capacity_variant_is_exact(gpu_required, n, spacing, seed, variant
     o.execute(sysm.pos)
     nheavy = int(np.sum(sysm.ishydrogen == 0))
     assert int(ctx.kernel.scalar("total_nodes")) == nheavy + sum(o.tree_stats()["level_counts"][2:])
+
+
+@pytest.mark.parametrize("n,spacing,seed,whole_variant", [(150, 0.24, 1, 2), (150, 0.22, 1, 3)])
+def test_big_subtrees_are_shared_before_the_variant_is_raised(gpu_required, n, spacing, seed, whole_variant):
+    """The same clusters with the default settings: a lone subtree that outgrows the store is first shared four ways (the
+    repeat runs on the four-way fallback packing, later evaluations on parts planned from the measured shapes); only what
+    does not fit even then moves the system to a larger store.  Exact either way, on a smaller variant than whole subtrees
+    need, and steady: later evaluations are not withheld again."""
+    sysm = _lattice_cluster(n, spacing, seed, [0.17, 0.18, 0.19, 0.2])
+    oracle = Oracle(*sysm.params(), version=1)
+    e, f, ctx = gpu_eval(sysm, 1)
+    eo, fo = oracle.execute(sysm.pos)
+    assert_close(e, f, eo, fo)
+    assert int(ctx.kernel.scalar("variant")) < whole_variant
+    k = ctx.kernel
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    geoms = [sysm.pos + np.random.default_rng(step).normal(0.0, 0.001, sysm.pos.shape) for step in range(6)]
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((sysm.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(6):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0, k.withheld()  # planned packings (shared subtrees, forests) hold from here on
+    want = [oracle.execute(g) for g in geoms]
+    assert abs(ene.item() - sum(w[0] for w in want)) < 6 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 6 * TIGHT
 
 
 def test_forest_packing_and_its_overflow_protocol(gpu_required, systems):
