@@ -39,13 +39,6 @@
 #include "agbnp_common.h"
 #include "device_math.h"
 
-#ifndef AGBNP_PIPE_PHASE0
-#define AGBNP_PIPE_PHASE0 0
-#endif
-#ifndef AGBNP_WORD_TMAP
-#define AGBNP_WORD_TMAP 0
-#endif
-
 namespace agbnp {
 
 // Rows of the heavy-atom table: ONE device allocation [kHvRows][hstride] of doubles, heavy index.  The tree kernels
@@ -422,22 +415,6 @@ __device__ __forceinline__ unsigned long long kept_bits(const unsigned long long
   return m & ((1ull << len) - 1ull);
 }
 
-// the task -> node byte map of a batch: node `tid` owns the bytes [first, first + count).  Word stores between a
-// byte-wise head and tail: the longest sibling list (45 entries at level 2) takes 17 stores instead of 45 -- the loop is
-// serial in the lane and the wave waits for its longest lane.
-__device__ __forceinline__ void fill_task_map(unsigned char* tm, int first, int count, int tid) {
-#if AGBNP_WORD_TMAP
-  int b = first;
-  const int e = first + count;
-  for (; b < e && (b & 3); b++) tm[b] = (unsigned char)tid;
-  const unsigned pat = 0x01010101u * (unsigned)tid;
-  for (; b + 4 <= e; b += 4) *reinterpret_cast<unsigned*>(tm + b) = pat;
-  for (; b < e; b++) tm[b] = (unsigned char)tid;
-#else
-  for (int i = 0; i < count; i++) tm[first + i] = (unsigned char)tid;
-#endif
-}
-
 enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
 
 // ---- build the forest of the heavy atoms roots[0..m) (large radii) -----------------------------------------
@@ -703,165 +680,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       const int q = S.npar[k], pp = S.rt[kRtPart + q];
       return level2_owner(k - S.rt[kRtBase + q], pp >> 8) == (pp & 0xff);
     };
-#if AGBNP_PIPE_PHASE0
-    // Round-4 experiment: phase 0 of batch k+1 (wave 0) rides underneath phase 1 of batch k (the other waves), into a
-    // second set of task-start words / byte map / control words; a level's first batch is set up as before.
-    {
-      unsigned short* const tsA = S.tstart;
-      unsigned short* const tsB = S.cbase;                                      // (idle since phases 2 and 3 are one)
-      unsigned char* const tmA = tmap;
-      unsigned char* const tmB = reinterpret_cast<unsigned char*>(S.at[9]);     // (idle during the build; handed back as zeros)
-      auto phase0_narrow = [&](int nb0, unsigned short* ts, unsigned char* tm, int* out_n, int* out_t) {  // wave 0: up to 64 nodes
-        const int k = nb0 + tid;
-        const bool has = k < le;
-        const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
-        const int incl = wave_inclusive_scan(cnt);
-        const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
-        const int nin = __popcll(__ballot(inb));
-        const int T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
-        if (inb) {
-          const int excl = incl - cnt;
-          ts[tid] = (unsigned short)excl;
-          fill_task_map(tm, excl, cnt, tid);
-        }
-        if (tid == 0) {
-          ts[nin] = (unsigned short)T;
-          *out_n = nin;
-          *out_t = T;
-        }
-      };
-      int buf = 0;
-      {
-        const bool wide = BS > 64 && le - lb > 64;
-        if (!wide) {
-          if (tid < 64) phase0_narrow(lb, tsA, tmA, &S.ctl[1], &S.ctl[2]);
-        } else {
-          const int wv = tid >> 6, ln = tid & 63;
-          const int k = lb + tid;
-          const bool has = k < le;
-          const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
-          const int local = wave_inclusive_scan(cnt);
-          if (ln == 63) S.ctl[4 + wv] = local;
-          tree_barrier<NCAP>();
-          int woff = 0;
-          for (int w = 0; w < wv; w++) woff += S.ctl[4 + w];
-          const int incl = local + woff;
-          const bool inb = has && (incl <= TCAP);
-          const unsigned long long bm = __ballot(inb);
-          const int nw = __popcll(bm);
-          const int tw = nw > 0 ? __builtin_amdgcn_readlane(incl, nw > 0 ? nw - 1 : 0) : 0;
-          if (inb) {
-            const int excl = incl - cnt;
-            tsA[tid] = (unsigned short)excl;
-            fill_task_map(tmA, excl, cnt, tid);
-          }
-          if (ln == 0) {
-            S.ctl[8 + wv] = nw;
-            S.rt[kRtNum + 1 + wv] = tw;
-          }
-          tree_barrier<NCAP>();
-          if (tid == 0) {
-            int n = 0, T = 0;
-            for (int w = 0; w < BS / 64; w++) {
-              n += S.ctl[8 + w];
-              T = S.ctl[8 + w] > 0 ? S.rt[kRtNum + 1 + w] : T;
-            }
-            tsA[n] = (unsigned short)T;
-            S.ctl[1] = n;
-            S.ctl[2] = T;
-          }
-        }
-        tree_barrier<NCAP>();
-      }
-      AGBNP_BUILD_STAMP(10);
-      for (int nb = lb; nb < le;) {
-        const unsigned short* ts = buf ? tsB : tsA;
-        const unsigned char* tm = buf ? tmB : tmA;
-        const int nin = S.ctl[buf ? 3 : 1], T = S.ctl[buf ? 7 : 2];
-        const int nb_next = nb + nin;
-        const bool more = BS > 64 && nb_next < le;
-        if (more && tid < 64) phase0_narrow(nb_next, buf ? tsA : tsB, buf ? tmA : tmB, &S.ctl[buf ? 1 : 3], &S.ctl[buf ? 2 : 7]);
-        // phase 1: one task per lane -> switched volume of (node, sibling's atom); wave 0 is busy with the next batch if there is one
-        {
-          const int lanes = more ? BS - 64 : BS, t0 = more ? tid - 64 : tid;
-          if (t0 >= 0)
-            for (int t = t0; t < T; t += lanes) {
-              const int j = tm[t];
-              const int kk = nb + j;
-              const int s_ = kk + 1 + (t - (int)ts[j]);
-              const int la = S.nla[s_];
-              double gv;
-              const double v = dev_merge_volume2(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
-                                                 S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la], gv);
-              const bool kept = v > kMinGvol;
-              tvol[t] = kept ? gv : 0.0;
-              const unsigned long long km = __ballot(kept);  // tasks t0..t0+63 of this wave trip: t0 = t - lane
-              if ((tid & 63) == 0) S.kmask[t >> 6] = km;
-            }
-        }
-        tree_barrier<NCAP>();
-        AGBNP_BUILD_STAMP(11);
-        const int nwords = (T + 63) >> 6;
-        int created = 0;
-        for (int w = 0; w < nwords; w++) created += __popcll(S.kmask[w]);
-        if (tail + created > NCAP) return kBuildNodeOverflow;
-        auto kept_before = [&](int ts0) {
-          const int wi = ts0 >> 6;
-          int c = __popcll(S.kmask[wi] & ((1ull << (ts0 & 63)) - 1ull));
-          for (int w = 0; w < wi; w++) c += __popcll(S.kmask[w]);
-          return c;
-        };
-        AGBNP_BUILD_STAMP(12);
-        for (int t = tid; t < T; t += BS) {
-          const double v = tvol[t];
-          const int j = tm[t];
-          const int kk = nb + j;
-          const int ts0 = ts[j], te = ts[j + 1];
-          if (v > 0.0 || t == ts0) {
-            int rank = 0, c = 0;
-            for (int s0 = ts0; s0 < te; s0 += 63) {
-              const int s1 = (ACAP <= 64 || s0 + 63 >= te) ? te : s0 + 63;
-              unsigned long long mk = kept_bits(S.kmask, s0, s1);
-              c += __popcll(mk);
-              if (v > 0.0)
-                for (; mk; mk &= mk - 1) {
-                  const int u = s0 + __builtin_ctzll(mk);
-                  const double vu = tvol[u];
-                  rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
-                }
-              if (ACAP <= 64) break;
-            }
-            const int cb = tail + kept_before(ts0);
-            if (t == ts0 && c > 0) {
-              S.ncs[kk] = (unsigned short)cb;
-              S.ncc[kk] = (unsigned short)c;
-            }
-            if (v > 0.0) {
-              const int slot = cb + rank;
-              const int la = S.nla[kk + 1 + (t - ts0)];
-              double mx, my, mz, ma;
-              dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
-                              mx, my, mz, ma);
-              S.nd[0][slot] = mx;
-              S.nd[1][slot] = my;
-              S.nd[2][slot] = mz;
-              S.nd[3][slot] = ma;
-              S.nd[4][slot] = v;
-              S.nla[slot] = (unsigned short)la;
-              S.npar[slot] = (unsigned short)kk;
-              S.ncs[slot] = (unsigned short)(cb + c);
-              S.ncc[slot] = 0;
-            }
-          }
-        }
-        tree_barrier<NCAP>();
-        AGBNP_BUILD_STAMP(13);
-        tail += created;
-        nb = nb_next;
-        if (more) buf ^= 1;
-      }
-    }
-#else
     for (int nb = lb; nb < le;) {
       // phase 0: one node per lane -> number of younger siblings = tasks, their prefix sum, the task -> node byte
       // map.  A node's ncs still holds the end of its sibling list at this point.  Up to 64 nodes are handled by
@@ -879,7 +697,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           if (inb) {
             const int excl = incl - cnt;
             S.tstart[tid] = (unsigned short)excl;
-            fill_task_map(tmap, excl, cnt, tid);
+            for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
           }
           if (tid == 0) {
             S.tstart[nin] = (unsigned short)T;
@@ -905,7 +723,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         if (inb) {
           const int excl = incl - cnt;
           S.tstart[tid] = (unsigned short)excl;
-          fill_task_map(tmap, excl, cnt, tid);
+          for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
         }
         if (ln == 0) {
           S.ctl[8 + wv] = nw;
@@ -1010,16 +828,12 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       tail += created;
       nb += nin;
     }
-#endif
     if (tid == 0) S.lvl[L + 2] = tail;
   }
   if (tid == 0) {
     // lvl[L+1] already equals tail (set when level L-1 was expanded); deeper levels are empty
     for (int M = L + 2; M <= 9; M++) S.lvl[M] = tail;
   }
-#if AGBNP_PIPE_PHASE0
-  for (int la = tid; la < ACAP; la += BS) S.at[9][la] = 0.0;  // (second byte map of the pipelined expansion)
-#endif
   tree_barrier<NCAP>();
   *nnodes_out = tail;
   *natoms_out = m + ncand;
@@ -1398,218 +1212,6 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
   tree_barrier<NCAP>();
   AGBNP_BUILD_STAMP(14);
   return true;
-}
-
-// ---- both cavity passes of a freshly built forest from ONE walk over the ancestor chains (round 4) -----------------------
-// Pass 2 (vdW radii) used to recompute every node from its atom path after pass 1: a second chain of up to seven dependent
-// LDS round trips per node, behind a phase that switched the local atoms' radii.  The overlap of K Gaussians does not depend
-// on the order in which they are merged:
-//   G = (prod v_i) ((prod a_i) / (A pi^(K-1)))^(3/2) exp(-E),   A = sum a_i,  c = sum a_i r_i / A,  E = sum a_i |r_i|^2 - A |c|^2
-// so the leaf-to-root walk that lays down a node's path for pass 1 adds up A, sum a_i r_i, sum a_i |r_i|^2, prod a_i and
-// prod v_i for the vdW radii on its way (positions relative to the node's own centre of the build, a fraction of an
-// angstrom from every one of its atoms: no cancellation to speak of), and the node step of pass 2 is arithmetic only.
-// Where its results wait for the gather of pass 1 to be done with the node rows: the gather weight w_n in the volume row
-// (pass 1 only needs it for the diagnostic self volumes, which keep the two-pass form), the coefficient in the path row --
-// the path itself goes straight to the topology pool and stays in registers for the membership sort --, the centre in
-// registers (three doubles for each of the lane's <= ceil(NCAP / BS) nodes).  The vdW exponent and volume of a local atom
-// follow from its enlarged ones (a = KFC / r^2, v = 4 pi r^3 / 3, enlarged radius = r + kRadiusIncrement): no second trip
-// to the heavy-atom table.
-template <int NCAP, int BS>
-struct FusedNodes {
-  static constexpr int KN = (NCAP + BS - 1) / BS;
-  double cx[KN], cy[KN], cz[KN];
-};
-
-__device__ __forceinline__ void vdw_from_enlarged(double a_large, double& a_vdw, double& v_vdw) {
-  const double r = sqrt(kKFC / a_large) - kRadiusIncrement;
-  a_vdw = kKFC / (r * r);
-  v_vdw = (4.0 * kPi / 3.0) * (r * r * r);
-}
-
-// first half: node steps of both passes (paths out to `pool`), the membership list.  Returns false (workgroup-uniform) if
-// the list does not fit.  *e1 / *e2: sum_n c_n gamma_n s(G_n) G_n of pass 1 / pass 2 (valid on every lane).
-template <int NCAP, int ACAP, int BS>
-__device__ bool fused_first(const TreeStore<NCAP, ACAP>& S, int tid, int m, int nnodes, int natoms, unsigned long long* __restrict__ pool,
-                            double* e1, double* e2, int* npairs, bool det, FusedNodes<NCAP, BS>& F) {
-  static_assert(TreeStore<NCAP, ACAP>::kPairGather && ACAP <= BS, "the fused passes are for the LDS variants with a pair list");
-  static_assert(2 * ACAP * sizeof(double) <= 2 * (kTreeBlock + 2) * sizeof(unsigned short), "vdW parameters live in the idle task-start words");
-  constexpr int PCAP = TreeStore<NCAP, ACAP>::PCAP;
-  constexpr int KN = FusedNodes<NCAP, BS>::KN;
-  constexpr unsigned long long kPartners = 0x00ffffffffffffffull;
-  double* vda = reinterpret_cast<double*>(S.tstart);  // [ACAP] vdW exponents, [ACAP] vdW volumes (the expansion is over)
-  double* vdv = vda + ACAP;
-  double* cf2 = S.nd[6];                               // pass 2's coefficients wait in the path row
-  AGBNP_BUILD_STAMP_BEGIN();
-  for (int la = tid; la < ACAP; la += BS) S.pcnt[la] = 0;
-  if (tid < natoms) {
-    double a2, v2;
-    vdw_from_enlarged(S.at[3][tid], a2, v2);
-    vda[tid] = a2;
-    vdv[tid] = v2;
-  }
-  tree_barrier<NCAP>();
-  double e_part1 = 0.0, e_part2 = 0.0;
-  unsigned long long pws[KN];
-#pragma unroll
-  for (int it = 0; it < KN; it++) {
-    const int n = m + it * BS + tid;
-    F.cx[it] = F.cy[it] = F.cz[it] = 0.0;
-    pws[it] = 0ull;
-    if (m + it * BS >= nnodes) continue;  // (workgroup-uniform)
-    int level = 0, rootq = -1;
-    double w2 = 0.0;
-    do {
-      if (n >= nnodes) break;
-      {
-        // a level-2 node that another work item owns is a sibling only: empty path = inert in every pass
-        const int par = S.npar[n];
-        if (par < m) {
-          const int pp = S.rt[kRtPart + par];
-          if (level2_owner(n - S.rt[kRtBase + par], pp >> 8) != (pp & 0xff)) {
-            pool[n] = (unsigned long long)par << 56;
-            S.nd[3][n] = 0.0;
-            S.wrow[n] = 0.0;
-            cf2[n] = 0.0;
-            break;
-          }
-        }
-      }
-      const double ox = S.nd[0][n], oy = S.nd[1][n], oz = S.nd[2][n];
-      unsigned long long pw = 0ull;
-      double gam = 0.0, A2 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, s2 = 0.0, pa = 1.0, pv = 1.0;
-      auto meet = [&](int la) {  // one more atom of the node
-        gam += S.at[5][la];
-        const double a2 = vda[la], dx = S.at[0][la] - ox, dy = S.at[1][la] - oy, dz = S.at[2][la] - oz;
-        A2 += a2;
-        sx = fma(a2, dx, sx);
-        sy = fma(a2, dy, sy);
-        sz = fma(a2, dz, sz);
-        s2 = fma(a2, fma(dz, dz, fma(dy, dy, dx * dx)), s2);
-        pa *= a2;
-        pv *= vdv[la];
-      };
-      level = 1;
-      int p = n;
-      for (; p >= m; p = S.npar[p]) {  // leaf to root: the deepest atom is met first
-        const int la = S.nla[p];
-        pw = (pw << 8) | (unsigned long long)la;
-        atomicAdd(&S.pcnt[la], 1);
-        meet(la);
-        level++;
-      }
-      rootq = p;
-      meet(rootq);
-      pws[it] = pw;
-      pool[n] = pw | ((unsigned long long)rootq << 56);  // (all a replay needs of the node)
-      const double cp = ((level & 1) ? 1.0 : -1.0) / (double)level;
-      {  // pass 1: the build's own Gaussian (enlarged radii), nu = +gamma / roffset
-        const double g = S.nd[4][n];
-        double sp;
-        const double sw = dev_switch(g, sp);
-        S.nd[3][n] = -2.0 * cp * gam * (sp * g + sw) * g;
-        e_part1 += quantize(gam * (cp * sw * g), kQEnergy, det);
-      }
-      {  // pass 2: vdW radii, nu = -gamma / roffset
-        const double inv = fast_rcp(A2);
-        const double E = fmax(s2 - (sx * sx + sy * sy + sz * sz) * inv, 0.0);
-        const double g = pv * pow_three_halves(pa * fast_rcp(A2 * pi_power(level - 1))) * exp_nonpositive(-E);
-        double sp;
-        const double sw = dev_switch(g, sp);
-        F.cx[it] = fma(sx, inv, ox);
-        F.cy[it] = fma(sy, inv, oy);
-        F.cz[it] = fma(sz, inv, oz);
-        cf2[n] = 2.0 * cp * gam * (sp * g + sw) * g;  // (-2 c_n nu ... with nu = -gam)
-        w2 = quantize(cp * sw * g, kQVol, det);
-        S.wrow[n] = w2;
-        e_part2 -= quantize(gam * (cp * sw * g), kQEnergy, det);
-      }
-    } while (false);
-    // The root is in every node of its tree: its self volume (pass 2) is the tree's sum of w, its node count the count
-    // (folded per root inside the wave: same-address LDS atomics from all lanes serialize; see volume_pass)
-    for (unsigned long long todo = __ballot(rootq >= 0); todo;) {
-      const int q = __builtin_amdgcn_readlane(rootq, __builtin_ctzll(todo));
-      const unsigned long long mine = __ballot(rootq == q);
-      const double sq = wave_sum_f64(rootq == q ? w2 : 0.0);
-      if ((tid & 63) == 0) {
-        lds_add(&S.at[9][q], sq);
-        atomicAdd(&S.rt[kRtNodes + q], (int)__popcll(mine));
-      }
-      todo &= ~mine;
-    }
-  }
-  e_part1 = wave_sum_f64(e_part1);
-  e_part2 = wave_sum_f64(e_part2);
-  if ((tid & 63) == 0) {
-    S.misc[tid >> 6] = e_part1;
-    S.misc[4 + (tid >> 6)] = e_part2;
-  }
-  static_assert(BS / 64 <= 4, "two sets of per-wave partial sums in misc[8]");
-  // counting sort of the (atom, node) memberships by atom (as in volume_pass): counts -> offsets ...
-  tree_barrier<NCAP>();
-  {
-    double es1 = 0.0, es2 = 0.0;
-    for (int w = 0; w < BS / 64; w++) es1 += S.misc[w], es2 += S.misc[4 + w];  // fixed order
-    *e1 = es1;
-    *e2 = es2;
-  }
-  AGBNP_BUILD_STAMP(7);
-  if (tid < 64) {
-    const int a0 = 2 * tid, a1 = 2 * tid + 1;
-    const int c0 = a0 < ACAP ? S.pcnt[a0] : 0, c1 = a1 < ACAP ? S.pcnt[a1] : 0;
-    const int incl = wave_inclusive_scan(c0 + c1);
-    if (a0 < ACAP) S.pcnt[a0] = incl - c0 - c1;
-    if (a1 < ACAP) S.pcnt[a1] = incl - c1;
-    if (tid == 63) S.ctl[4] = incl;
-  }
-  tree_barrier<NCAP>();
-  const int total = S.ctl[4];
-  *npairs = total;
-  if (total > PCAP) return false;
-  // ... every node drops its own entries (its path is still in registers) at its atoms' cursors
-#pragma unroll
-  for (int it = 0; it < KN; it++) {
-    const int n = m + it * BS + tid;
-    for (unsigned long long pw = pws[it] & kPartners; pw; pw >>= 8) {
-      const int la = (int)(pw & 0xffull);
-      S.pairs[atomicAdd(&S.pcnt[la], 1)] = (unsigned short)((la << 9) | n);
-    }
-  }
-  tree_barrier<NCAP>();
-  return true;
-}
-
-// second half: gather of pass 1, then the node rows take pass 2's values and the local atoms their vdW radii, gather of pass 2
-template <int NCAP, int ACAP, int BS>
-__device__ void fused_second(const TreeStore<NCAP, ACAP>& S, int tid, int m, int nnodes, int natoms, int npairs, bool det,
-                             const FusedNodes<NCAP, BS>& F) {
-  constexpr int KN = FusedNodes<NCAP, BS>::KN;
-  const double* vda = reinterpret_cast<const double*>(S.tstart);
-  const double* vdv = vda + ACAP;
-  const double* cf2 = S.nd[6];
-  AGBNP_BUILD_STAMP_BEGIN();
-  pair_gather<NCAP, ACAP, BS>(S, tid, npairs, false, det);
-  tree_barrier<NCAP>();
-  AGBNP_BUILD_STAMP(14);
-  if (tid < natoms) {
-    S.at[3][tid] = vda[tid];
-    S.at[4][tid] = vdv[tid];
-    S.at[5][tid] = -S.at[5][tid];
-  }
-#pragma unroll
-  for (int it = 0; it < KN; it++) {
-    const int n = m + it * BS + tid;
-    if (n < nnodes) {
-      S.nd[0][n] = F.cx[it];
-      S.nd[1][n] = F.cy[it];
-      S.nd[2][n] = F.cz[it];
-      S.nd[3][n] = cf2[n];
-    }
-  }
-  tree_barrier<NCAP>();
-  AGBNP_BUILD_STAMP(7);
-  pair_gather<NCAP, ACAP, BS>(S, tid, npairs, true, det);
-  tree_barrier<NCAP>();
-  AGBNP_BUILD_STAMP(14);
 }
 
 // ---- after the passes: a root's gradient = -(sum of its partners' gradients) (translation invariance of its tree)

@@ -3,10 +3,6 @@
 
 #include "row_kernels.h"
 
-#ifndef AGBNP_FUSED_PASSES
-#define AGBNP_FUSED_PASSES 0
-#endif
-
 namespace agbnp {
 
 // Diagnostic build only (-DAGBNP_STAMPS): shader-clock cycles per phase of k_tree_cavity, summed over
@@ -163,29 +159,14 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     int npairs = 0;
     constexpr bool want_sv1 = SV1;
     const bool det = A.det != 0;
-#if AGBNP_FUSED_PASSES
-    // both passes from one walk over the ancestor chains (fused_first / fused_second in tree_kernels.h); the diagnostic
-    // self volumes of pass 1 keep the two-pass form
-    constexpr bool kFused = TreeStore<NCAP, ACAP>::kPairGather && ACAP <= BS && !GLOBAL && !SV1;
-#else
-    constexpr bool kFused = false;
-#endif
-    FusedNodes<kFused ? NCAP : BS, BS> fused;
-    double e_second = 0.0;
     // the vdW parameters of pass 2 are requested now and arrive underneath pass 1 (natoms <= ACAP <= BS for the
     // LDS variants: one atom per lane)
     const int hj_mine = (rc == kBuildOk && tid < natoms) ? S.at_gidx[tid] : work_item_root(items[0]);
-    double a_vdw_mine = 0.0, v_vdw_mine = 0.0;
-    if (!kFused) a_vdw_mine = A.hvat(kHvAVdw, hj_mine), v_vdw_mine = A.hvat(kHvVVdw, hj_mine);
+    const double a_vdw_mine = A.hvat(kHvAVdw, hj_mine), v_vdw_mine = A.hvat(kHvVVdw, hj_mine);
     // ---- pass 1: enlarged radii, nu = +gamma/roffset (reference steps A-B, ReferenceAGBNPKernels.cpp:293-339).
     // The node slots still hold the Gaussians of the build, so only the atom paths and the membership list are
     // laid down before the gather.  Its gradient stays in the local accumulators and leaves with that of pass 2.
-    if (kFused) {
-      if constexpr (kFused) {
-        if (rc == kBuildOk && !fused_first<NCAP, ACAP, BS>(S, tid, m, nnodes, natoms, A.node_pool + (size_t)slot * NCAP, &e_sum, &e_second, &npairs, det, fused))
-          rc = kBuildNodeOverflow;
-      }
-    } else if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs, det))
+    if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs, det))
       rc = kBuildNodeOverflow;  // the membership list does not fit: same protocol as a node overflow
     if (rc != kBuildOk) {
       if (tid == 0) {
@@ -206,7 +187,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     CSTAMP(1);
     // Take delivery of the prefetched vdW parameters HERE, while nothing else is in flight: the memory counter is in
     // order, so a wait placed after the topology stores below would also wait for every one of them.
-    if (!kFused) asm volatile("" ::"v"(a_vdw_mine), "v"(v_vdw_mine));
+    asm volatile("" ::"v"(a_vdw_mine), "v"(v_vdw_mine));
     if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatCavityQueue], 1);  // the forest AFTER this one
     if (tid == 0) {
       // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141); once per subtree (its part 0)
@@ -226,8 +207,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     {
       const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
       const unsigned long long* path = reinterpret_cast<const unsigned long long*>(S.nd[6]);
-      if (!kFused)  // (the fused walk has written the paths itself)
-        for (int n = m + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
+      for (int n = m + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
       for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
       if (TreeStore<NCAP, ACAP>::kPairGather) {
         const size_t pair_off = (size_t)slot * TreeStore<NCAP, ACAP>::PCAP;
@@ -252,11 +232,6 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
       }
     }
     CSTAMP(2);
-    if (kFused) {
-      CSTAMP(3);
-      if constexpr (kFused) fused_second<NCAP, ACAP, BS>(S, tid, m, nnodes, natoms, npairs, det, fused);
-      e_sum = e_second;
-    } else {
     // switch the local atoms to vdW radii, nu = -gamma/roffset, for pass 2, whose self volumes the Born stage needs
     if (ACAP <= BS) {
       if (tid < natoms) {
@@ -277,7 +252,6 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
 
     // ---- pass 2: vdW radii, nu = -gamma/roffset
     volume_pass<NCAP, ACAP, BS, true>(S, tid, m, nnodes, natoms, true, &e_sum, &npairs, det);
-    }
     CSTAMP(4);
     root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
     CSTAMP(5);
