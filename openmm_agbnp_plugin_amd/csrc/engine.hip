@@ -799,7 +799,12 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     // forest's loads queue behind the force atomics of the one before (three adds on one line of the caller's [n][3]
     // buffer retire more slowly than the heavy-atom table's separate rows: lattice of 16.6 k atoms 49 -> 99 us): there the
     // output launch stays.  (No heavy atom: no tree launch to carry them.)
-    const bool fused = c->fused_outputs && c->nh > 0 && c->nh <= 2 * c->tree_slots[c->variant];
+    // (Round 4: the replay of queued forests is pipelined -- the next forest's data are asked for in front of the flush -- and
+    // the forces were tried in the launch again: lattice k_tree_pseudo 51 -> 109 us once more.  On gfx9 loads, stores and
+    // atomics share one in-order counter, and a wait that crosses the loop's back edge is a wait for everything, the
+    // flush's atomics included.  AGBNP_HIP_FUSE_QUEUED=1 keeps the experiment reachable.)
+    static const bool fuse_queued = getenv("AGBNP_HIP_FUSE_QUEUED") && atoi(getenv("AGBNP_HIP_FUSE_QUEUED")) != 0;
+    const bool fused = c->fused_outputs && c->nh > 0 && (c->nh <= 2 * c->tree_slots[c->variant] || (fuse_queued && c->variant <= 1));
     O.enabled = fused ? 1 : 0;
     O.n = c->n;
     O.a2h = c->d_a2h.p;

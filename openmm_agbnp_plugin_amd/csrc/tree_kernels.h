@@ -988,9 +988,14 @@ __device__ __forceinline__ double pi_power(int k) {  // pi^k, k = 1..7
 
 // *npairs: length of the (atom, node) pair list; written by a FRESH_BUILD pass (which builds the list), read by the
 // others.  Returns false (workgroup-uniform) if the list does not fit: the caller reports a capacity overflow.
-template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_pairs: called by every thread once the node step is done and the replayed pair list (pair_word) has been moved
+// from registers into LDS -- the point from which a replay's registers are free for the NEXT forest's loads (k_tree_pseudo)
+template <int NCAP, int ACAP, int BS, bool WITH_ENERGY, bool FRESH_BUILD = false, class AfterPairs = NoHook>
 __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int nnodes, int natoms, bool with_selfvol,
-                            double* e_sum, int* npairs, bool det, const uint4* pair_word = nullptr) {
+                            double* e_sum, int* npairs, bool det, const uint4* pair_word = nullptr, AfterPairs after_pairs = AfterPairs()) {
   static_assert(ACAP <= 256, "atom path stores one byte per level");
   static_assert(BS % 64 == 0 && BS >= 64, "whole waves");
   constexpr bool kPairs = TreeStore<NCAP, ACAP>::kPairGather;
@@ -1138,6 +1143,7 @@ __device__ bool volume_pass(const TreeStore<NCAP, ACAP>& S, int tid, int m, int 
       for (int k = 0; k < (PCAP / 8 + BS - 1) / BS; k++)
         if (tid + k * BS < PCAP / 8) reinterpret_cast<uint4*>(S.pairs)[tid + k * BS] = pair_word[k];
       tree_barrier<NCAP>();
+      after_pairs();
     }
     pair_gather<NCAP, ACAP, BS>(S, tid, *npairs, with_selfvol, det);
     tree_barrier<NCAP>();

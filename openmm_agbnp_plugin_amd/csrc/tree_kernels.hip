@@ -351,6 +351,152 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
   const int nforests = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
   // The workgroup's own work slot needs no test: k_tree_cavity leaves "nothing to replay" in the header of an idle slot,
   // so the forest's topology is requested straight away.
+  constexpr bool kPipelined = !GLOBAL && NCAP <= 8 * BS && ACAP <= BS && TreeStore<NCAP, ACAP>::kPairGather;
+  if constexpr (kPipelined) {
+    // Round 4: the replay of QUEUED forests is pipelined (systems with more forests than resident workgroups: the 16.6 k-atom
+    // lattice replays ~4 forests per workgroup).  A forest's two dependent trips to memory -- stored topology, then the
+    // per-atom parameters of its local atoms -- used to start when the forest before it had flushed its sums; now the
+    // topology of the NEXT forest is requested as soon as the current one's has left the registers for LDS (after_pairs,
+    // in the middle of the volume pass), and its per-atom parameters behind the current forest's root gradients, in front
+    // of the flush.  Lattice: k_tree_pseudo 51.5 -> 48.4-51.2 us (A/B on one box, profiles/r04): the trips were mostly hidden
+    // by the other four workgroups of the CU already.  One forest per workgroup (1dwc): the same work as before.
+    constexpr int KP = (NCAP + BS - 1) / BS;
+    constexpr int kPairWordsP = TreeStore<NCAP, ACAP>::PCAP / 8;  // 16-byte words of the pair list
+    constexpr int kPairRegsP = (kPairWordsP + BS - 1) / BS;         // ... per lane
+    unsigned long long pw[KP];
+    uint4 pair_word[kPairRegsP];
+    int hj_pre = 0;
+    int h_nnodes = 0, h_natoms = 0, h_m = 0, h_npairs = 0, h_partners[kMaxRoots];  // the forest's header (wave-uniform)
+    auto request_topology = [&](int slot_) {  // one round trip: header, paths, membership list, local atoms (capacity-strided
+                                              // slots: reading past the forest's own entries is harmless, the values are masked)
+      const SubtreeHeader* H = &A.hdr[slot_];  // written by k_tree_cavity's workgroup of the same slot
+      const size_t pool_off = (size_t)slot_ * NCAP, atom_off = (size_t)slot_ * ACAP;
+#pragma unroll
+      for (int k = 0; k < kPairRegsP; k++) {
+        pair_word[k] = make_uint4(0, 0, 0, 0);
+        if (tid + k * BS < kPairWordsP)
+          pair_word[k] = reinterpret_cast<const uint4*>(A.pair_pool + (size_t)slot_ * TreeStore<NCAP, ACAP>::PCAP)[tid + k * BS];
+      }
+#pragma unroll
+      for (int k = 0; k < KP; k++) pw[k] = tid + k * BS < NCAP ? A.node_pool[pool_off + tid + k * BS] : 0ull;
+      hj_pre = tid < ACAP ? A.atom_pool[atom_off + tid] : 0;
+      h_nnodes = H->nnodes, h_natoms = H->natoms, h_m = H->nroots, h_npairs = H->npairs;
+#pragma unroll
+      for (int q = 0; q < kMaxRoots; q++) h_partners[q] = H->partners[q];
+    };
+    double px = 0.0, py = 0.0, pz = 0.0, pa = 0.0, pv = 0.0, pnu = 0.0;  // per-atom parameters of the forest about to be replayed
+    int pidx = 0;
+    auto request_parameters = [&]() {  // second round trip (needs the local atom list); one atom per lane
+      if (tid < h_natoms) {
+        const int hj = hj_pre;
+        px = A.hvat(kHvX, hj), py = A.hvat(kHvY, hj), pz = A.hvat(kHvZ, hj);
+        pa = A.hvat(kHvAVdw, hj), pv = A.hvat(kHvVVdw, hj);
+        pnu = A.db_wu[hj] * A.hvat(kHvInvVol, hj);
+        pidx = write_forces ? A.out.h2a[hj] : 0;
+      }
+    };
+    const bool queued = nforests > grid;
+    const bool det = A.det != 0;
+    request_topology(block);
+    bool have_parameters = false;
+    for (;;) {
+      PSTAMP_BEGIN();
+      const int nnodes = h_nnodes, natoms = h_natoms, m = h_m;
+      int npairs = h_npairs;
+      if (nnodes <= m) {  // not built (capacity overflow: the host repeats the evaluation), lone atoms only, or an idle slot
+        if (!queued) break;
+        int ticket = 0;
+        if (tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
+        const int slot_ = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, grid));
+        if (slot_ >= nforests) break;
+        request_topology(slot_);
+        have_parameters = false;
+        continue;
+      }
+      if (tid == 0) {
+        int run = m;
+        for (int q = 0; q < m; q++) {
+          S.rt[kRtCount + q] = h_partners[q];
+          S.rt[kRtBase + q] = run;
+          run += h_partners[q];
+        }
+      }
+      {
+        unsigned long long* path = reinterpret_cast<unsigned long long*>(S.nd[6]);
+#pragma unroll
+        for (int k = 0; k < KP; k++)
+          if (tid + k * BS >= m && tid + k * BS < nnodes) path[tid + k * BS] = pw[k];
+      }
+      if (!have_parameters) request_parameters();
+      if (tid < natoms) {
+        S.at_gidx[tid] = hj_pre;
+        S.at[0][tid] = px;
+        S.at[1][tid] = py;
+        S.at[2][tid] = pz;
+        S.at[3][tid] = pa;
+        S.at[4][tid] = pv;
+        S.at[5][tid] = pnu;
+        S.at[6][tid] = 0.0;
+        S.at[7][tid] = 0.0;
+        S.at[8][tid] = 0.0;
+        // (the self-volume accumulators are idle in this pass: the slot carries the atom's index for the flush)
+        S.at[9][tid] = write_forces ? __hiloint2double(0, pidx) : 0.0;
+      }
+      tree_barrier<NCAP>();
+      PSTAMP(0);
+      // every global load of this forest has been consumed: ask for the number of the next one (see k_tree_cavity) ...
+      int ticket = 0x3fffffff;
+      if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatPseudoQueue], 1);
+      int next = 0x7fffffff;
+      bool next_there = false;
+      // ... and, when this forest's topology has left the registers, for the next forest's (the ticket has had the node step
+      // to come back)
+      auto after_pairs = [&]() {
+        if (!queued) return;
+        next = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, grid));
+        next_there = next < nforests;
+        if (next_there) request_topology(next);
+      };
+      double e_sum = 0.0;
+      volume_pass<NCAP, ACAP, BS, false, false>(S, tid, m, nnodes, natoms, false, &e_sum, &npairs, det, pair_word, after_pairs);
+      PSTAMP(1);
+      root_gradients_from_invariance<NCAP, ACAP, BS>(S, tid, m);
+      // the next forest's per-atom parameters: its local atom list is back by now; requested IN FRONT of the flush below
+      have_parameters = false;
+      if (next_there && h_nnodes > h_m) {
+        request_parameters();
+        have_parameters = true;
+      }
+      if (write_forces) {  // force = -gradient, straight into the caller's buffer (nothing of an overflowed evaluation)
+        if (!evaluation_void(A.status)) {
+          if (A.out.force_fixed) {
+            for (int la = tid; la < natoms; la += BS) add_force(A.out, __double2loint(S.at[9][la]), -S.at[6][la], -S.at[7][la], -S.at[8][la]);
+          } else {
+            // the caller's [n][3] array: the three components of an atom are one lane each, next to each other, so that they
+            // leave in ONE atomic request per atom.  (A lane per atom and one instruction per component sends three requests
+            // to the same line one behind the other, and same-line adds queue at the memory side: +1.9 us on 1dwc.)
+            for (int k = tid; k < 3 * natoms; k += BS) {
+              const int la = k / 3, c = k - 3 * la;
+              const double* row = c == 0 ? S.at[6] : (c == 1 ? S.at[7] : S.at[8]);
+              glb_add(&A.out.force[3 * (size_t)__double2loint(S.at[9][la]) + c], -row[la]);
+            }
+          }
+        }
+      } else {
+        for (int la = tid; la < natoms; la += BS) {
+          const int hj = S.at_gidx[la];
+          glb_add(&A.hvat(kHvGx, hj), S.at[6][la]);
+          glb_add(&A.hvat(kHvGy, hj), S.at[7][la]);
+          glb_add(&A.hvat(kHvGz, hj), S.at[8][la]);
+        }
+      }
+      tree_barrier<NCAP>();
+      PSTAMP(2);
+      PSTAMP_FLUSH();
+      if (!next_there) break;  // (one forest per workgroup, or the queue is empty)
+    }
+    return;
+  }
   for (int slot = block;;) {
     int ticket = 0x3fffffff;  // (a forest that asks for no successor ends the workgroup's run)
     do {
