@@ -151,7 +151,7 @@ def pair_wave_steps(system, pos):
 def gather_records(dist, record, device):
     """All-gather of one small python record per rank (backend nccl (= RCCL over xGMI) on GPUs, gloo in the CPU
     tests).  Returns the list of records by rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [record]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, record)
@@ -216,6 +216,15 @@ class HipBackend:
         self.device = torch.device("cuda", self.index)
 
     def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def wait_idle(self):
+        """synchronize(), reached through a spin on the stream's status: a blocking wait sleeps in the driver and comes back
+        tens of microseconds after the last kernel has ended -- at the driver's 20 steps that is a microsecond per step of
+        host latency, not of evaluation.  (The synchronize behind the spin returns at once and keeps the contract literal.)"""
+        st = self.torch.cuda.current_stream()
+        while not st.query():
+            pass
         self.torch.cuda.synchronize()
 
     def current_stream(self):
@@ -315,7 +324,7 @@ class Replica:
             self.dev.synchronize()
             t0 = time.perf_counter()
             self.run(first, count)
-            self.dev.synchronize()
+            self.dev.wait_idle()
             barrier()
             t1 = time.perf_counter()
             # finish() reads the device's sticky overflow log: EVERY one of the timed evaluations is accounted for, not
@@ -567,7 +576,7 @@ class Job:
 
     def __init__(self, dist, device, rank):
         self.dist, self.device, self.rank, self.error = dist, device, rank, None
-        self.multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        self.multi = dist is not None and dist.is_initialized()  # (a one-rank group too: the rehearsal of the backend)
 
     def sync(self, withheld=0, seconds=0.0):
         """-> (MAX withheld, MAX seconds) over the ranks; leaves through abort() if any rank has failed."""
@@ -650,13 +659,21 @@ def worker(args):
     backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
     dev = make_backend(torch, local_rank, backend)
     coll_device = dev.device if backend == "nccl" else torch.device("cpu")
-    if env_world > 1:
+    # AGBNP_BENCH_FORCE_DIST=1: a ONE-rank job still initialises the process group and sends every collective through the
+    # backend (a rehearsal of the RCCL plumbing on a box with one GPU)
+    force_dist = os.environ.get("AGBNP_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if env_world > 1 or force_dist:
+        if force_dist and env_world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev.device)
         else:
             dist.init_process_group(backend=backend)
     world = dist.get_world_size() if dist.is_initialized() else 1  # what took part, not what the environment promised
-    mdist = dist if world > 1 else None
+    mdist = dist if (world > 1 or force_dist) else None
     job = Job(mdist, coll_device, rank)
 
     K, W = args.steps, args.warmup
@@ -686,7 +703,7 @@ def worker(args):
 
     # ---- the closing collectives: from here on rank 0 works alone (per-kernel pass, CPU baseline, secondary records) and
     #      the other ranks are done -- nobody sits in a collective while rank 0 runs twenty seconds of CPU oracle
-    if world > 1:
+    if mdist is not None:
         job.sync()
         dist.destroy_process_group()
     if rank != 0:
@@ -713,6 +730,7 @@ def worker(args):
         "ranks": per_rank,
         "distinct_devices": len({(r["device_uuid"], r["pci_bus_id"], r["device_index"]) for r in per_rank}),
         "launcher": os.environ.get("AGBNP_BENCH_LAUNCHER", "torch.distributed.run" if env_world > 1 else "none"),
+        "collectives": (backend if mdist is not None else "none (one rank)"),
         "algorithmic_bytes_per_eval": b_eval,
         "eval_hbm_fraction": (b_eval / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9),
     }

@@ -65,6 +65,9 @@ class Backend:
     def synchronize(self):
         pass
 
+    def wait_idle(self):
+        pass
+
     def current_stream(self):
         return 0
 

@@ -86,6 +86,10 @@ def _fake_replica(bench, torch, script, raise_at=0):
         def synchronize():
             pass
 
+        @staticmethod
+        def wait_idle():
+            pass
+
     rep = bench.Replica.__new__(bench.Replica)  # the real settle / preheat / timed logic, no device
     rep.dev, rep.kernel, rep.stream = _Dev, _FakeKernel(script), None
     rep.d_force, rep.d_energy = torch.zeros(3), torch.zeros(1)
