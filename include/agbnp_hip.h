@@ -168,11 +168,14 @@ unsigned agbnp_hip_generation(const agbnp_hip_context* ctx);
  * energies): sums of such terms are exact in FP64, hence independent of their order.  Results stay within 1e-8 of the
  * default mode's (far inside the 1e-4 parity bar).
  *
- * AGBNP_HIP_MODE_SINGLE (only together with AGBNP_HIP_MODE_FAST): the GB pair stage -- the dominant pair stage -- computes
- * its pair terms in single precision (packed FP32, hardware exp2 / rsqrt; positions relative to a block-local origin),
- * as the reference's OpenCL platform does in its default precision; Born radii, the range-limited stages, the trees and
- * every sum across tiles stay FP64.  Forces differ from the FP64 fast mode by ~1e-3 kJ/mol/nm, the energy by ~1e-2
- * kJ/mol on a 4000-atom protein.  Rejected without AGBNP_HIP_MODE_FAST: the Reference semantics are FP64. */
+ * AGBNP_HIP_MODE_SINGLE (only together with AGBNP_HIP_MODE_FAST): the pair stages compute their pair terms in single
+ * precision (hardware exp2 / rsqrt; positions relative to a local origin before they are rounded), as the reference's
+ * OpenCL platform does in its default precision (AGBNPBornRadii.cl:181-430, AGBNPGBEnergy.cl are all-float).  In the row
+ * form -- where the fast mode normally runs -- that is all three of them: descreening sums, GB, chain rule (the spline table
+ * as FP32 in LDS); in the tile form (no neighbour lists: NoCutoff, AGBNP_HIP_ROWS=0) the GB strips only.  The sums of a
+ * slice or tile run in FP32, everything that leaves a wave, the Born-radius algebra, the trees and the energies stay
+ * FP64.  Forces differ from the FP64 fast mode by ~5e-4 kJ/mol/nm, the energy by ~3e-3 kJ/mol on a 4000-atom protein.
+ * Rejected without AGBNP_HIP_MODE_FAST: the Reference semantics are FP64. */
 enum agbnp_hip_mode { AGBNP_HIP_MODE_REFERENCE = 0, AGBNP_HIP_MODE_FAST = 1, AGBNP_HIP_MODE_DETERMINISTIC = 2, AGBNP_HIP_MODE_SINGLE = 4 };
 int agbnp_hip_set_mode(agbnp_hip_context* ctx, int mode);
 int agbnp_hip_get_mode(const agbnp_hip_context* ctx);

@@ -1547,7 +1547,8 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
 // ---- row form of the pair stages: the launches (device code in row_kernels.h) -----------------------------------------
 // (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers; the GB rows, whose pair terms and
 // bookkeeping role need more, four)
-template <int KIND>
+// SINGLE: the Born / chain-rule rows with their pair terms in single precision (row_kernels.h; fast mode + AGBNP_HIP_MODE_SINGLE)
+template <int KIND, bool SINGLE = false>
 __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
   extern __shared__ double2 s_dyn[];
 
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
     blk -= 1;
   }
   __shared__ int s_busy;
-  rows_workgroup<KIND, row_waves(KIND)>(P, blk, s_dyn, &s_busy);
+  rows_workgroup<KIND, row_waves(KIND), SINGLE>(P, blk, s_dyn, &s_busy);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1679,7 +1680,10 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
     AGBNP_MARK(kKBornRows);
-    hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    if (P.single)
+      hipLaunchKernelGGL((k_rows<kBornRows, true>), dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    else
+      hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
     AGBNP_CHECK_LAUNCH();
     if (P.gb_rows) {
       AGBNP_MARK(kKGbRows);
@@ -1691,7 +1695,10 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     }
     AGBNP_CHECK_LAUNCH();
     AGBNP_MARK(kKDbornRows);
-    hipLaunchKernelGGL(k_rows<kChainRows>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    if (P.single)
+      hipLaunchKernelGGL((k_rows<kChainRows, true>), dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    else
+      hipLaunchKernelGGL(k_rows<kChainRows>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
     AGBNP_CHECK_LAUNCH();
     return hipSuccess;
   }

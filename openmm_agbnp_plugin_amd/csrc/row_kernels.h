@@ -244,8 +244,13 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
 
 // The work of one workgroup of WAVES waves of a row launch of kind KIND (blk: its number among the launch's row
 // workgroups).
-template <int KIND, int WAVES>
+// SINGLE (Born and chain-rule rows under AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_SINGLE): the pair terms in single precision, as
+// the reference's GPU platform computes them (AGBNPBornRadii.cl:181-430 is all-float): the table in LDS as one 16-byte
+// float4 {c0, c1, c2, c3} per entry (half the copy, one look-up per pair instead of two), distances from positions relative
+// to the group's first row atom, hardware rsqrt, the sums of a slice in FP32; everything that leaves a wave stays FP64.
+template <int KIND, int WAVES, bool SINGLE = false>
 __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, double2* s_dyn, int* s_busy_word) {
+  static_assert(!SINGLE || KIND != kGbRows, "the GB rows choose their precision at run time (P.single)");
   constexpr int R = kRowGroup;
   static_assert(R == 4, "the butterfly below folds 16 sums");
   int& s_busy = *s_busy_word;  // (a word of the caller's LDS)
@@ -330,15 +335,27 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     __syncthreads();
     if (!s_busy) return;
   }
-  double2 tv0, tv1, tv2;
-  if (KIND != kGbRows) tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
+  float4* const s_tab4 = reinterpret_cast<float4*>(s_dyn);  // SINGLE: {c0, c1, c2, c3} per entry
+  double2 tv0, tv1, tv2, tv3;
+  if (KIND != kGbRows && !SINGLE) tv0 = gtab[min(tx, 2 * tab - 1)], tv1 = gtab[min(kWg + tx, 2 * tab - 1)], tv2 = gtab[min(2 * kWg + tx, 2 * tab - 1)];  // (1dwc: 1440 entries)
+  if (KIND != kGbRows && SINGLE)  // (1dwc: 720 entries, both halves of an entry per thread)
+    tv0 = gtab[min(tx, tab - 1)], tv1 = gtab[tab + min(tx, tab - 1)], tv2 = gtab[min(kWg + tx, tab - 1)], tv3 = gtab[tab + min(kWg + tx, tab - 1)];
   PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 7, "vmcnt(0) lgkmcnt(0)");
-  if (KIND != kGbRows) {
+  if (KIND != kGbRows && !SINGLE) {
     if (tx < 2 * tab) s_tab[tx] = tv0;
     if (kWg + tx < 2 * tab) s_tab[kWg + tx] = tv1;
     if (2 * kWg + tx < 2 * tab) s_tab[2 * kWg + tx] = tv2;
     for (int base = 3 * kWg; base < 2 * tab; base += kWg)  // (larger tables)
       if (base + tx < 2 * tab) s_tab[base + tx] = gtab[base + tx];
+  }
+  if (KIND != kGbRows && SINGLE) {
+    if (tx < tab) s_tab4[tx] = make_float4((float)tv0.x, (float)tv0.y, (float)tv1.x, (float)tv1.y);
+    if (kWg + tx < tab) s_tab4[kWg + tx] = make_float4((float)tv2.x, (float)tv2.y, (float)tv3.x, (float)tv3.y);
+    for (int base = 2 * kWg; base < tab; base += kWg)  // (larger tables)
+      if (base + tx < tab) {
+        const double2 a = gtab[base + tx], b = gtab[tab + base + tx];
+        s_tab4[base + tx] = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+      }
   }
   int slice_at[R];  // first entry of the row's slice of the table
 #pragma unroll
@@ -382,6 +399,49 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     PAIR_STAMP((KIND == kChainRows ? 2 : 0), 8);
     PAIR_STAMP_WAIT((KIND == kChainRows ? 2 : 0), 1, "vmcnt(0)");  // the first records are here
     ROWS_LOG_COUNTS((KIND == kChainRows ? 2 : 0), todo, nsteps);
+    if (SINGLE) {
+      float ox[R], oy[R], oz[R], accf[4 * R];
+#pragma unroll
+      for (int r = 0; r < R; r++) ox[r] = (float)(A.x[r] - A.x[0]), oy[r] = (float)(A.y[r] - A.y[0]), oz[r] = (float)(A.z[r] - A.z[0]);
+#pragma unroll
+      for (int q = 0; q < 4 * R; q++) accf[q] = 0.0f;
+      const float per_node = (float)kPerNode, range2f = (float)P.range2;
+      for (int k = 0; k < nsteps; k++) {
+        const unsigned e = e1;
+        const double4 rb = r1;
+        const double wb = w1;
+        e1 = e2;
+        r1 = rec[e1 & 0xffffffu];
+        w1 = wsrc[e1 & 0xffffffu];
+        e2 = list[min(first + 64 * (k + 2) + lane, stride - 1)];
+        const int b = (int)(e & 0xffffffu);
+        const int tent = (int)(e >> 24) * kRowIntervals;
+        const float w = (float)((KIND == kChainRows ? wb : wb * rb.w) * kPerNode);
+        const float cut2 = 64 * k + lane < todo ? range2f : -1.0f;  // (a lane beyond the slice meets nobody)
+        const float nx = (float)(rb.x - A.x[0]), ny = (float)(rb.y - A.y[0]), nz = (float)(rb.z - A.z[0]);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float dx = nx - ox[r], dy = ny - oy[r], dz = nz - oz[r];
+          const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          if (d2 < cut2 && b != A.self[r]) {
+            const float rinv = __builtin_amdgcn_rsqf(d2);
+            const float u = fminf((d2 * rinv) * per_node, (float)kRowIntervals - 1e-3f);  // (rounding must not step past the last interval)
+            const int ent = slice_at[r] + tent + (int)u;
+            const float t = u - (float)(int)u;
+            const float4 c = s_tab4[ent];
+            const float b2 = fmaf(c.w, t, c.z), b1 = fmaf(b2, t, c.y);
+            const float val = fmaf(b1, t, c.x), der = fmaf(fmaf(c.w, t, b2), t, b1);
+            accf[4 * r] = fmaf(w, val, accf[4 * r]);
+            const float g = w * der * rinv;
+            accf[4 * r + 1] = fmaf(dx, g, accf[4 * r + 1]);
+            accf[4 * r + 2] = fmaf(dy, g, accf[4 * r + 2]);
+            accf[4 * r + 3] = fmaf(dz, g, accf[4 * r + 3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4 * R; q++) acc[q] = (double)accf[q];
+    } else
     for (int k = 0; k < nsteps; k++) {
       const unsigned e = e1;
       const double4 rb = r1;

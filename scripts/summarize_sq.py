@@ -10,7 +10,10 @@ for r in csv.DictReader(open(src)):
     if "agbnp::" not in r["Kernel_Name"]:
         continue
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("agbnp::", "")
-    name = name if name.startswith("k_rows") else name.split("<")[0]  # (k_rows<0 | 1 | 2>: Born, chain-rule and GB rows are different kernels)
+    if name.startswith("k_rows"):  # (k_rows<0 | 1 | 2>: Born, chain-rule and GB rows are different kernels; since round 4 a second
+        name = name.replace(", false>", ">").replace(", true>", ">[single]")  # template argument says whether the pair terms are FP32)
+    else:
+        name = name.split("<")[0]
     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
         "SQ_LDS_BANK_CONFLICT"]

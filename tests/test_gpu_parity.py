@@ -1563,3 +1563,37 @@ def test_every_queued_evaluation_behind_a_truncated_row_is_withheld(gpu_required
     assert k.scalar("rows_on") == 0  # the whole stride was walked already: the tile kernels took over
     assert abs(ene.item() - sum(w[0] for w in want)) < 3 * TIGHT
     assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 3 * TIGHT
+
+
+@pytest.mark.parametrize("name,cutoff", [("1dwc", 1.0), ("2clr", 1.0), ("1dwc_x4", 1.0)])
+def test_fast_single_mode_rows_against_the_cutoff_oracle(gpu_required, systems, name, cutoff):
+    """AGBNP_HIP_MODE_FAST | AGBNP_HIP_MODE_SINGLE since round 4: ALL three pair stages compute their pair terms in single
+    precision (Born and chain-rule rows too: FP32 table in LDS, positions relative to the group's first row atom), as the
+    reference's OpenCL platform does throughout (AGBNPBornRadii.cl:181-430).  Against the FP64 oracle with the same cutoff
+    switch, at single-precision tolerances: relative 2e-6 in the energy, 2e-4 of the largest force.  (Parity unpinned: the
+    reference holds no vector of its OpenCL platform; the oracle's switch is tied to the pinned path by its limit.)"""
+    s = P.lattice(systems("1dwc"), 2, 2, 1, 7.0) if name == "1dwc_x4" else systems(name)
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+    force.setCutoffDistance(cutoff)
+    k = P.HipCalcAGBNPForceKernel(mode="fast+single")
+    k.initialize(force)
+    oracle = Oracle(*s.params(), version=1, cutoff=cutoff)
+    rng = np.random.default_rng(9)
+    for pos in (s.pos, s.pos + rng.normal(0.0, 0.04, s.pos.shape)):  # (the second geometry rebuilds the lists)
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        assert abs(e - eo) < 2e-6 * abs(eo) + 2e-2, (e, eo)
+        assert np.abs(f - fo).max() < 2e-4 * np.abs(fo).max(), (np.abs(f - fo).max(), np.abs(fo).max())
+        assert np.abs(f - fo).max() > 1e-9  # (and it IS single precision)
+    assert k.scalar("rows_on") == 1
+    born64 = None
+    k64 = P.HipCalcAGBNPForceKernel(mode="fast")
+    k64.initialize(force)
+    f = np.zeros((s.n, 3))
+    k64.execute(s.pos, f)
+    born64 = k64.vector("born")
+    f = np.zeros((s.n, 3))
+    k.execute(s.pos, f)
+    assert np.abs(k.vector("born") / born64 - 1.0).max() < 5e-6  # Born radii from FP32 descreening sums
