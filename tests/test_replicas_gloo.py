@@ -229,3 +229,25 @@ def test_the_launching_parent_never_loads_the_gpu_stack():
             "print([m for m in ('torch', 'numpy', 'openmm_agbnp_plugin_amd') if m in sys.modules])")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and out.stdout.strip() == "[]", (out.stdout, out.stderr)
+
+
+def test_bench_main_under_torch_distributed_run():
+    """The contract's launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- still works: with RANK in the environment the same file is the worker."""
+    pytest.importorskip("torch")
+    import json
+    import subprocess
+
+    env = dict(os.environ, AGBNP_BENCH_BACKEND="gloo", AGBNP_BENCH_BACKEND_MODULE="tests.fake_bench_backend")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--system", "trpcage", "--steps", "6",
+                        "--warmup", "2", "--preheat-ms", "0", "--cpu-evals", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = lines[0]
+    assert r["n_gpus"] == 2 and len(r["ranks"]) == 2 and r["distinct_devices"] == 2
+    assert r["launcher"] == "torch.distributed.run" and r["collectives"] == "gloo"
+    assert "roofline" in r and "cpu_baseline" in r
