@@ -658,11 +658,6 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     S.ncs[slot] = (unsigned short)(bq + cq);  // until the node is expanded: end of its sibling list
     S.ncc[slot] = 0;
   }
-  if (tid == 0) {
-    S.lvl[1] = 0;
-    S.lvl[2] = m;
-    S.lvl[3] = m + ncand;
-  }
   tree_barrier<NCAP>();
 
   AGBNP_BUILD_STAMP(9);
@@ -671,12 +666,20 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   double* tvol = S.nd[6];                                                // task -> switched volume (0 = rejected)
   int tail = m + ncand;
   int L = 2;
+  // (round 4: three dependent LDS round trips less per level -- the level bounds live in registers, every wave works the
+  // batch's task counts out for itself instead of reading wave 0's result back after the barrier, and a forest without a
+  // shared subtree does not look the ownership of its level-2 nodes up)
+  bool any_shared = false;
+#pragma unroll
+  for (int q = 0; q < kMaxRoots; q++) any_shared = any_shared || (q < m && work_item_parts(items[q]) > 1);
+  int level_begin = m;  // first node of level L (level 2 follows the roots)
   for (; L < kMaxOrder; L++) {
-    const int lb = S.lvl[L], le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
+    const int lb = level_begin, le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
+    level_begin = le;
     if (lb >= le) break;
     // a level-2 node is expanded by the work item that owns its rank (see kRtPart); deeper nodes by whoever created them
     auto owned_level2 = [&](int k) {
-      if (L != 2) return true;
+      if (L != 2 || !any_shared) return true;
       const int q = S.npar[k], pp = S.rt[kRtPart + q];
       return level2_owner(k - S.rt[kRtBase + q], pp >> 8) == (pp & 0xff);
     };
@@ -685,25 +688,24 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       // map.  A node's ncs still holds the end of its sibling list at this point.  Up to 64 nodes are handled by
       // wave 0 alone; wider levels (forests, big subtrees) take all waves and one more barrier for up to BS nodes.
       const bool wide = BS > 64 && le - nb > 64;
+      int nin, T;
       if (!wide) {
+        // (every wave: the counts are one LDS read and a DPP scan; only wave 0 writes the map)
+        const int ln = tid & 63;
+        const int k = nb + ln;
+        const bool has = k < le;
+        const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
+        const int incl = wave_inclusive_scan(cnt);
+        const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
+        nin = __popcll(__ballot(inb));
+        T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
         if (tid < 64) {
-          const int k = nb + tid;
-          const bool has = k < le;
-          const int cnt = (has && owned_level2(k)) ? (int)S.ncs[k] - k - 1 : 0;
-          const int incl = wave_inclusive_scan(cnt);
-          const bool inb = has && (incl <= TCAP);  // prefix property: the batch is lanes 0..nin-1
-          const int nin = __popcll(__ballot(inb));
-          const int T = __builtin_amdgcn_readlane(incl, nin - 1);  // nin >= 1: a single node has < ACAP <= TCAP tasks
           if (inb) {
             const int excl = incl - cnt;
             S.tstart[tid] = (unsigned short)excl;
             for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)tid;
           }
-          if (tid == 0) {
-            S.tstart[nin] = (unsigned short)T;
-            S.ctl[1] = nin;
-            S.ctl[2] = T;
-          }
+          if (tid == 0) S.tstart[nin] = (unsigned short)T;
         }
       } else {
         const int wv = tid >> 6, ln = tid & 63;
@@ -742,15 +744,23 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         }
       }
       tree_barrier<NCAP>();
-      const int nin = S.ctl[1];
-      const int T = S.ctl[2];
+      if (wide) {
+        nin = S.ctl[1];
+        T = S.ctl[2];
+      }
       AGBNP_BUILD_STAMP(10);
 
-      // phase 1: one task per lane -> switched volume of (node, sibling's atom)
+      // phase 1: one task per lane -> switched volume of (node, sibling's atom).  A lane meets the same tasks again in phase
+      // 3; what it has looked up for its FIRST one (node, the node's task range, the sibling's atom, the volume) stays in
+      // registers across the barrier: three dependent LDS round trips less at the head of phase 3 for all but the widest
+      // batches (round 4).
+      int keep_j = 0, keep_ts = 0, keep_te = 0, keep_la = 0;
+      double keep_v = 0.0;
       for (int t = tid; t < T; t += BS) {
         const int j = tmap[t];
         const int kk = nb + j;
-        const int s = kk + 1 + (t - (int)S.tstart[j]);
+        const int tsj = S.tstart[j], tej = S.tstart[j + 1];
+        const int s = kk + 1 + (t - tsj);
         const int la = S.nla[s];
         double gv;
         const double v = dev_merge_volume2(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
@@ -759,6 +769,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         // the UNSWITCHED volume is kept: it is the child's node volume, and the switched volume s(V) V that the
         // reference sorts by is strictly increasing in V wherever a child survives, so the order is the same
         tvol[t] = kept ? gv : 0.0;
+        if (t == tid) keep_j = j, keep_ts = tsj, keep_te = tej, keep_la = la, keep_v = kept ? gv : 0.0;
         const unsigned long long km = __ballot(kept);  // tasks t0..t0+63 of this wave trip: t0 = t - lane
         if ((tid & 63) == 0) S.kmask[t >> 6] = km;
       }
@@ -780,11 +791,8 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
         return c;
       };
       AGBNP_BUILD_STAMP(12);
-      for (int t = tid; t < T; t += BS) {
-        const double v = tvol[t];
-        const int j = tmap[t];
+      auto create = [&](int t, double v, int j, int ts, int te, int la_known) {
         const int kk = nb + j;
-        const int ts = S.tstart[j], te = S.tstart[j + 1];
         if (v > 0.0 || t == ts) {
           // the node's survivors: count (all pieces), and this task's rank among them (descending volume, index on ties)
           int rank = 0, c = 0;
@@ -807,7 +815,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
           }
           if (v > 0.0) {
             const int slot = cb + rank;
-            const int la = S.nla[kk + 1 + (t - ts)];
+            const int la = la_known >= 0 ? la_known : (int)S.nla[kk + 1 + (t - ts)];
             double mx, my, mz, ma;
             dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
                             mx, my, mz, ma);
@@ -822,17 +830,17 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
             S.ncc[slot] = 0;
           }
         }
+      };
+      if (tid < T) create(tid, keep_v, keep_j, keep_ts, keep_te, keep_la);
+      for (int t = tid + BS; t < T; t += BS) {
+        const int j = tmap[t];
+        create(t, tvol[t], j, S.tstart[j], S.tstart[j + 1], -1);
       }
       tree_barrier<NCAP>();
       AGBNP_BUILD_STAMP(13);
       tail += created;
       nb += nin;
     }
-    if (tid == 0) S.lvl[L + 2] = tail;
-  }
-  if (tid == 0) {
-    // lvl[L+1] already equals tail (set when level L-1 was expanded); deeper levels are empty
-    for (int M = L + 2; M <= 9; M++) S.lvl[M] = tail;
   }
   tree_barrier<NCAP>();
   *nnodes_out = tail;
