@@ -17,7 +17,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "agbnp::" in r["Kernel_Name"]:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("agbnp::", "")
-            base = name if name.startswith("k_rows") else name.split("<")[0]  # (k_rows<0 | 1 | 2>: different kernels)
+            base = name.replace(", false>", ">").replace(", true>", ">[single]") if name.startswith("k_rows") else name.split("<")[0]  # (k_rows<0 | 1 | 2>: different kernels)
             d[base].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 
