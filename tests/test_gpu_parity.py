@@ -843,6 +843,22 @@ def test_every_capacity_variant_is_exact(gpu_required, monkeypatch, n, spacing, 
     assert int(ctx.kernel.scalar("total_nodes")) == nheavy + sum(o.tree_stats()["level_counts"][2:])
 
 
+def test_big_subtrees_are_shared_in_gaussvol_mode_too(gpu_required):
+    """Version 0 (GaussVol only: three launches, the bookkeeping rides in k_outputs) walks the same sharing protocol."""
+    sysm = _lattice_cluster(150, 0.24, 1, [0.17, 0.18, 0.19, 0.2])
+    oracle = Oracle(*sysm.params(), version=0)
+    e, f, ctx = gpu_eval(sysm, 0)
+    eo, fo = oracle.execute(sysm.pos)
+    assert_close(e, f, eo, fo)
+    assert int(ctx.kernel.scalar("variant")) < 2 and int(ctx.kernel.scalar("max_subtree_nodes")) > 512
+    for step in range(4):  # planned packings with shared subtrees, evaluation after evaluation
+        pos = sysm.pos + np.random.default_rng(step).normal(0.0, 0.001, sysm.pos.shape)
+        ctx.setPositions(pos)
+        e, f = ctx.getState()
+        eo, fo = oracle.execute(pos)
+        assert_close(e, f, eo, fo)
+
+
 @pytest.mark.parametrize("n,spacing,seed,whole_variant", [(150, 0.24, 1, 2), (150, 0.22, 1, 3)])
 def test_big_subtrees_are_shared_before_the_variant_is_raised(gpu_required, n, spacing, seed, whole_variant):
     """The same clusters with the default settings: a lone subtree that outgrows the store is first shared four ways (the
