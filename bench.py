@@ -342,12 +342,14 @@ class Replica:
         return out
 
 
-def secondary_entry(dev, name, version, steps, warmup, cpu_evals, method=None, cutoff=1.0, mode=None, **oracle_kw):
-    """ms/eval, ns/day and parity-on-sample of another configuration (rank 0, one GPU)."""
+def secondary_entry(dev, name, version, steps, warmup, cpu_evals, method=None, cutoff=1.0, mode=None, preheat_seconds=0.05, **oracle_kw):
+    """ms/eval, ns/day and parity-on-sample of another configuration (rank 0, one GPU); the headline's protocol: settle,
+    a short pre-heat (a new context starts on cold caches and an unplanned forest packing), then the timed steps."""
     system = load_workload(name)
     r = Replica(dev, system, version, steps + warmup, 7000, method=method, cutoff=cutoff, mode=mode)
     if not r.settle(warmup):
         raise SystemExit(f"bench: tree capacity did not settle ({name})")
+    r.preheat(preheat_seconds, max(warmup, 5))
     seconds = r.timed(warmup, steps)
     if seconds is None:
         raise SystemExit(f"bench: tree capacity did not settle ({name})")
