@@ -1395,27 +1395,6 @@ def test_slice_length_of_the_neighbour_rows_is_tuned_on_the_device(gpu_required,
     assert int(k3.scalar("row_slice")) == 256 and int(k3.scalar("row_builds")) == 1
 
 
-def test_born_rows_at_the_tail_of_the_cavity_launch(gpu_required, systems, monkeypatch):
-    """AGBNP_HIP_BORN_TAIL=1 (experiment, off by default): the Born rows ride in the cavity launch behind the forest
-    workgroups and wait on a device-scope counter of finished tree workgroups.  Same numbers, lists rebuilt when atoms move."""
-    s = systems("1dwc")
-    monkeypatch.setenv("AGBNP_HIP_ROWS", "1")
-    monkeypatch.setenv("AGBNP_HIP_BORN_TAIL", "1")
-    monkeypatch.setenv("AGBNP_HIP_ROW_SLICE", "320")  # (fixed: every build below is one that moving atoms asked for)
-    k = P.HipCalcAGBNPForceKernel()
-    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
-    oracle = Oracle(*s.params(), version=1)
-    rng = np.random.default_rng(2)
-    pos = s.pos.copy()
-    for sigma in (0.0, 0.003, 0.07, 0.002):
-        pos = pos + rng.normal(0.0, sigma, pos.shape) if sigma > 0 else pos
-        f = np.zeros((s.n, 3))
-        e = k.execute(pos, f)
-        eo, fo = oracle.execute(pos)
-        assert_close(e, f, eo, fo)
-    assert int(k.scalar("row_builds")) == 2
-
-
 def test_two_contexts_on_two_streams_do_not_stall_or_disturb_each_other(gpu_required, systems):
     """Multi-walker use: two contexts enqueue on streams of their own; parameters of one are updated (in place, behind a
     drain of ITS streams only) while evaluations of the other are in flight.  Both end with the oracle's numbers."""
