@@ -397,9 +397,13 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
     };
     const bool queued = nforests > grid;
     const bool det = A.det != 0;
+    // whether the evaluation is void (its forces are then withheld) is final since the launches before this one: asked for
+    // NOW, with the first forest's topology, not in front of the flush, where the answer is one more cold round trip that
+    // every workgroup waits for with its sums ready (round 4)
+    const bool is_void = write_forces && evaluation_void(A.status);
     request_topology(block);
     bool have_parameters = false;
-    for (;;) {
+    for (int slot = block;;) {  // (`slot`: the forest in hand; the diagnostic stamps log by it)
       PSTAMP_BEGIN();
       const int nnodes = h_nnodes, natoms = h_natoms, m = h_m;
       int npairs = h_npairs;
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
         if (slot_ >= nforests) break;
         request_topology(slot_);
         have_parameters = false;
+        slot = slot_;
         continue;
       }
       if (tid == 0) {
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
         have_parameters = true;
       }
       if (write_forces) {  // force = -gradient, straight into the caller's buffer (nothing of an overflowed evaluation)
-        if (!evaluation_void(A.status)) {
+        if (!is_void) {
           if (A.out.force_fixed) {
             for (int la = tid; la < natoms; la += BS) add_force(A.out, __double2loint(S.at[9][la]), -S.at[6][la], -S.at[7][la], -S.at[8][la]);
           } else {
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
       PSTAMP(2);
       PSTAMP_FLUSH();
       if (!next_there) break;  // (one forest per workgroup, or the queue is empty)
+      slot = next;
     }
     return;
   }
