@@ -280,10 +280,18 @@ class Replica:
         self.d_energy = dev.zeros((1,), torch.float64)
         self.stream = dev.current_stream() if stream is None else stream.cuda_stream
         self.step_bytes = self.n * 3 * 8
+        # AGBNP_BENCH_FAIL_AT=<rank>:<k>: the k-th evaluation of that rank's TIMED pass raises (test hook, see Replica.run)
+        want = os.environ.get("AGBNP_BENCH_FAIL_AT", "").split(":")
+        self.fail_at = int(want[1]) if len(want) == 2 and int(want[0]) == int(os.environ.get("RANK", "0")) else -1
+        self.in_timed_pass, self.timed_calls = False, 0
 
     def run(self, first, count):
         base = self.d_pos.data_ptr()
         for s in range(first, first + count):
+            if self.in_timed_pass:  # (tests of the N > 1 path on real GPUs: a rank that dies between the barriers)
+                self.timed_calls += 1
+                if self.timed_calls == self.fail_at:
+                    raise RuntimeError(f"injected failure at evaluation {self.timed_calls} of this rank's timed pass (AGBNP_BENCH_FAIL_AT)")
             self.kernel.execute_device(base + s * self.step_bytes, self.d_force.data_ptr(), self.d_energy.data_ptr(), self.stream)
 
     def settle(self, count, agree=None):
@@ -323,10 +331,14 @@ class Replica:
             barrier()
             self.dev.synchronize()
             t0 = time.perf_counter()
-            self.run(first, count)
+            self.in_timed_pass = True
+            try:
+                self.run(first, count)
+            finally:
+                self.in_timed_pass = False
             self.dev.wait_idle()
+            t1 = time.perf_counter()  # (this rank's time; the job's is the MAX over the ranks, taken by the caller)
             barrier()
-            t1 = time.perf_counter()
             # finish() reads the device's sticky overflow log: EVERY one of the timed evaluations is accounted for, not
             # just the last.  Non-zero = some were withheld (capacity negotiation still under way): time the run again.
             if not agree(self.kernel.finish(self.stream)):
@@ -660,6 +672,7 @@ def worker(args):
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
     dev = make_backend(torch, local_rank, backend)
+    print(f"bench: rank {rank} of {env_world}: pid {os.getpid()}, device {getattr(dev, 'index', '?')}", file=sys.stderr, flush=True)
     coll_device = dev.device if backend == "nccl" else torch.device("cpu")
     # AGBNP_BENCH_FORCE_DIST=1: a ONE-rank job still initialises the process group and sends every collective through the
     # backend (a rehearsal of the RCCL plumbing on a box with one GPU)
@@ -691,6 +704,18 @@ def worker(args):
     record = {"rank": rank, "local_rank": local_rank, **dev.identity(),
               "ms_per_eval": 1e3 * elapsed_local / K, "ns_day": 86.4 / (1e3 * elapsed_local / K), "pid": os.getpid(),
               "timed_tries": rep.tries, "clock_warm_evals": warm_evals}
+    if mdist is not None and args.cpu_evals > 0:
+        # N > 1: EVERY rank checks the first of its own timed geometries against the CPU oracle (the ranks run different
+        # geometries on different devices; rank 0's sample says nothing about rank 5's GPU).  All ranks at once, one host
+        # core each, outside the timed region; a rank that disagrees ends the job.
+        def own_sample():
+            oracle_kw = {"cutoff": 1.0} if mode in ("fast", "fast+single") else {}
+            cpu_ms, de, df = cpu_baseline_leg(system, rep.geoms[W:], rep.host_results(W, 1), 1, **oracle_kw)
+            if mode != "fast+single" and not (de < 1e-4 and df < 1e-4):
+                raise SystemExit(f"rank {rank}: the HIP path disagrees with the CPU oracle on this rank's sample (dE {de:.3e}, dF {df:.3e})")
+            return {"evals": 1, "max_abs_dE_kJmol": de, "max_abs_dF_kJmolnm": df, "cpu_ms_per_eval": cpu_ms}
+        record["parity_on_sample"] = job.run("parity sample of this rank", own_sample)
+        job.sync()
     per_rank = gather_records(mdist, record, coll_device)
     value = world * 86.4 / ms_per_step  # whole job: all replicas' steps / max-over-ranks time
 

@@ -70,17 +70,20 @@ enum StatusWord {
                            // the subtree among more items instead of moving the whole system to a larger store
   kStatOrderStale = 11,    // agbnp_hip_execute_openmm: the context's atom order is not the one the engine's particle -> slot map
                            // was built for (OpenMM has reordered its atoms): evaluation void, the map is rebuilt, the host repeats
-  kStatEvalWords = 12,     // ---- everything below is sticky
-  kStatEvalSeq = 12,       // evaluations enqueued since the last agbnp_hip_finish
-  kStatBadCount = 13,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
-  kStatStickyNode = 14,    // OR of the per-evaluation overflow words over those evaluations
-  kStatStickyAtom = 15,
-  kStatStickyPack = 16,
-  kStatStickyRow = 17,
-  kStatStickyOrder = 18,
-  kStatStickySplit = 19,   // MAX of kStatSplitWanted over those evaluations
-  kStatWords = 20,
-  kStatBadBitmap = 20,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatForestOverflow = 12,  // the part of kStatPackOverflow that IS a misprediction of the packing: forests of SEVERAL work items
+                           // that outgrew their store (a lone splittable item is counted in kStatPackOverflow only: the
+                           // capacity the packing assumes is not tightened for it)
+  kStatEvalWords = 13,     // ---- everything below is sticky
+  kStatEvalSeq = 13,       // evaluations enqueued since the last agbnp_hip_finish
+  kStatBadCount = 14,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
+  kStatStickyNode = 15,    // OR of the per-evaluation overflow words over those evaluations
+  kStatStickyAtom = 16,
+  kStatStickyPack = 17,
+  kStatStickyRow = 18,
+  kStatStickyOrder = 19,
+  kStatStickySplit = 20,   // MAX of kStatSplitWanted over those evaluations
+  kStatWords = 21,
+  kStatBadBitmap = 21,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
   kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };

@@ -123,6 +123,7 @@ struct agbnp_hip_context {
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
   double skin = 0.1;           // nm; AGBNP_HIP_SKIN
+  double row_move = -1.0;      // nm; AGBNP_HIP_ROW_MOVE, read ONCE when the context is created (< 0: half the skin)
   int nlh_stride = 0, nla_stride = 0;  // entries reserved per list part
   DevBuf<int2> d_sizes;
   DevBuf<double> d_born_part, d_born, d_born_fp, d_brw, d_e_atom, d_gbf, d_dbf, d_egb_part, d_components;
@@ -350,6 +351,9 @@ void wire_args(agbnp_hip_context* c) {
   P.det = (c->mode & AGBNP_HIP_MODE_DETERMINISTIC) ? 1 : 0;
   P.range2 = P.fast ? std::min(kI4MaxA * kI4MaxA, c->cutoff * c->cutoff) : kI4MaxA * kI4MaxA;
   P.gb_cut2 = P.fast ? c->cutoff * c->cutoff : 1e300;
+  // far strips (pair_kernels.hip, gb_strip): only systems with more than 8192 atoms can have blocks some 4 nm apart in
+  // numbers that pay for the test (1dwc, 4152 atoms: none; 2clr, 5983: 3-5 %); AGBNP_HIP_GB_FAR = 0 / 1 forces it (tests)
+  P.gb_far = !P.fast && (getenv("AGBNP_HIP_GB_FAR") ? atoi(getenv("AGBNP_HIP_GB_FAR")) != 0 : c->n > 8192) ? 1 : 0;
   P.pslot = c->d_pslot.p;
   P.nslots = (int)c->d_pslot.count;
   P.nhb = (c->nh + 63) / 64;
@@ -423,7 +427,7 @@ void wire_args(agbnp_hip_context* c) {
     // an atom further than this from where it was at the last build makes the lists stale: half the skin -- or
     // AGBNP_HIP_ROW_MOVE (nm; measurement only: 0 rebuilds the lists at every new geometry at the default skin, which is how
     // bench.py prices a rebuild evaluation)
-    const double move = getenv("AGBNP_HIP_ROW_MOVE") ? std::min(std::max(atof(getenv("AGBNP_HIP_ROW_MOVE")), 0.0), 0.5 * c->skin) : 0.5 * c->skin;
+    const double move = c->row_move >= 0.0 ? std::min(c->row_move, 0.5 * c->skin) : 0.5 * c->skin;
     P.nl_move2 = move * move;
     P.nl_flag = c->d_nl_flag.p;
     P.row_target = c->row_slice > 0 ? 0 : 2 * c->cus;
@@ -492,7 +496,7 @@ void wire_args(agbnp_hip_context* c) {
     P.pack_enabled = no_pack ? 0 : (getenv("AGBNP_HIP_ITEMS_ALONE") ? 2 : 1);
     const int round_permille = getenv("AGBNP_HIP_ROUND_PERMILLE") ? atoi(getenv("AGBNP_HIP_ROUND_PERMILLE")) : 1000;
     P.round_permille = std::max(100, round_permille);
-    P.replan_every = std::max(1, getenv("AGBNP_HIP_REPLAN_EVERY") ? atoi(getenv("AGBNP_HIP_REPLAN_EVERY")) : 4);
+    P.replan_every = std::max(1, getenv("AGBNP_HIP_REPLAN_EVERY") ? atoi(getenv("AGBNP_HIP_REPLAN_EVERY")) : 16);
     const int split_big = getenv("AGBNP_HIP_SPLIT_BIG") ? atoi(getenv("AGBNP_HIP_SPLIT_BIG")) : 3;
     const int split_permille = getenv("AGBNP_HIP_SPLIT_PERMILLE") ? atoi(getenv("AGBNP_HIP_SPLIT_PERMILLE")) : 550;
     // a full device has slot_cap = 2 x subtrees work slots: more parts per subtree than that could plan more work items
@@ -541,6 +545,7 @@ int allocate_rows(agbnp_hip_context* c) {
   if (c->lut.nscreened > kMaxTypes || c->lut.nscreener > kMaxTypes) return AGBNP_HIP_OK;
   if ((size_t)c->lut.nscreened * c->lut.nscreener * (kI4Nodes - 1) * 2 * sizeof(double2) > kMaxTableBytes) return AGBNP_HIP_OK;
   if (getenv("AGBNP_HIP_SKIN")) c->skin = std::min(1.0, std::max(0.0, atof(getenv("AGBNP_HIP_SKIN"))));
+  if (getenv("AGBNP_HIP_ROW_MOVE")) c->row_move = std::max(atof(getenv("AGBNP_HIP_ROW_MOVE")), 0.0);
   if (getenv("AGBNP_HIP_ROW_SLICE")) c->row_slice = atoi(getenv("AGBNP_HIP_ROW_SLICE"));
   if (getenv("AGBNP_HIP_ROW_FILL")) c->row_fill = std::max(0.01, atof(getenv("AGBNP_HIP_ROW_FILL")));  // (tests: force the walk to widen)
   auto sorted_by_type = [&](int count, auto type_of) {
@@ -861,6 +866,8 @@ int upload_identity_packing(agbnp_hip_context* c) {
     forest.push_back(no_plan);
     forest.push_back(0);  // [slots+5] clean plans in a row since the assumed capacity was last tightened
     forest.push_back(0);  // [slots+6] packings planned so far (diagnostic: bench.py counts the plans inside a timed region)
+    forest.push_back(0);  // [slots+7] total nodes and
+    forest.push_back(0);  // [slots+8] largest subtree of the evaluation the packing in use was planned from (drift trigger)
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
@@ -925,6 +932,11 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   // evaluation that follows a withheld one is otherwise planned from whatever evaluation ran last), and if a lone item
   // outgrew the store while its subtree was shared by fewer than four, every subtree is shared four ways from here on
   // (straight to four: one repeat instead of a ladder of them; the fallback only ever runs repeats) ...
+  // It stays at four when the capacity variant is raised below (ADVICE r04 asked for a reset; measured: a geometry that has to
+  // climb several variants -- test_graph_replay_..., 5527-node subtree -- then pays TWO repeats per variant, whole subtrees
+  // first and four-way next, instead of one; the fallback only ever runs repeats, the planned packings decide the parts from
+  // the measured shapes whatever this says)
+  const bool raise = s[kStatStickyNode] || s[kStatStickyAtom];
   if (s[kStatStickySplit] > 0) c->fallback_parts = 4;
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
@@ -944,7 +956,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
     wire_args(c);
     c->generation++;
   }
-  if (s[kStatStickyNode] || s[kStatStickyAtom]) {
+  if (raise) {
     // ... and, if a single subtree outgrew the store, on the next larger capacity variant
     if (c->variant >= kGlobalVariant)
       return c->fail(AGBNP_HIP_ERR_CAPACITY, "overlap subtree exceeds the largest supported capacity (32768 nodes / 255 partners per heavy atom)");

@@ -64,12 +64,14 @@ struct PairArgs {
   double4* srec;           // [nslots] {B, f', brw, q} by slot, published by the GB stage's diagonal tiles for the chain rule
   double* ys;              // [nslots] the GB stage's Y sums by slot (atomic sums)
   double* pbox;            // [nslots/64][6] bounding box {min xyz, max xyz} of every 64-slot block
-  double* abox;            // [ceil(n/64)][6] the same for the 64-atom blocks in ATOM order (GB tiles; fast mode only)
+  double* abox;            // [ceil(n/64)][6] the same for the 64-atom blocks in ATOM order (GB tiles: fast mode, and the far-strip test of large systems)
   // Pair range.  Reference semantics: the descreening stages reach as far as the tables (2 nm), GB has no limit.
   // Fast mode (the semantics of the reference's OpenCL platform, AGBNPBornRadii.cl:268,430, AGBNPGBEnergy.cl:145,186):
   // every pair stage only meets pairs with r^2 < cutoff^2.
   double range2;           // squared reach of the Born / chain-rule stages: min(2 nm, cutoff)^2 in fast mode, else 4
   double gb_cut2;          // squared GB cutoff (fast mode) -- the GB kernel is compiled twice, this is read by the cut one
+  int gb_far;              // reference mode: 1 = the GB launch is the instantiation that tests every strip for "so far apart that the
+                           // pair terms are pure Coulomb to FP64 rounding" (systems large enough to have such strips)
   int cull_first;          // range-limited stages: 1 = a tile tests its bounding boxes before it asks for its data (large systems)
   int fast;                // 1 = fast mode
   int single;              // 1 = fast mode with the GB pair terms in single precision (GB rows; packed FP32 strips in the tile form)
@@ -82,10 +84,11 @@ struct PairArgs {
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
-  int* pack_state;         // [4] persistent ([3]: packings planned so far, a diagnostic): how often a packed forest has overflowed (tightens the packing; relaxes again after
-                           // clean plans: word [2] counts them); evaluations since
-                           // the packing in use was planned (huge = it is no plan: one subtree per slot)
-  int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 4)
+  int* pack_state;         // [6] persistent: [0] how often a packed forest has overflowed (tightens the packing; relaxes again after
+                           // clean plans: word [2] counts them); [1] evaluations since the packing in use was planned (huge = it
+                           // is no plan: one work item per slot); [3] packings planned so far (a diagnostic); [4], [5] total
+                           // nodes / largest subtree of the evaluation the packing was planned from (drift trigger)
+  int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 16), or when the trees have drifted
   int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k
   int* forest_time;        // [slots + 1] predicted time of every forest (packing_role -> dealing_role), then: are they there
   int* rows;               // [kRowStride * slots] the work items of the NEXT evaluation in WORK-SLOT order (what the tree kernel

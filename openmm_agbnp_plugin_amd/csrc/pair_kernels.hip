@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
       }
     }
   }
-  if (P.fast && !P.gb_rows && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage
+  if (((P.fast && !P.gb_rows) || P.gb_far) && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage / the far-strip test
     double lo[3], hi[3];
     {
       const Pos3 r = atom_position(P, i < P.n ? i : 0);
@@ -481,13 +481,21 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     return make_int2(v >> 9, v & 511);
   };
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
-  const bool overflow = (P.status[kStatNodeOverflow] | P.status[kStatAtomOverflow] | P.status[kStatPackOverflow]) != 0;
-  // level: how often the assumed capacity has been tightened by 15 % (a forest outgrew its store).  It relaxes again: after
-  // kPackRelax plans in a row without a misprediction one step is given back, so a run with the occasional overflow does
-  // not drift to one subtree per slot for the life of the context.
+  // every control word is asked for here, together, underneath the shapes (one cold round trip for all of them)
+  const int st_node = P.status[kStatNodeOverflow], st_atom = P.status[kStatAtomOverflow], st_pack = P.status[kStatPackOverflow];
+  const int st_forest = P.status[kStatForestOverflow];
+  const int ps_level = P.pack_state[0], age = P.pack_state[1], ps_clean = P.pack_state[2];
+  const int tot_planned = P.pack_state[4], max_planned = P.pack_state[5];
+  const bool overflow = (st_node | st_atom | st_pack) != 0;
+  // level: how often the assumed capacity has been tightened by 15 % (a FOREST outgrew its store: a misprediction of the
+  // packing; a lone item of a subtree that can still be shared is not one -- its subtree is shared among more items, the
+  // capacity assumed for everybody else stays).  It relaxes again: after kPackRelax plans in a row without a misprediction
+  // one step is given back, so a run with the occasional overflow does not drift to one subtree per slot for the life of
+  // the context.  Never beyond 6 (= packing off): whatever is queued behind a run of overflows, sixteen clean plans give a
+  // step back.
   constexpr int kPackRelax = 16;
-  const bool relax = P.status[kStatPackOverflow] == 0 && P.pack_state[0] > 0 && P.pack_state[2] >= kPackRelax;
-  const int level = P.pack_state[0] + (P.status[kStatPackOverflow] != 0 ? 1 : 0) - (relax ? 1 : 0);
+  const bool relax = st_pack == 0 && ps_level > 0 && ps_clean >= kPackRelax;
+  const int level = min(6, ps_level + (st_forest != 0 ? 1 : 0) - (relax ? 1 : 0));
   const bool pack = P.pack_enabled && !overflow && level < 6;
   float share = 0.9f;
   for (int k = 0; k < level; k++) share *= 0.85f;
@@ -511,10 +519,10 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const float fit_nodes = 0.85f * (share * (1.0f / 0.9f)) * (float)P.tree_node_cap;
   auto parts_of = [&](int2 sz) {
     int p = min(max_parts, 1 + (sz.x >= split_nodes ? 1 : 0) + (sz.x >= 2 * split_nodes ? 1 : 0) + (sz.x >= 3 * split_nodes ? 1 : 0));
-    if (P.split_fit) {
+    if (P.split_fit) {  // the smallest p <= 4 with (1 + l2) + 1.35 deep / p <= fit_nodes, straight-line
       const int l2 = max(sz.y - 1, 0);
-      const float deep = (float)max(sz.x - 1 - l2, 0);
-      while (p < 4 && (float)(1 + l2) + 1.35f * deep * inv_parts(p) > fit_nodes) p++;
+      const float need = 1.35f * (float)max(sz.x - 1 - l2, 0), room = fit_nodes - (float)(1 + l2);
+      p = max(p, need <= room ? 1 : need <= 2.0f * room ? 2 : need <= 3.0f * room ? 3 : 4);
     }
     return p;
   };
@@ -525,6 +533,8 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     return (unsigned)fminf(w, 2047.0f);
   };
   __syncthreads();
+  // the tree statistics of THIS evaluation: plain reads, no histogram yet (three evaluations in four, or fifteen in sixteen,
+  // need nothing else of this role)
   int tot = 0, mx = 0, ma = 0;
 #pragma unroll 1
   for (int h0 = t; h0 < P.nh; h0 += 256 * 4) {  // (four LDS reads in flight)
@@ -537,12 +547,8 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
       tot += sz[c].x;
       mx = max(mx, sz[c].x);
       ma = max(ma, sz[c].y);
-      const int parts = parts_of(sz[c]);
-      const unsigned w = weight(sz[c], parts);
-      atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
     }
   }
-  PAIR_STAMP(1, 7);
   for (int off = 32; off > 0; off >>= 1) {
     tot += __shfl_xor(tot, off, 64);
     mx = max(mx, __shfl_xor(mx, off, 64));
@@ -554,28 +560,49 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     imax[8 + (t >> 6)] = tot;
   }
   __syncthreads();
+  const int tot_now = (imax[8] + imax[9]) + (imax[10] + imax[11]);
+  const int max_now = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
   // The tree statistics are taken at every evaluation.  The PACKING is planned anew when the one in use is not a plan at
-  // all (a fresh context, or the one-subtree-per-slot fallback after an overflow: its age says so), when this evaluation
-  // overflowed, and otherwise at every replan_every-th evaluation: geometries change little between MD steps, a
-  // misprediction is caught by the overflow protocol whatever its age, and everything below this point is latency that
-  // small systems and version 0 (whose k_outputs launch lasts as long as this role) cannot hide.
-  const int age = P.pack_state[1];
-  const bool plan = overflow || age + 1 >= P.replan_every;
+  // all (a fresh context, or the fallback after an overflow: its age says so), when this evaluation overflowed, when the
+  // trees have DRIFTED from the shapes the packing was planned for (total nodes by more than 1.5 %, or the largest subtree
+  // grown by more than 6 %), and otherwise at every replan_every-th evaluation: geometries change little between MD steps,
+  // a misprediction is caught by the overflow protocol whatever the packing's age, and everything below this point is
+  // latency (a plan ends ~5 us after the GB launch's own work items on 1dwc) that small systems and version 0 (whose
+  // k_outputs launch lasts as long as this role) cannot hide at all.
+  const bool drifted = abs(tot_now - tot_planned) * 64 > tot_planned || max_now * 16 > max_planned * 17;
+  const bool plan = overflow || age + 1 >= P.replan_every || drifted;
+  PAIR_STAMP(1, 7);
   if (t == 0) {
-    P.status[kStatTotalNodes] = (imax[8] + imax[9]) + (imax[10] + imax[11]);
-    P.status[kStatMaxNodes] = max(max(imax[0], imax[1]), max(imax[2], imax[3]));
+    P.status[kStatTotalNodes] = tot_now;
+    P.status[kStatMaxNodes] = max_now;
     P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
     P.pack_state[0] = level;
-    // (after an overflow the one-subtree-per-slot fallback written below is no plan: the next clean evaluation plans anew)
+    // (after an overflow the fallback written below is no plan: the next clean evaluation plans anew)
     if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
-    if (plan) P.pack_state[2] = (overflow || relax) ? 0 : P.pack_state[2] + 1;
+    if (plan) P.pack_state[2] = (st_forest != 0 || relax) ? 0 : ps_clean + 1;
     if (plan) P.pack_state[3] += 1;  // (plans so far: a diagnostic)
+    if (plan && !overflow) P.pack_state[4] = tot_now, P.pack_state[5] = max_now;  // (the shapes this plan is made for)
     if (!plan) {
       P.status[kStatForests] = P.nforests[0];       // (the packing stays)
       P.forest_time[P.tree_slot_cap] = 2;           // tells dealing_role that there is nothing to deal
     }
   }
   if (!plan) return;
+  // (count, weight) histogram of the work items over the weight bins
+#pragma unroll 1
+  for (int h0 = t; h0 < P.nh; h0 += 256 * 4) {
+    int2 sz[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) sz[c] = shape(min(h0 + 256 * c, P.nh - 1));
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (h0 + 256 * c >= P.nh) continue;
+      const int parts = parts_of(sz[c]);
+      const unsigned w = weight(sz[c], parts);
+      atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts));
+    }
+  }
+  __syncthreads();
   // exclusive scan of the (count, weight) histogram (bins are in descending weight order): thread t owns bins 2t, 2t+1
   const unsigned long long h0 = comb[2 * t], h1 = comb[2 * t + 1];
   unsigned long long incl = h0 + h1;
@@ -813,30 +840,54 @@ struct StripSums {
 };
 constexpr int kGbStripFlag = 1 << 24;  // work item = I0 | J << 12 | flag
 
-template <bool kCut>
+// Squared gap between the bounding box of block J and the nearer of the boxes of blocks I0, I0 + 1 (atom-order boxes of k_prep)
+__device__ __forceinline__ double strip_gap2(const PairArgs& P, int I0, int J) {
+  double gmin = 1e300;
+  for (int b = 0; b < 2; b++) {
+    double gap2 = 0.0;
+    for (int d = 0; d < 3; d++) {
+      const double g = fmax(0.0, fmax(P.abox[6 * J + d] - P.abox[6 * (I0 + b) + 3 + d], P.abox[6 * (I0 + b) + d] - P.abox[6 * J + 3 + d]));
+      gap2 += g * g;
+    }
+    gmin = fmin(gmin, gap2);
+  }
+  return gmin;
+}
+// max over the wave of the HIGH words of positive doubles (monotonic in the value): 32-bit DPP steps; lane 63 holds it
+__device__ __forceinline__ int wave_max_hi_to_lane63(int m) {
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x111, 0xf, 0xf, false));  // row_shr:1 (a lane without a source keeps its own)
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x112, 0xf, 0xf, false));  // row_shr:2
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x114, 0xf, 0xf, false));  // row_shr:4
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x118, 0xf, 0xf, false));  // row_shr:8 -> lane 15 of every row
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+  m = max(m, __builtin_amdgcn_update_dpp(m, m, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+  return m;
+}
+
+// kFar (reference mode, systems large enough to have such strips: the host picks the instantiation): a strip whose blocks
+// are so far apart that exp(-d^2 / (4 B_i B_j)) < 2^-60 for every one of its pairs -- box gap^2 > 4 * 60 ln2 * Bmax_J *
+// Bmax_I, the Born radii of its 192 atoms are in the prologue's registers -- walks a Coulomb-only loop: the pair term
+// 1/sqrt(d^2 + B_i B_j eta) IS 1/sqrt(d^2) to FP64 rounding there (B_i B_j eta < 2^-67 d^2), the direct force's factor
+// 1 - eta/4 IS 1, and the Y term (< 2^-60 of a pair's Coulomb energy) is dropped: no exp2, no Born-radius products, no Y
+// sums -- about half the instructions of a pair step (ReferenceAGBNPKernels.cpp:477-499 evaluates the full formula for
+// every pair; the 16 608-atom lattice has 71 % of its tiles out there, 1dwc none).
+constexpr double kGbFarFactor = 4.0 * 60.0 * 0.69314718055994530942;
+template <bool kCut, bool kFar>
 __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __restrict__ aposq, const double* __restrict__ born_part,
                                          const double* __restrict__ inv_rvdw, double* __restrict__ gb_rows, double* __restrict__ egb_out,
-                                         const PairArgs& P, char* s_area, double* s_e) {
+                                         const PairArgs& P, char* s_area, double* s_e, int* s_bmax) {
   double2* const s_xy = reinterpret_cast<double2*>(s_area);  // block J twice over
   double2* const s_zq = s_xy + 128;
   double2* const s_bb = s_zq + 128;
   double2* const s_i = s_bb + 128;  // blocks I0, I0 + 1: [block][{x, y}, {z, q}, {B, -log2(e)/(4 B)}][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (kCut) {  // fast mode: both tiles of the strip beyond the cutoff
-    double gmin = 1e300;
-    for (int b = 0; b < 2; b++) {
-      double gap2 = 0.0;
-      for (int d = 0; d < 3; d++) {
-        const double g = fmax(0.0, fmax(P.abox[6 * J + d] - P.abox[6 * (I0 + b) + 3 + d], P.abox[6 * (I0 + b) + d] - P.abox[6 * J + 3 + d]));
-        gap2 += g * g;
-      }
-      gmin = fmin(gmin, gap2);
-    }
-    if (gmin >= P.gb_cut2) {
+    if (strip_gap2(P, I0, J) >= P.gb_cut2) {
       if (threadIdx.x == 0) egb_out[0] = 0.0;
       return;
     }
   }
+  const double far_gap2 = kFar ? strip_gap2(P, I0, J) : 0.0;  // (scalar loads, underneath the records)
   PAIR_STAMP_WHERE(1, I0 | (J << 12) | kGbStripFlag);
   // the Y sums leave by pair-order slot (the chain-rule stage reads them so): the wave that will add them asks for
   // the slots of its three blocks now
@@ -867,6 +918,10 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
       r[64 + lane] = make_double2(pa.z, qa);
       r[128 + lane] = make_double2(bra.br, (-0.25 * 1.4426950408889634074) * bra.inv_br);
     }
+    if (kFar) {  // an upper bound of the block's largest Born radius: (max high word + 1) << 32
+      const int m = wave_max_hi_to_lane63(__double2hiint(bra.br));
+      if (lane == 63) s_bmax[wave] = m + 1;
+    }
   }
   __syncthreads();
   PAIR_STAMP(1, 1);
@@ -879,6 +934,37 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   const double2* __restrict__ jzq = s_zq + base;
   const double2* __restrict__ jbb = s_bb + base;
   double fxa = 0, fya = 0, fza = 0, ya = 0, fxc = 0, fyc = 0, fzc = 0, yc = 0, fxj = 0, fyj = 0, fzj = 0, yj = 0, e = 0;
+  bool far = false;
+  if (kFar) {
+    const double bj = __hiloint2double(s_bmax[0], 0), bi = __hiloint2double(max(s_bmax[1], s_bmax[2]), 0);
+    far = __builtin_amdgcn_readfirstlane(far_gap2 > kGbFarFactor * bj * bi ? 1 : 0) != 0;  // (the same for every lane of the workgroup)
+  }
+  if (kFar && far) {
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {  // Coulomb only (see above)
+      const double2 xy = jxy[k], zq = jzq[k];
+      const double dxa = xy.x - axy.x, dya = xy.y - axy.y, dza = zq.x - azq.x;
+      const double d2a = fma(dza, dza, fma(dya, dya, dxa * dxa));
+      const double fa = rsqrt_pos(d2a);
+      const double s1a = (azq.y * zq.y) * fa;
+      const double mwa = s1a * (fa * fa);
+      const double dxc = xy.x - cxy.x, dyc = xy.y - cxy.y, dzc = zq.x - czq.x;
+      const double d2c = fma(dzc, dzc, fma(dyc, dyc, dxc * dxc));
+      const double fc = rsqrt_pos(d2c);
+      const double s1c = (czq.y * zq.y) * fc;
+      const double mwc = s1c * (fc * fc);
+      e += s1a + s1c;
+      fxa = fma(dxa, mwa, fxa);
+      fya = fma(dya, mwa, fya);
+      fza = fma(dza, mwa, fza);
+      fxc = fma(dxc, mwc, fxc);
+      fyc = fma(dyc, mwc, fyc);
+      fzc = fma(dzc, mwc, fzc);
+      fxj = rot1(fma(-dxa, mwa, fma(-dxc, mwc, fxj)));
+      fyj = rot1(fma(-dya, mwa, fma(-dyc, mwc, fyj)));
+      fzj = rot1(fma(-dza, mwa, fma(-dzc, mwc, fzj)));
+    }
+  } else
 #pragma unroll 4
   for (int k = 0; k < 16; k++) {
     const double2 xy = jxy[k], zq = jzq[k], bj = jbb[k];
@@ -947,7 +1033,9 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   const int ia = 64 * I0 + lane, ic = ia + 64, j = 64 * J + lane;
   const bool det = P.det != 0;  // deterministic mode: a tile's totals are rounded to the sums' quantum (device_math.h)
   const double qs = wave == 3 ? kQSum : kQGrad;
-  if (P.rows_on && wave == 3) {  // (the row form never runs in the deterministic mode)
+  if (kFar && far && wave == 3) {
+    // (a far strip has no Y sums to add)
+  } else if (P.rows_on && wave == 3) {  // (the row form never runs in the deterministic mode)
     if (ia < n) hbm_add(&P.bw[ia], beta_a * fold(3));
     if (ic < n) hbm_add(&P.bw[ic], beta_c * fold(7));
     if (j < n) hbm_add(&P.bw[j], beta_j * fold(11));
@@ -1081,7 +1169,7 @@ __device__ __forceinline__ void gb_strip_f32(int n, int I0, int J, const double4
   if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
-template <bool kCut, bool kSingle>
+template <bool kCut, bool kSingle, bool kFar>
 __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                   const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
                                                   const double* __restrict__ alpha, double* __restrict__ born,
@@ -1095,6 +1183,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   // workgroup 0 does the bookkeeping of the next evaluation (it needs the tree's shapes only): mostly serial work that
   // hides underneath this launch, the longest of the pair stages
   __shared__ double s_e[4];
+  __shared__ int s_bmax[4];  // (kFar: the blocks' largest Born radii)
   if (blockIdx.x == 0) {
     PAIR_STAMP(1, 0);
     packing_role(P, s_area, (int)sizeof(StripSums));
@@ -1118,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   PAIR_STAMP(1, 0);
   if (item & kGbStripFlag) {
     if (kSingle) return gb_strip_f32<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
-    return gb_strip<kCut>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e);
+    return gb_strip<kCut, kFar>(n, I, J, aposq, born_part, inv_rvdw, gb_rows, egb_part + (blockIdx.x - 1), P, s_area, s_e, s_bmax);
   }
   const bool diag = I == J;
   if (kCut && !diag) {  // fast mode: a tile whose two blocks are further apart than the cutoff has no pair to meet
@@ -1670,7 +1759,7 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     if (e != hipSuccess) return e;
   }
   if (P.rows_on) {  // row form of the two range-limited stages (and, in fast mode, of the GB stage)
-    auto gb = P.fast ? k_gb_tiles<true, false> : k_gb_tiles<false, false>;
+    auto gb = P.fast ? k_gb_tiles<true, false, false> : (P.gb_far ? k_gb_tiles<false, false, true> : k_gb_tiles<false, false, false>);
     const int born_groups = (P.n + kRowGroup - 1) / kRowGroup, chain_groups = (P.nh + kRowGroup - 1) / kRowGroup;
     auto walk_blocks = [](int lists, int cap) { return (lists + kRowWaves - 1) / kRowWaves * ((cap + kRowSlice - 1) / kRowSlice); };
     const int born_blocks = walk_blocks(born_groups * kBornParts, P.nlh_cap), chain_blocks = walk_blocks(chain_groups * kChainParts, P.nla_cap);
@@ -1708,7 +1797,8 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
                        (const double*)P.pbox, (const double4*)P.prec, (const double*)P.sv_vdw, P.inv_vol_h, P.lut, P.born_part, P.range2, P.det, P.cull_first);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKGbTiles);
-  auto gb = P.fast ? (P.single ? k_gb_tiles<true, true> : k_gb_tiles<true, false>) : k_gb_tiles<false, false>;
+  auto gb = P.fast ? (P.single ? k_gb_tiles<true, true, false> : k_gb_tiles<true, false, false>)
+                   : (P.gb_far ? k_gb_tiles<false, false, true> : k_gb_tiles<false, false, false>);
   hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
                      (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();

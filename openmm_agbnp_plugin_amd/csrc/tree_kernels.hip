@@ -177,7 +177,15 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
         const int parts0 = work_item_parts(items[0]);
         const bool splittable = m == 1 && rc == kBuildNodeOverflow && parts0 < 4 && A.split_fit != 0;
         atomicAdd(&A.status[(m > 1 || splittable) ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
-        if (splittable) atomicMax(&A.status[kStatSplitWanted], parts0);
+        if (m > 1) atomicAdd(&A.status[kStatForestOverflow], 1);  // (what tightens the packing's assumed capacity)
+        if (splittable) {
+          atomicMax(&A.status[kStatSplitWanted], parts0);
+          // The device reacts by itself (evaluations may be queued behind this one long before a host sees the log): the
+          // subtree's shape is recorded as "more than four stores' worth of nodes", so that this evaluation's bookkeeping
+          // -- whose fallback packing shares to FIT -- hands the subtree to four work items in the very next evaluation
+          // (its level-2 count is left at what the other items of the subtree report, or 0: the conservative side)
+          atomicAdd(reinterpret_cast<int*>(&A.sizes[work_item_root(items[0])]), 4 * NCAP);
+        }
         A.hdr[slot].nnodes = 0;
         A.hdr[slot].natoms = 0;
       }

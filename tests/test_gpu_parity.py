@@ -744,6 +744,29 @@ def test_config4_lattice_against_the_oracle_at_full_size(gpu_required, systems):
     assert int(ctx.kernel.scalar("forests")) > 5 * 256  # more than fit the device at once
 
 
+@pytest.mark.parametrize("name,shape,pitch", [("1dwc", (4, 1, 1), 5.5), ("2clr", (1, 1, 1), 0.0)])
+def test_far_strips_of_the_gb_stage_are_coulomb_to_rounding(gpu_required, systems, monkeypatch, name, shape, pitch):
+    """Reference mode on large systems: a GB strip whose blocks are further apart than sqrt(4 * 60 ln2 * Bmax_I * Bmax_J)
+    walks a Coulomb-only loop (exp(-d^2 / 4 B_i B_j) < 2^-60 there: the reference's pair term,
+    ReferenceAGBNPKernels.cpp:477-499, IS the Coulomb term to FP64 rounding).  An elongated 16 608-atom stand-in (four
+    copies of 1dwc in a row, 5.5 nm pitch: 22 nm long, most strips far) and 2clr (a few per cent of its strips) with the
+    test forced on: the oracle's numbers at the usual bar, and the same numbers as with the test switched off to 1e-9."""
+    base = systems(name)
+    s = P.lattice(base, *shape, pitch) if shape != (1, 1, 1) else base
+    pos = s.jittered(5, sigma=0.003)
+    out = {}
+    for far in ("1", "0"):
+        monkeypatch.setenv("AGBNP_HIP_GB_FAR", far)
+        ctx = P.AGBNPContext(P.AGBNPForce.from_arrays(*s.params(), version=1))
+        ctx.setPositions(s.pos)
+        ctx.getState()
+        ctx.setPositions(pos)
+        out[far] = ctx.getState()
+    eo, fo = Oracle(*s.params(), version=1).execute(pos)
+    assert_close(out["1"][0], out["1"][1], eo, fo)
+    assert abs(out["1"][0] - out["0"][0]) < 1e-9 * max(1.0, abs(eo) * 1e-3) and np.abs(out["1"][1] - out["0"][1]).max() < 1e-9
+
+
 def test_finite_difference_gradient_on_gpu(gpu_required, systems):
     s = systems("fixture264")
     force = P.AGBNPForce.from_arrays(*s.params(), version=1)
@@ -886,6 +909,47 @@ def test_big_subtrees_are_shared_before_the_variant_is_raised(gpu_required, n, s
     want = [oracle.execute(g) for g in geoms]
     assert abs(ene.item() - sum(w[0] for w in want)) < 6 * TIGHT
     assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 6 * TIGHT
+
+
+def test_a_lone_subtree_beyond_the_store_heals_on_the_device_while_evaluations_are_queued(gpu_required, systems):
+    """a FRESH context whose first evaluations are all queued on the device-resident path before anybody
+    reads the log (a captured MD graph, bench.py's drift chunks).  2clr has subtrees of up to 479 nodes; the smallest store
+    holds 432, so the first evaluation (one whole subtree per work slot) is withheld.  The device must react by itself: the
+    overflowing item records its subtree as too big, that evaluation's bookkeeping hands it to four work items, and
+    everything queued behind is COMPLETE -- not withheld until a host finish() arrives -- without the packing's assumed
+    capacity being tightened (a lone item is no misprediction of the packing)."""
+    torch = pytest.importorskip("torch")
+    s = systems("2clr")
+    oracle = Oracle(*s.params(), version=1)
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel(device=0)
+    k.initialize(force)
+    dev = torch.device("cuda:0")
+    geoms = [s.jittered(40 + step) for step in range(6)]
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(6):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 1 and list(k.withheld()) == [0]  # only the evaluation that met the unshared subtree
+    assert int(k.scalar("variant")) == 0 and int(k.scalar("pack_level")) == 0
+    assert int(k.scalar("max_subtree_nodes")) > 432
+    want = [oracle.execute(g) for g in geoms]
+    assert abs(ene.item() - sum(w[0] for w in want[1:])) < 5 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want[1:])).max() < 5 * TIGHT
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # the repeat completes the sum
+    assert k.finish(stream) == 0
+    assert abs(ene.item() - sum(w[0] for w in want)) < 6 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 6 * TIGHT
+    # ... and a long queue behind a late finish does not leave the packing switched off: level stays 0, forests are packed
+    for rep in range(3):
+        for i in range(6):
+            k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0
+    nheavy = int(np.sum(s.ishydrogen == 0))
+    assert int(k.scalar("pack_level")) == 0 and int(k.scalar("forests")) < nheavy
 
 
 def test_forest_packing_and_its_overflow_protocol(gpu_required, systems):
@@ -1515,7 +1579,7 @@ def test_random_walk_small_system_every_step(gpu_required, systems):
         assert_close(e, f, eo, fo)
         worst = max(worst, np.abs(f - fo).max())
     assert int(k.scalar("row_builds")) >= len(_predicted_rebuilds(walk))
-    assert int(k.scalar("pack_plans")) >= 300 // 4 - 2  # (a healthy packing is planned anew every fourth evaluation)
+    assert int(k.scalar("pack_plans")) >= 300 // 16 - 2  # (a healthy packing is planned anew every sixteenth evaluation, or when the trees have drifted)
 
 
 def test_every_queued_evaluation_behind_a_truncated_row_is_withheld(gpu_required, systems, monkeypatch):

@@ -208,6 +208,7 @@ def test_bench_main_self_launches_two_ranks_end_to_end():
     assert r["roofline"]["kernel"] == "k_tree_pseudo" and r["roofline"]["bound"] == "hbm"  # (the fake's slowest kernel)
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["ms_per_eval"] > 0
     assert r["parity_on_sample"]["max_abs_dF_kJmolnm"] == 0.0  # (the fake answers with the oracle itself)
+    assert [x["parity_on_sample"]["max_abs_dF_kJmolnm"] for x in r["ranks"]] == [0.0, 0.0]  # every rank checks its own sample
     assert "secondary" not in r
 
 
@@ -220,6 +221,15 @@ def test_bench_main_a_failing_rank_ends_the_self_launched_job():
     assert lines == []
     assert "fake HIP error" in p.stderr
     assert __import__("time").time() - t0 < 120
+
+
+def test_bench_main_failure_hook_of_the_gpu_tests():
+    """AGBNP_BENCH_FAIL_AT=<rank>:<k> (what tests/test_gpu_replicas.py uses on real GPUs): the k-th evaluation of that rank's
+    timed pass raises; same outcome as a HIP error."""
+    pytest.importorskip("torch")
+    p, lines = _self_launch({"AGBNP_BENCH_FAIL_AT": "1:3"}, "--cpu-evals", "0")
+    assert p.returncode == 1, (p.returncode, p.stderr[-2000:])
+    assert lines == [] and "injected failure at evaluation 3" in p.stderr
 
 
 def test_the_launching_parent_never_loads_the_gpu_stack():
