@@ -74,6 +74,26 @@ def newest_profile_dir():
     return os.path.join(root, tags[-1]) if tags else None
 
 
+def profile_head(directory=None):
+    """What the committed counter summaries were measured on (profiles/rNN/profile_head.json, written by
+    scripts/profile_round.sh: the library's build id = SHA-256 of its sources, the git head, the date) and whether that is
+    the library this process is running.  None when the newest profile carries no such record (rounds 1-4)."""
+    d = directory or newest_profile_dir()
+    path = os.path.join(d, "profile_head.json") if d else None
+    if not path or not os.path.exists(path):
+        return {"profile": os.path.relpath(d, ROOT) if d else None, "library_build_id": None, "git_head": None,
+                "matches_running_library": None, "note": "this profile predates the self-dating record"}
+    rec = json.load(open(path))
+    try:
+        from openmm_agbnp_plugin_amd import _lib
+        running = _lib.build_id()
+    except Exception:  # noqa: BLE001 -- (the CPU double of the tests has no library)
+        running = None
+    return {"profile": os.path.relpath(d, ROOT), "library_build_id": rec.get("library_build_id"), "git_head": rec.get("git_head"),
+            "taken": rec.get("taken"), "running_library_build_id": running,
+            "matches_running_library": (running == rec.get("library_build_id")) if running else None}
+
+
 ROW_KERNEL_NAMES = {"k_rows<0>": "k_born_rows", "k_rows<1>": "k_dborn_rows", "k_rows<2>": "k_gb_rows"}  # rocprof name -> engine name
 
 
@@ -672,7 +692,8 @@ def worker(args):
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("AGBNP_BENCH_BACKEND", "nccl")
     dev = make_backend(torch, local_rank, backend)
-    print(f"bench: rank {rank} of {env_world}: pid {os.getpid()}, device {getattr(dev, 'index', '?')}", file=sys.stderr, flush=True)
+    sys.stderr.write(f"bench: rank {rank} of {env_world}: pid {os.getpid()}, device {getattr(dev, 'index', '?')}\n")  # (one write: the ranks share the pipe)
+    sys.stderr.flush()
     coll_device = dev.device if backend == "nccl" else torch.device("cpu")
     # AGBNP_BENCH_FORCE_DIST=1: a ONE-rank job still initialises the process group and sends every collective through the
     # backend (a rehearsal of the RCCL plumbing on a box with one GPU)
@@ -751,7 +772,8 @@ def worker(args):
                                f"CutoffNonPeriodic 1.0 nm ({semantics}), one jittered geometry per step "
                                "(sigma 0.002 nm), positions/forces/energy resident in HBM",
                    "replicas": world, "tree_slots": slots, "kernel_variant": int(kernel.scalar("variant")), "mode": args.mode,
-                   "pair_stage_form": "rows" if int(kernel.scalar("rows_on")) else "tiles"},
+                   "pair_stage_form": "rows" if int(kernel.scalar("rows_on")) else "tiles",
+                   "forests": int(kernel.scalar("forests")), "pack_level": int(kernel.scalar("pack_level"))},
         "clock_warm_evals": warm_evals,
         "per_replica_ns_day": [round(r["ns_day"], 4) for r in per_rank],
         "ranks": per_rank,
@@ -802,6 +824,11 @@ def worker(args):
     result["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                           "algorithmic_bytes_per_launch": b_kernel.get(dominant, 0), "avg_launch_us": avg_us[dominant]}
+    head = profile_head()
+    result["roofline"]["profile_head"] = head  # (what `traffic` and the counter-based figures below were measured on)
+    if head.get("matches_running_library") is False:
+        print("bench: the committed counter summaries (" + str(head.get("profile")) + ") were taken on library build " + str(head.get("library_build_id")) +
+              ", this run is build " + str(head.get("running_library_build_id")) + ": traffic / issue bounds are those of the older kernels", file=sys.stderr)
     if eval_traffic:  # what really crosses the HBM interface, by the PMC counters of the committed profile
         result["eval_hbm_fraction_counter_bytes"] = (eval_traffic / (ms_per_step * 1e-3)) / (HBM_PEAK_GBS * 1e9)
         if traffic:
@@ -829,13 +856,17 @@ def worker(args):
         if counters and kname in counters:
             entry["lds_bank_conflict_share"] = counters[kname]["lds_conflict_share"]
         issue.append(entry)
+    for entry in issue:
+        entry["profile_head"] = head.get("git_head") or head.get("library_build_id")
     result["rooflines_issue"] = issue
     # speed of light of the evaluation as launched: per kernel the roof that binds it -- vector issue for the pair
     # kernels, the modelled bytes at the HBM peak for the rest (tree kernels: latency-bound far above that)
     issue_by_kernel = {e["kernel"]: e["bound_us"] for e in issue}
     sol = {k: issue_by_kernel.get(k, b_kernel.get(k, 0) / (HBM_PEAK_GBS * 1e9) * 1e6) for k in avg_us}
     result["speed_of_light_us"] = {"sum": round(sum(sol.values()), 2), "per_kernel": {k: round(v, 2) for k, v in sol.items()},
-                                   "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3)}
+                                   "frac_of_measured": round(sum(sol.values()) / (1e3 * ms_per_step), 3),
+                                   "profile_head": head.get("git_head") or head.get("library_build_id"),
+                                   "profile_matches_running_library": head.get("matches_running_library")}
     result["kernel_avg_us"] = {k: round(v, 2) for k, v in avg_us.items()}
     result["kernel_avg_us_note"] = ("hipEvent intervals of a second pass minus one uniform event overhead chosen so that the kernels sum to the "
                                     "measured step (they do by construction: this is a SPLIT of ms_per_step, not a check of it; the independent "
@@ -872,6 +903,8 @@ def worker(args):
                         **secondary_entry(dev, "trpcage", 1, 200, 20, 20, cutoff=1.2)))
         sec.append(dict(config="4: HIV-RT stand-in = 2x2x1 lattice of 1dwc (synthetic), AGBNP1",
                         **secondary_entry(dev, "1dwc_x4", 1, 40, 6, 1)))
+        sec.append(dict(config="(bundled example, not a BASELINE.json config) 2clr, 5983 atoms, AGBNP1: example/2clr_agbnp1.dms",
+                        **secondary_entry(dev, "2clr", 1, 200, 20, 2)))
         result["secondary"] = sec
         # the other evaluation modes on the headline workload (each has a line of its own with --mode; here for the record)
         result["other_modes"] = [dict(mode=m, **secondary_entry(dev, "1dwc", 1, 200, 20, 0, cutoff=1.0, mode=m))

@@ -187,12 +187,14 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *          9 1 if the range-limited pair stages run in row form (neighbour rows with a skin, rebuilt on the device when an
  *            atom has moved more than half the skin; Reference mode, version 1)  10 builds of those rows so far
  *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; every overflow of a packed forest
- *             adds one step of 15 %, sixteen clean plans in a row give one back)  12 evaluations since the packing was planned
+ *             adds one step of 15 %, clean plans in a row give one back)  12 evaluations since the packing was planned
  *          13 entries per slice of a neighbour row (one wave of a row launch walks one slice; tuned on the device)
  *          15 why the last agbnp_hip_finish() withheld evaluations: 1 a subtree outgrew the store's nodes, 2 its local atoms,
- *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms;
+ *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms,
+ *             32 / 64 a forest of several work items outgrew its nodes / its local atoms (the two kinds of 4);
  *             bits 8.. the part count of a lone work item that asked for its subtree to be shared further
- *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation)
+ *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation,
+ *             default 16, or when the trees have drifted from the shapes it was planned for)
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor
  *          3 self volume (enlarged radii)
  *          4 / 5 nodes / local atoms of the overlap subtree rooted at the atom (tree shape, capacity planning) */
@@ -229,6 +231,11 @@ void agbnp_hip_destroy(agbnp_hip_context* ctx);
 
 /* Number of HIP devices visible to this process (0 if none / runtime unavailable). */
 int agbnp_hip_device_count(void);
+
+/* What this library was built from: the first 16 hex digits of the SHA-256 of the engine's sources (csrc/Makefile), "unknown"
+ * for a build made another way.  No counterpart in the reference; measurement support: scripts/profile_round.sh stores it
+ * beside every rocprofv3 summary under profiles/, bench.py compares it with the library it is running (profile_head). */
+const char* agbnp_hip_build_id(void);
 
 #ifdef __cplusplus
 }

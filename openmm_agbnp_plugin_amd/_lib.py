@@ -15,7 +15,7 @@ SYMBOLS = [
     "agbnp_hip_create", "agbnp_hip_update_parameters", "agbnp_hip_execute_host", "agbnp_hip_execute_device",
     "agbnp_hip_execute_openmm", "agbnp_hip_atom_order_changed", "agbnp_hip_finish", "agbnp_hip_poll", "agbnp_hip_wait_verdict", "agbnp_hip_withheld_evaluations", "agbnp_hip_generation", "agbnp_hip_get_scalar", "agbnp_hip_get_vector", "agbnp_hip_get_table_sizes",
     "agbnp_hip_get_tables", "agbnp_hip_host_tables", "agbnp_hip_num_particles", "agbnp_hip_version",
-    "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count",
+    "agbnp_hip_last_error", "agbnp_hip_destroy", "agbnp_hip_device_count", "agbnp_hip_build_id",
     "agbnp_hip_set_mode", "agbnp_hip_get_mode", "agbnp_hip_set_diagnostics", "agbnp_hip_set_profiling", "agbnp_hip_num_kernels", "agbnp_hip_kernel_name", "agbnp_hip_get_kernel_times",
 ]
 
@@ -76,6 +76,8 @@ def load():
     lib.agbnp_hip_destroy.argtypes = [vp]
     lib.agbnp_hip_destroy.restype = None
     lib.agbnp_hip_device_count.argtypes = []
+    lib.agbnp_hip_build_id.argtypes = []
+    lib.agbnp_hip_build_id.restype = C.c_char_p
     lib.agbnp_hip_set_mode.argtypes = [vp, C.c_int]
     lib.agbnp_hip_get_mode.argtypes = [vp]
     lib.agbnp_hip_set_diagnostics.argtypes = [vp, C.c_int]
@@ -88,6 +90,11 @@ def load():
         getattr(lib, name)  # AttributeError if the library does not export it
     _lib = lib
     return lib
+
+
+def build_id():
+    """First 16 hex digits of the SHA-256 of the sources the loaded library was built from (csrc/Makefile)."""
+    return load().agbnp_hip_build_id().decode()
 
 
 def last_error(handle=None):

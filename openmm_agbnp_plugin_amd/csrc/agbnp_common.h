@@ -71,7 +71,7 @@ enum StatusWord {
   kStatOrderStale = 11,    // agbnp_hip_execute_openmm: the context's atom order is not the one the engine's particle -> slot map
                            // was built for (OpenMM has reordered its atoms): evaluation void, the map is rebuilt, the host repeats
   kStatForestOverflow = 12,  // the part of kStatPackOverflow that IS a misprediction of the packing: forests of SEVERAL work items
-                           // that outgrew their store (a lone splittable item is counted in kStatPackOverflow only: the
+                           // that outgrew their store (low half: by nodes, high half: by local atoms) (a lone splittable item is counted in kStatPackOverflow only: the
                            // capacity the packing assumes is not tightened for it)
   kStatEvalWords = 13,     // ---- everything below is sticky
   kStatEvalSeq = 13,       // evaluations enqueued since the last agbnp_hip_finish
@@ -82,8 +82,9 @@ enum StatusWord {
   kStatStickyRow = 18,
   kStatStickyOrder = 19,
   kStatStickySplit = 20,   // MAX of kStatSplitWanted over those evaluations
-  kStatWords = 21,
-  kStatBadBitmap = 21,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatStickyForest = 21,  // bit 0: a forest of several items outgrew its NODES, bit 1: its local ATOMS (diagnostic: scalar 15)
+  kStatWords = 22,
+  kStatBadBitmap = 22,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
   kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };

@@ -90,10 +90,10 @@ struct agbnp_hip_context {
   // second stream + fork/join events: the enlarged-radius cavity pass runs underneath the pair kernels
 
   // static device data
-  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_ftime, d_rows, d_forest, d_gb_items, d_db_items, d_pslot, d_ctx_slot;
+  DevBuf<int> d_a2h, d_h2a, d_status, d_order, d_ftime, d_rows, d_forest, d_pack_items, d_gb_items, d_db_items, d_pslot, d_ctx_slot;
   int cus = 256;
   DevBuf<unsigned long long> d_nbmask;
-  DevBuf<double> d_charge, d_alpha, d_inv_rvdw;
+  DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_a;
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
   size_t hstride = 64;
   double* hrow(int r) const { return d_heavy.p + (size_t)r * hstride; }
@@ -119,6 +119,7 @@ struct agbnp_hip_context {
   DevBuf<double> d_nl_ref, d_bw;
   DevBuf<double4> d_rec_h, d_hrow, d_grec, d_hrec;
   DevBuf<double2> d_pw;        // four arrays of nti * ntj * 15 entries: {c0, c1} / {c2, c3} by [screened][screener], the same by [screener][screened]
+  int forests_hint = 0;        // forests of the last evaluation the host has read the status of (0: none yet); reset by a fallback packing
   bool fused_outputs = true;   // version 1: the pseudo-volume launch adds the forces itself (AGBNP_HIP_OUTPUT_LAUNCH=1: k_outputs does)
   bool rows_capable = false;   // the buffers above exist
   bool rows_disabled = false;  // a neighbour row outgrew its stride once: the tile kernels from then on
@@ -264,6 +265,12 @@ int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
   HIP_TRY(c, c->d_charge.upload(c->charge));
   HIP_TRY(c, c->d_alpha.upload(c->alpha));
   HIP_TRY(c, c->d_inv_rvdw.upload(inv_rvdw));
+  {  // the heavy table's 1/V row once more, by ATOM (0 for hydrogens): k_prep fills the rows' records without waiting for a
+     // heavy index first
+    std::vector<double> inv_vol_a(n, 0.0);
+    for (int h = 0; h < nh; h++) inv_vol_a[c->h2a[h]] = inv_vol_h[h];
+    HIP_TRY(c, c->d_inv_vol_a.upload(inv_vol_a));
+  }
   if (c->d_heavy.p == nullptr) {
     c->hstride = ((size_t)std::max(nh, 1) + 63) / 64 * 64;
     HIP_TRY(c, c->d_heavy.alloc((size_t)kHvRows * c->hstride));
@@ -326,6 +333,7 @@ void wire_args(agbnp_hip_context* c) {
   P.alpha = c->d_alpha.p;
   P.inv_rvdw = c->d_inv_rvdw.p;
   P.inv_vol_h = c->hrow(kHvInvVol);
+  P.inv_vol_a = c->d_inv_vol_a.p;
   P.gam_cav = c->hrow(kHvGam);
   P.ameta = c->d_ameta.p;
   P.lut = c->d_lut.p;
@@ -471,6 +479,7 @@ void wire_args(agbnp_hip_context* c) {
   P.sizes = c->d_sizes.p;
   T.sizes = c->d_sizes.p;
   P.order = c->d_order.p;
+  P.pack_items = reinterpret_cast<int2*>(c->d_pack_items.p);
   P.forest_time = c->d_ftime.p;
   P.rows = c->d_rows.p;
   T.rows = c->d_rows.p;
@@ -809,7 +818,11 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     // atomics share one in-order counter, and a wait that crosses the loop's back edge is a wait for everything, the
     // flush's atomics included.  AGBNP_HIP_FUSE_QUEUED=1 keeps the experiment reachable.)
     static const bool fuse_queued = getenv("AGBNP_HIP_FUSE_QUEUED") && atoi(getenv("AGBNP_HIP_FUSE_QUEUED")) != 0;
-    const bool fused = c->fused_outputs && c->nh > 0 && (c->nh <= 2 * c->tree_slots[c->variant] || (fuse_queued && c->variant <= 1));
+    // (Round 5: a system with more subtrees than that whose forests nevertheless fit ONE round -- 2clr under the rounds rule of
+    // the packing: 3084 subtrees in 1280 forests -- is told by the forest count of the last evaluation the host has seen;
+    // a stale hint costs time, never correctness.)
+    const bool one_round = c->forests_hint > 0 && c->forests_hint <= c->tree_slots[c->variant];
+    const bool fused = c->fused_outputs && c->nh > 0 && (c->nh <= 2 * c->tree_slots[c->variant] || one_round || (fuse_queued && c->variant <= 1));
     O.enabled = fused ? 1 : 0;
     O.n = c->n;
     O.a2h = c->d_a2h.p;
@@ -852,6 +865,7 @@ int upload_identity_packing(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_rows.upload(ident));
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
   HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
+  if (c->d_pack_items.p == nullptr) HIP_TRY(c, c->d_pack_items.upload(std::vector<int>(2 * nslots + 2, 0)));
   // layout: [0, slots] forest_start, [slots+1] number of forests, [slots+2] the count the running evaluation took,
   // [slots+3] how often a packed forest has overflowed so far (kept), [slots+4] the age of the packing in evaluations
   // (huge: this one is no plan, the next evaluation's bookkeeping plans at once)
@@ -915,6 +929,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   const int* s = c->last_status;
   c->withheld.clear();
   c->withheld_count = s[kStatBadCount];
+  if (s[kStatEvalSeq] > 0) c->forests_hint = s[kStatForests];  // (what the NEXT evaluation runs on, written by the last one's bookkeeping)
   // the last evaluation's own words say whether the diagnostics on the device are those of a complete evaluation
   c->have_results = s[kStatEvalSeq] > 0 ? !(s[kStatNodeOverflow] | s[kStatAtomOverflow] | s[kStatPackOverflow] | s[kStatOrderStale] | s[kStatRowOverflow]) : c->have_results;
   if (!c->h_report && (s[kStatEvalSeq] != 0 || s[kStatBadCount] != 0))  // start a new log
@@ -940,6 +955,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   if (s[kStatStickySplit] > 0) c->fallback_parts = 4;
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
+  c->forests_hint = 0;  // (one work item per slot again: the old rule decides)
   if (s[kStatStickyOrder]) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
   if (s[kStatStickyRow] && !c->rows_disabled) {
     // a neighbour list of the row-form pair stages outgrew what the launches walk of it: they walk twice as much from
@@ -970,6 +986,11 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifndef AGBNP_SRC_HASH
+#define AGBNP_SRC_HASH "unknown"  // (a build outside csrc/Makefile: diagnostic libraries)
+#endif
+const char* agbnp_hip_build_id(void) { return AGBNP_SRC_HASH; }
 
 int agbnp_hip_device_count(void) {
   int k = 0;
@@ -1253,7 +1274,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
   if (which == 15) {  // why the last agbnp_hip_finish withheld evaluations (valid whether or not an evaluation has completed)
     const int* s = c->last_status;
     *value = (s[kStatStickyNode] ? 1 : 0) | (s[kStatStickyAtom] ? 2 : 0) | (s[kStatStickyPack] ? 4 : 0) | (s[kStatStickyRow] ? 8 : 0) |
-             (s[kStatStickyOrder] ? 16 : 0) | (s[kStatStickySplit] << 8);
+             (s[kStatStickyOrder] ? 16 : 0) | (s[kStatStickyForest] << 5) | (s[kStatStickySplit] << 8);  // (32 / 64: a forest's nodes / local atoms)
     return AGBNP_HIP_OK;
   }
   if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");

@@ -44,6 +44,7 @@ struct PairArgs {
   const double* alpha;     // [n]
   const double* inv_rvdw;  // [n] 1/R_i
   const double* inv_vol_h;  // [nh] 1/(4 pi R^3/3), vdW radius
+  const double* inv_vol_a;  // [n] the same by atom (0 for hydrogens)
   const double* gam_cav;   // [nh] gamma/roffset
   const double *a_large, *v_large;  // [nh] Gaussian exponent / volume with the enlarged radii
   double rcut2;            // conservative squared cutoff of the 2-body overlap search
@@ -89,6 +90,7 @@ struct PairArgs {
                            // is no plan: one work item per slot); [3] packings planned so far (a diagnostic); [4], [5] total
                            // nodes / largest subtree of the evaluation the packing was planned from (drift trigger)
   int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 16), or when the trees have drifted
+  int2* pack_items;        // [slots] packing_role's scratch: the work items in descending weight order {item, predicted time} (rounds rule)
   int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k
   int* forest_time;        // [slots + 1] predicted time of every forest (packing_role -> dealing_role), then: are they there
   int* rows;               // [kRowStride * slots] the work items of the NEXT evaluation in WORK-SLOT order (what the tree kernel

@@ -206,6 +206,12 @@ __device__ void neighbor_tile(const PairArgs& P, int tile) {
 }
 
 __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
+#ifdef AGBNP_TIMING_PREP  // timing experiment only (results wrong): 1 = an empty launch of the same grid, 2 = no neighbour-mask
+                          // tiles, 3 = the neighbour-mask tiles alone; the raw event interval of k_prep says what each part costs
+  if (AGBNP_TIMING_PREP == 1) return;
+  if (AGBNP_TIMING_PREP == 2 && (int)blockIdx.x >= prep_blocks) return;
+  if (AGBNP_TIMING_PREP == 3 && (int)blockIdx.x < prep_blocks) return;
+#endif
   if ((int)blockIdx.x >= prep_blocks) return neighbor_tile(P, blockIdx.x - prep_blocks);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // the status words of ONE evaluation start from zero; the sticky ones (overflow log since the last
@@ -285,6 +291,8 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   if (P.in.posq && P.in.atom_index && P.in.atom_index[P.omm.ctx_slot[i]] != i) P.status[kStatOrderStale] = 1;  // (the context has reordered its atoms)
   const Pos3 r_i = atom_position(P, i);
   const double x = r_i.x, y = r_i.y, z = r_i.z;
+  const double inv_vol_i = P.rows_on ? P.inv_vol_a[i] : 0.0;  // (asked for with everything else: no load waits for the heavy index)
+  const int screener_i = P.rows_on ? P.ameta[i].y : 0;
   P.aposq[i] = make_double4(x, y, z, P.charge[i]);
   if (P.rows_on) {
     P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
@@ -312,9 +320,9 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
     P.sv_large[h] = 0.0;
     P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
     if (P.rows_on) {
-      P.rec_h[h] = make_double4(x, y, z, P.inv_vol_h[h]);
+      P.rec_h[h] = make_double4(x, y, z, inv_vol_i);
       P.hrec[h] = make_double4(0.0, 0.0, 0.0, 0.0);  // H arrives through the chain-rule rows' atomics
-      P.hrow[h] = make_double4(x, y, z, __hiloint2double(0, i | (P.ameta[i].y << 24)));
+      P.hrow[h] = make_double4(x, y, z, __hiloint2double(0, i | (screener_i << 24)));
     }
   }
 }
@@ -337,6 +345,9 @@ __device__ __forceinline__ double rot1(double v) {  // lane l <- lane l+1 (mod 6
 }
 
 
+#ifndef AGBNP_PACK_ROUNDS_RULE
+#define AGBNP_PACK_ROUNDS_RULE 1  // (0: diagnostic build without the rounds rule of packing_role)
+#endif
 constexpr size_t kRoleScratchBytes = 4352;  // LDS the two roles borrow from their host kernel's dynamic area
 // ---- two single-workgroup roles, off the critical path:
 //   energy:      fixed-order sum of every energy partial, ADDED to the caller's scalar; needs the GB stage's partials:
@@ -413,6 +424,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyRow] |= rowo;
           P.status[kStatStickyOrder] |= order;
           P.status[kStatStickySplit] = max(P.status[kStatStickySplit], P.status[kStatSplitWanted]);
+          const int fo = P.status[kStatForestOverflow];
+          P.status[kStatStickyForest] |= ((fo & 0xffff) ? 1 : 0) | ((fo >> 16) ? 2 : 0);
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
         if (P.host_status) {  // the host's window on the log (agbnp_hip_poll): the withheld count first, then the running number
@@ -449,6 +462,9 @@ __device__ __forceinline__ bool evaluation_overflowed(const int* __restrict__ st
 //                 forest's items written into its slot's row.
 // The shapes are fetched once, sixteen loads per thread in flight together, and packed into LDS; the passes are rolled
 // loops over LDS without divisions (at most four parts, at most eight places per forest).
+// kRounds: with the rounds rule (below).  The GB rows kernel of the fast mode hosts the role without it: its own walk sits at
+// the register limit and spilled with the longer role inlined beside it.
+template <bool kRounds>
 __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes) {
   const int t = threadIdx.x;
   constexpr int kBins = 512, kBatch = 16;
@@ -491,9 +507,9 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   // packing; a lone item of a subtree that can still be shared is not one -- its subtree is shared among more items, the
   // capacity assumed for everybody else stays).  It relaxes again: after kPackRelax plans in a row without a misprediction
   // one step is given back, so a run with the occasional overflow does not drift to one subtree per slot for the life of
-  // the context.  Never beyond 6 (= packing off): whatever is queued behind a run of overflows, sixteen clean plans give a
-  // step back.
-  constexpr int kPackRelax = 16;
+  // the context.  Never beyond 6 (= packing off): whatever is queued behind a run of overflows, kPackRelax clean plans give
+  // a step back.
+  constexpr int kPackRelax = 4;  // (x the replan period of 16 evaluations = the 64 evaluations of round 4's 16 plans x 4)
   const bool relax = st_pack == 0 && ps_level > 0 && ps_clean >= kPackRelax;
   const int level = min(6, ps_level + (st_forest != 0 ? 1 : 0) - (relax ? 1 : 0));
   const bool pack = P.pack_enabled && !overflow && level < 6;
@@ -642,13 +658,13 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const int nb = nab - na;
   const int npair = forests ? min(nb, nitems - imax[16]) : 0;  // class-B items that get a light partner
   const int nc = nitems - nab - npair;          // items dealt over the remaining forests
-  int fs = 0;
+  const int round = max(1, (int)(((long long)P.tree_slots * P.round_permille) / 1000));  // a round of resident workgroups, a few % spare
+  int fs = 0, rounds_classes = (nab + round - 1) / round;
   if (nc > 0) {
     const unsigned wc = (unsigned)imax[19] - (unsigned)imax[15];               // (the partners' weight is left in: safe side)
     const int fmin = max((int)((wc + 869u) / 870u), (nc + 7) / 8);            // mean fill <= 85 %, at most 8 roots
-    const int round = max(1, (int)(((long long)P.tree_slots * P.round_permille) / 1000));  // a round of resident workgroups, a few % spare
-    const int rounds = (nab + fmin + round - 1) / round;                       // whole rounds that hold fmin
-    fs = min(nc, max(fmin, rounds * round - nab));
+    rounds_classes = (nab + fmin + round - 1) / round;                          // whole rounds that hold fmin
+    fs = min(nc, max(fmin, rounds_classes * round - nab));
   }
   const int nf = nab + fs;
   const int full = fs > 0 ? nc / fs : 0, rem = fs > 0 ? nc % fs : 0;  // full serpentine rounds, items of the last one
@@ -663,74 +679,217 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     }
     return f < nf ? nab + npair + small_start(f - nab) : nitems;
   };
+  auto class_place = [&](int pos, int* place) {  // position in descending weight order -> forest, place (the classes' rule)
+    if (pos < nab) {
+      *place = 0;  // a forest of its own, or the leader of a class-B forest
+      return pos;
+    }
+    if (pos >= nitems - npair) {
+      *place = 1;  // the lightest item joins the heaviest class-B item
+      return na + (nitems - 1 - pos);
+    }
+    const int k = pos - nab;
+    int r = 0;  // k / fs: the serpentine round, at most kMaxItems - 1
+#pragma unroll
+    for (int q = 1; q < kMaxItems; q++) r += k >= q * fs ? 1 : 0;
+    const int idx = k - r * fs;
+    *place = r;
+    return nab + ((r & 1) ? fs - 1 - idx : idx);
+  };
+  // predicted time of a work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom, 1.6 per root;
+  // units of 0.01 us)
+  auto item_time = [&](int2 sz, int parts) {
+    const int l2 = max(sz.y - 1, 0);
+    return 9 * (1 + l2 + (int)((float)max(sz.x - 1 - l2, 0) * inv_parts(parts))) + 34 * sz.y + 160;
+  };
   PAIR_STAMP(1, 8);
   if (P.pack_enabled == 3) return;  // (diagnostics: the packing is frozen from the host)
+  // ---- The classes above waste room on mid-size systems: 2clr's 3358 work items weigh 1120 stores' worth (most of them
+  // bound by the 64 local atoms of a store, not by its nodes), yet 445 class-A/B forests with one light partner each and
+  // the 85 % mean fill of the rest make 1477 forests -- two rounds of 1280, a third full.  When the total weight says a
+  // round can be saved, a second rule is tried: THE ROUNDS RULE.  The F heaviest items lead a forest each (F = the rounds
+  // the weight needs, filled); then, pass by pass, every forest that still has room for the HEAVIEST item left (a bound
+  // that decouples the forests' decisions from each other) is open, and the open forests take the next items of the
+  // sorted order, the heaviest open forest the lightest item of the batch.  A pass is a count, a block scan and one
+  // look-up per open forest; at most seven passes.  If an item is left over (no forest open) the classes' packing is
+  // used after all.  Needs the sorted order as an array: the items' weights by position in LDS, their identity and
+  // predicted time in global scratch (pack_items), the forests' running sums in LDS.
+  const int rounds_weight = (int)(((unsigned)imax[19] + (unsigned)(kUnit * round) - 1u) / (unsigned)(kUnit * round));
+  const int F = min(nitems, rounds_weight * round);
+  const int region = F;  // ints: running sums (weight | items << 16), later the predicted times (if the rule fails and the
+                         // classes' forests outnumber it, they are handed over unranked: a rare path of a rare path)
+  unsigned short* ws = reinterpret_cast<unsigned short*>(lds_time + region);  // [nitems] weight by sorted position
+  unsigned short* where = ws + ((nitems + 1) & ~1);                            // [nitems] forest << 3 | place by sorted position
+  const bool try_rounds = forests && nc > 0 && rounds_weight < rounds_classes && F <= 8191 && P.pack_items != nullptr &&
+                          region + (nitems + 1) / 2 * 2 <= lds_forests && kRounds && AGBNP_PACK_ROUNDS_RULE;
+  if (!try_rounds) {
 #pragma unroll 1
-  for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
-  // (the forests are ranked by predicted time when the times fit the lent LDS: always, short of ~3000 forests)
-  const bool rank_by_time = nf <= lds_forests;
+    for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
+    // (the forests are ranked by predicted time when the times fit the lent LDS: always, short of ~3000 forests)
+    const bool rank_by_time = nf <= lds_forests;
+    if (rank_by_time)
+      for (int f = t; f < nf; f += 256) lds_time[f] = 0;
+    __syncthreads();
+    if (t == 0) {
+      P.nforests[0] = nf;
+      P.status[kStatForests] = nf;
+      P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;  // (word behind the times: are they there)
+    }
+    PAIR_STAMP(1, 9);
+    // sorted order -> place inside the forests.  Four subtrees per thread and trip, their LDS round trips (shape, then the
+    // ranked add) in flight together: the role's time is its chain of dependent LDS latencies.
+    constexpr int kChains = 4;
+#pragma unroll 1
+    for (int h0 = t; h0 < P.nh; h0 += 256 * kChains) {
+      int2 sz[kChains];
+      int parts[kChains];
+      unsigned long long v[kChains];
+#pragma unroll
+      for (int c = 0; c < kChains; c++) sz[c] = shape(min(h0 + 256 * c, P.nh - 1));
+#pragma unroll
+      for (int c = 0; c < kChains; c++) {
+        parts[c] = parts_of(sz[c]);
+        const unsigned w = weight(sz[c], parts[c]);
+        v[c] = 0ull;
+        if (h0 + 256 * c < P.nh) v[c] = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts[c] << 32) | (w * (unsigned)parts[c]));
+      }
+#pragma unroll
+      for (int c = 0; c < kChains; c++) {
+        const int h = h0 + 256 * c;
+        if (h >= P.nh) continue;
+        const int tm = item_time(sz[c], parts[c]);
+#pragma unroll 1
+        for (int part = 0; part < parts[c]; part++) {
+          int place;
+          const int forest = class_place((int)(v[c] >> 32) + part, &place);  // position in descending weight order -> forest
+          P.order[kMaxItems * forest + place] = h | (part << 24) | ((parts[c] - 1) << 26);
+          if (rank_by_time) atomicAdd(&lds_time[forest], tm);
+        }
+      }
+    }
+    PAIR_STAMP(1, 10);
+    __syncthreads();
+    if (rank_by_time)
+      for (int f = t; f < nf; f += 256) P.forest_time[f] = lds_time[f];
+    return;
+  }
+  // ---- the rounds rule.  (i) the sorted order, materialised
+#pragma unroll 1
+  for (int h = t; h < P.nh; h += 256) {
+    const int2 sz = shape(h);
+    const int parts = parts_of(sz);
+    const unsigned w = weight(sz, parts);
+    const int first = (int)(atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts << 32) | (w * (unsigned)parts)) >> 32);
+    const int tm = item_time(sz, parts);
+    for (int part = 0; part < parts; part++) {
+      ws[first + part] = (unsigned short)w;
+      P.pack_items[first + part] = make_int2(h | (part << 24) | ((parts - 1) << 26), tm);
+    }
+  }
+  __syncthreads();  // (also makes the global stores of this workgroup visible to its own later loads)
+  // (ii) the passes.  Thread t owns forests [t per, (t + 1) per): ranks follow the forests' order
+  const int per = (F + 255) / 256, f_lo = min(F, t * per), f_hi = min(F, f_lo + per);
+  for (int f = f_lo; f < f_hi; f++) lds_time[f] = (int)ws[f] | (1 << 16);
+  int taken = F;  // items placed so far = the next position
+  bool stuck = false;
+#pragma unroll 1
+  for (int pass = 1; pass < kMaxItems && taken < nitems && !stuck; pass++) {
+    const int wtop = ws[taken];
+    int open = 0;
+    for (int f = f_lo; f < f_hi; f++) open += (lds_time[f] & 0xffff) + wtop <= (int)kUnit ? 1 : 0;
+    int incl = open;  // block scan of the open counts (wave scan, then the four wave totals)
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += v;
+    }
+    __syncthreads();  // (the previous pass is done with imax[20..23])
+    if ((t & 63) == 63) imax[20 + (t >> 6)] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+      before += w < (t >> 6) ? imax[20 + w] : 0;
+      total += imax[20 + w];
+    }
+    const int take = min(total, nitems - taken);
+    stuck = total == 0;
+    int rank = before + incl - open;
+    for (int f = f_lo; f < f_hi; f++) {
+      const int sum = lds_time[f];
+      if ((sum & 0xffff) + wtop <= (int)kUnit) {
+        if (rank < take) {
+          const int pos = taken + (take - 1 - rank);  // the heaviest open forest takes the lightest item of the batch
+          where[pos] = (unsigned short)((f << 3) | (sum >> 16));
+          lds_time[f] = sum + (int)ws[pos] + (1 << 16);
+        }
+        rank++;
+      }
+    }
+    taken += take;
+  }
+  __syncthreads();
+  const bool placed = taken >= nitems;  // (the same on every thread)
+  const int nf_used = placed ? F : nf;
+  if (placed) {  // forest_start from the forests' item counts
+    int mine = 0;
+    for (int f = f_lo; f < f_hi; f++) mine += lds_time[f] >> 16;
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += v;
+    }
+    if ((t & 63) == 63) imax[20 + (t >> 6)] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < (t >> 6); w++) run += imax[20 + w];
+    for (int f = f_lo; f < f_hi; f++) {
+      P.forest_start[f] = run;
+      run += lds_time[f] >> 16;
+    }
+    if (t == 255) P.forest_start[F] = nitems;
+    __syncthreads();
+  } else {
+#pragma unroll 1
+    for (int f = t; f <= nf; f += 256) P.forest_start[f] = forest_first(f);
+  }
+  const bool rank_by_time = nf_used <= region;
   if (rank_by_time)
-    for (int f = t; f < nf; f += 256) lds_time[f] = 0;
+    for (int f = t; f < nf_used; f += 256) lds_time[f] = 0;
   __syncthreads();
   if (t == 0) {
-    P.nforests[0] = nf;
-    P.status[kStatForests] = nf;
-    P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;  // (word behind the times: are they there)
+    P.nforests[0] = nf_used;
+    P.status[kStatForests] = nf_used;
+    P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;
   }
   PAIR_STAMP(1, 9);
-  // sorted order -> place inside the forests.  Four subtrees per thread and trip, their LDS round trips (shape, then the
-  // ranked add) in flight together: the role's time is its chain of dependent LDS latencies.
-  constexpr int kChains = 4;
+  // (iii) every position hands its item to its forest
+  {
+    constexpr int kBatch = 4;
 #pragma unroll 1
-  for (int h0 = t; h0 < P.nh; h0 += 256 * kChains) {
-    int2 sz[kChains];
-    int parts[kChains];
-    unsigned long long v[kChains];
+    for (int base = 0; base < nitems; base += 256 * kBatch) {
+      int2 it[kBatch];
 #pragma unroll
-    for (int c = 0; c < kChains; c++) sz[c] = shape(min(h0 + 256 * c, P.nh - 1));
+      for (int b = 0; b < kBatch; b++) it[b] = P.pack_items[min(base + b * 256 + t, nitems - 1)];
 #pragma unroll
-    for (int c = 0; c < kChains; c++) {
-      parts[c] = parts_of(sz[c]);
-      const unsigned w = weight(sz[c], parts[c]);
-      v[c] = 0ull;
-      if (h0 + 256 * c < P.nh) v[c] = atomicAdd(&comb[kBins - 1 - (w >> 2)], ((unsigned long long)parts[c] << 32) | (w * (unsigned)parts[c]));
-    }
-#pragma unroll
-    for (int c = 0; c < kChains; c++) {
-      const int h = h0 + 256 * c;
-      if (h >= P.nh) continue;
-      // predicted time of a work item (fit of a workgroup timeline: 0.09 us per node, 0.34 per local atom, 1.6 per
-      // root; units of 0.01 us)
-      const int l2 = max(sz[c].y - 1, 0);
-      const int tm = 9 * (1 + l2 + (int)((float)max(sz[c].x - 1 - l2, 0) * inv_parts(parts[c]))) + 34 * sz[c].y + 160;
-#pragma unroll 1
-      for (int part = 0; part < parts[c]; part++) {
-        const int pos = (int)(v[c] >> 32) + part;  // position in descending weight order
-        int forest, place;                         // the item is number `place` of forest `forest`
-        if (pos < nab) {
-          forest = pos;  // a forest of its own, or the leader of a class-B forest
-          place = 0;
-        } else if (pos >= nitems - npair) {
-          forest = na + (nitems - 1 - pos);  // the lightest item joins the heaviest class-B item
-          place = 1;
+      for (int b = 0; b < kBatch; b++) {
+        const int pos = base + b * 256 + t;
+        if (pos >= nitems) continue;
+        int forest, place;
+        if (placed) {
+          const int code = where[pos];
+          forest = pos < F ? pos : code >> 3;
+          place = pos < F ? 0 : code & 7;
         } else {
-          const int k = pos - nab;
-          int r = 0;  // k / fs: the serpentine round, at most kMaxItems - 1
-#pragma unroll
-          for (int q = 1; q < kMaxItems; q++) r += k >= q * fs ? 1 : 0;
-          const int idx = k - r * fs;
-          forest = nab + ((r & 1) ? fs - 1 - idx : idx);
-          place = r;
+          forest = class_place(pos, &place);
         }
-        P.order[kMaxItems * forest + place] = h | (part << 24) | ((parts[c] - 1) << 26);
-        if (rank_by_time) atomicAdd(&lds_time[forest], tm);
+        P.order[kMaxItems * forest + place] = it[b].x;
+        if (rank_by_time) atomicAdd(&lds_time[forest], it[b].y);
       }
     }
   }
   PAIR_STAMP(1, 10);
   __syncthreads();
   if (rank_by_time)
-    for (int f = t; f < nf; f += 256) P.forest_time[f] = lds_time[f];
+    for (int f = t; f < nf_used; f += 256) P.forest_time[f] = lds_time[f];
 }
 
 // Second half.  Work slot s runs on CU s mod ncus (observed: the dispatcher deals workgroups round-robin over the CUs),
@@ -938,6 +1097,9 @@ __device__ __forceinline__ void gb_strip(int n, int I0, int J, const double4* __
   if (kFar) {
     const double bj = __hiloint2double(s_bmax[0], 0), bi = __hiloint2double(max(s_bmax[1], s_bmax[2]), 0);
     far = __builtin_amdgcn_readfirstlane(far_gap2 > kGbFarFactor * bj * bi ? 1 : 0) != 0;  // (the same for every lane of the workgroup)
+#ifdef AGBNP_TIMING_ALL_FAR  // timing experiment only (results wrong): what the launch costs if EVERY strip took the short walk
+    far = true;
+#endif
   }
   if (kFar && far) {
 #pragma unroll 4
@@ -1186,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   __shared__ int s_bmax[4];  // (kFar: the blocks' largest Born radii)
   if (blockIdx.x == 0) {
     PAIR_STAMP(1, 0);
-    packing_role(P, s_area, (int)sizeof(StripSums));
+    packing_role<true>(P, s_area, (int)sizeof(StripSums));
     PAIR_STAMP(1, 3);
     return;
   }
@@ -1653,7 +1815,7 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
       static_assert(kGbRowWaves >= 4, "the bookkeeping role is written for 256 lanes");
       if (threadIdx.x >= 256) return;
       PAIR_STAMP(1, 0);
-      packing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
+      packing_role<false>(P, reinterpret_cast<char*>(s_dyn), role_bytes);
       PAIR_STAMP(1, 3);
       return;
     }
@@ -1676,7 +1838,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   if (version != 1) {
     if (blk == 0) return energy_role(P, version, energy_out, components, s_role);
     if (blk == 1) {  // both halves of the bookkeeping, one after the other
-      packing_role(P, s_role, role_bytes);
+      packing_role<true>(P, s_role, role_bytes);
       __threadfence();
       __syncthreads();  // (the second half reads back what the first wrote)
       return dealing_role(P, s_role, role_bytes);

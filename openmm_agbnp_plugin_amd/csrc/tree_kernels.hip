@@ -177,7 +177,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
         const int parts0 = work_item_parts(items[0]);
         const bool splittable = m == 1 && rc == kBuildNodeOverflow && parts0 < 4 && A.split_fit != 0;
         atomicAdd(&A.status[(m > 1 || splittable) ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
-        if (m > 1) atomicAdd(&A.status[kStatForestOverflow], 1);  // (what tightens the packing's assumed capacity)
+        if (m > 1) atomicAdd(&A.status[kStatForestOverflow], rc == kBuildNodeOverflow ? 1 : 0x10000);  // (what tightens the packing's assumed capacity)
         if (splittable) {
           atomicMax(&A.status[kStatSplitWanted], parts0);
           // The device reacts by itself (evaluations may be queued behind this one long before a host sees the log): the

@@ -16,6 +16,6 @@ if not lines:
     print('$tag', 'NO JSON LINE -- see gpurun_out/abx_${tag}_$i.err')
 else:
     d = json.loads(lines[-1])
-    print('$tag', round(d['ms_per_step'] * 1e3, 2), d['kernel_avg_us'], d.get('parity_on_sample', {}).get('max_abs_dF_kJmolnm'))"
+    print('$tag', round(d['ms_per_step'] * 1e3, 2), d['kernel_avg_us'], d.get('parity_on_sample', {}).get('max_abs_dF_kJmolnm'), 'forests', d['config'].get('forests'), 'level', d['config'].get('pack_level'), 'tries', [r.get('timed_tries') for r in d.get('ranks', [])])"
   done
 done

@@ -6,6 +6,16 @@ set -e
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out profiles/$tag
+# what these summaries were measured on: the library's own build id (SHA-256 of its sources, csrc/Makefile) and the git head
+# that scripts/profile_here.sh wrote beside the snapshot (the GPU box has no .git)
+python3 - <<PY > profiles/$tag/profile_head.json
+import json, os, time
+from openmm_agbnp_plugin_amd import _lib
+head = open("profiles/.git_head").read().strip() if os.path.exists("profiles/.git_head") else None
+print(json.dumps({"library_build_id": _lib.build_id(), "git_head": head, "taken": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                  "command": "python3 bench.py --steps 100 --warmup 10 --cpu-evals 0 --secondary 0 under rocprofv3 (scripts/profile_round.sh)"}, indent=1))
+PY
+cat profiles/$tag/profile_head.json
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 BENCH="python3 bench.py --steps 100 --warmup 10 --cpu-evals 0 --secondary 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- $BENCH > $out/stats_bench.log 2>&1

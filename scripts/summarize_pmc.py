@@ -35,7 +35,9 @@ with open(out, "w") as fh:
     cw.writerows(rows)
 print(open(out).read())
 dom = max(rows, key=lambda r: r["hbm_bytes_per_launch"]) if len(sys.argv) < 6 else next(r for r in rows if r["kernel"] == sys.argv[5])
-json.dump(dict(kernel=dom["kernel"], system=system, hbm_bytes_per_launch=dom["hbm_bytes_per_launch"],
+head_file = os.path.join(ROOT, "profiles", tag, "profile_head.json")
+head = json.load(open(head_file)) if os.path.exists(head_file) else None
+json.dump(dict(kernel=dom["kernel"], system=system, profile_head=head, hbm_bytes_per_launch=dom["hbm_bytes_per_launch"],
                FETCH_SIZE_KiB=dom["FETCH_SIZE_KiB"], WRITE_SIZE_KiB=dom["WRITE_SIZE_KiB"],
                all_kernels_bytes_per_eval=sum(r["hbm_bytes_per_launch"] for r in rows),
                source=f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; profiles/{tag}/pmc_summary.csv"),

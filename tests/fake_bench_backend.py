@@ -47,7 +47,7 @@ class FakeKernel:
         return e
 
     def scalar(self, name):
-        return {"total_nodes": 12732.0, "variant": 0.0, "rows_on": 1.0, "row_builds": 2.0, "row_slice": 256.0, "pack_plans": 5.0}[name]
+        return {"total_nodes": 12732.0, "variant": 0.0, "rows_on": 1.0, "row_builds": 2.0, "row_slice": 256.0, "pack_plans": 5.0, "forests": 144.0, "pack_level": 0.0}[name]
 
     def set_profiling(self, enabled):
         self.profiling, self.profiled = bool(enabled), 0

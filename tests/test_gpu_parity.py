@@ -280,6 +280,42 @@ def test_second_larger_protein(gpu_required, systems):
         assert int(ctx.kernel.scalar("forests")) < s.nheavy
 
 
+def test_mid_size_system_packs_its_forests_into_one_round(gpu_required, systems):
+    """2clr's 3358 work items weigh ~1120 stores' worth; the classes' rule dealt them over 2560 forests (two rounds of the
+    1280 resident tree workgroups, a third full).  The rounds rule of the bookkeeping (pair_kernels.hip, packing_role)
+    packs them into ONE round when the total weight allows it: at most 1280 forests, every subtree built exactly once
+    (the tree statistics equal those of the unpacked first evaluation), the oracle's numbers on every step of a short
+    queue of jittered geometries, no evaluation withheld."""
+    torch = pytest.importorskip("torch")
+    s = systems("2clr")
+    oracle = Oracle(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel(device=0)
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    f0 = np.zeros((s.n, 3))
+    k.execute(s.pos, f0)  # unpacked (and the repeat that shares the 479-node subtree)
+    total0 = int(k.scalar("total_nodes"))
+    f1 = np.zeros((s.n, 3))
+    e1 = k.execute(s.pos, f1)  # planned packing
+    eo, fo = oracle.execute(s.pos)
+    assert_close(e1, f1, eo, fo)
+    assert int(k.scalar("total_nodes")) == total0
+    assert int(k.scalar("forests")) <= 1280, int(k.scalar("forests"))
+    dev = torch.device("cuda:0")
+    geoms = [s.jittered(70 + step) for step in range(8)]
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(8):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0, k.withheld()
+    assert int(k.scalar("forests")) <= 1280 and int(k.scalar("variant")) == 0
+    want = [oracle.execute(g) for g in geoms]
+    assert abs(ene.item() - sum(w[0] for w in want)) < 8 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 8 * TIGHT
+
+
 def test_atom_order_permutation_follows_the_reference_rules(gpu_required, systems):
     """The tree depends on atom order: the engine must follow the oracle for ANY order."""
     s = systems("fixture264")
@@ -1153,8 +1189,8 @@ def test_host_call_does_not_swallow_the_device_log(gpu_required, systems):
 
 
 def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
-    """Every overflow of a packed forest tightens the capacity the packing assumes (pack_level + 1); sixteen clean plans
-    in a row give one step back, so occasional mispredictions do not push a long run to one subtree per slot for good.
+    """Every overflow of a packed forest tightens the capacity the packing assumes (pack_level + 1); a few clean plans
+    in a row (four; sixteen until round 4, when plans came four times as often) give one step back, so occasional mispredictions do not push a long run to one subtree per slot for good.
     After an overflow the very next clean evaluation plans anew (the unpacked fallback is not kept for a replan period)."""
     s = systems("1dwc")
     monkeypatch.setenv("AGBNP_HIP_REPLAN_EVERY", "1")

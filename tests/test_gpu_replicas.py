@@ -7,6 +7,7 @@ Every case starts `python3 bench.py ...` as a FRESH child process (subprocess.ru
 ever exec'ed, the pytest process only waits.  Three processes use the GPU at most (pytest's own context + two ranks)."""
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -24,7 +25,7 @@ def _bench(extra_env, *flags, timeout=240):
     t0 = time.time()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
-    pids = [int(ln.split("pid ")[1].split(",")[0]) for ln in p.stderr.splitlines() if ln.startswith("bench: rank ") and "pid " in ln]
+    pids = [int(m) for m in re.findall(r"bench: rank \d+ of \d+: pid (\d+)", p.stderr)]  # (two ranks' lines may share a line of the pipe)
     return p, lines, pids, time.time() - t0
 
 
