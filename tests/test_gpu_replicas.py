@@ -58,7 +58,8 @@ def test_two_ranks_share_the_gpu_through_the_self_launcher(gpu_required):
     assert r["roofline"]["bound"] == "hbm" and r["roofline"]["kernel"] == "k_tree_cavity" and 0 < r["roofline"]["frac"] < 1
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["ms_per_eval"] > 50
     for x in r["ranks"]:  # the engine's answer on every rank against the oracle (same bar as the one-GPU parity tests)
-        assert x["parity_on_sample"]["max_abs_dE_kJmol"] <= 1e-7 and x["parity_on_sample"]["max_abs_dF_kJmolnm"] <= 1e-7, x
+        # (forces at the one-GPU tests' bar; the energy, ~ -1e5 kJ/mol, at 1e-6: the same relative bar as tests/test_gpu_parity.py)
+        assert x["parity_on_sample"]["max_abs_dE_kJmol"] <= 1e-6 and x["parity_on_sample"]["max_abs_dF_kJmolnm"] <= 1e-7, x
         assert x["device_name"] and x["timed_tries"] >= 1
     assert all(_gone(pid) for pid in pids)
     assert took < 90, took
