@@ -316,6 +316,31 @@ def test_mid_size_system_packs_its_forests_into_one_round(gpu_required, systems)
     assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < 8 * TIGHT
 
 
+def test_one_round_packing_in_gaussvol_mode_and_deterministic_mode(gpu_required, systems):
+    """The rounds rule where the bookkeeping rides in other launches: version 0 (both halves of the role in k_outputs) and the
+    deterministic mode (tile kernels: the role in the GB tile launch, bit-identical results on a second context)."""
+    s = systems("2clr")
+    for version in (0, 1):
+        oracle = Oracle(*s.params(), version=version)
+        outs = []
+        for ctx_no in range(2 if version == 1 else 1):
+            force = P.AGBNPForce.from_arrays(*s.params(), version=version)
+            k = P.HipCalcAGBNPForceKernel(device=0, mode="deterministic") if version == 1 else P.HipCalcAGBNPForceKernel(device=0)
+            k.initialize(force)
+            f = np.zeros((s.n, 3))
+            for step in range(3 + ctx_no):  # (the second context plans from another history: other forests, the same bits)
+                k.execute(s.jittered(30 + step), f)
+            pos = s.jittered(39)
+            f = np.zeros((s.n, 3))
+            e = k.execute(pos, f)
+            assert int(k.scalar("forests")) <= 1280, (version, int(k.scalar("forests")))
+            eo, fo = oracle.execute(pos)
+            assert_close(e, f, eo, fo)
+            outs.append((e, f.copy()))
+        if len(outs) == 2:
+            assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_atom_order_permutation_follows_the_reference_rules(gpu_required, systems):
     """The tree depends on atom order: the engine must follow the oracle for ANY order."""
     s = systems("fixture264")
