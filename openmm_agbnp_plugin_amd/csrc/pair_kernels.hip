@@ -1977,8 +1977,11 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl) {
   AGBNP_MARK(kKOutputs);
-  // (version 0: the roles' LDS, with room for the packed shapes and as many forest times of up to 6 k subtrees)
-  const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::min(2 * std::max(P.nh, 1) + 64, 12288);
+  // (version 0: the roles' LDS, with room for the packed shapes and as many forest times of up to 6 k subtrees -- or, where that
+  // is more, for the rounds rule of the packing: shapes, a round of running sums, the sorted order of ~1.25 items per subtree)
+  const int nh1 = std::max(P.nh, 1);
+  const int classes_ints = std::min(2 * nh1 + 64, 12288), rounds_ints = std::min(nh1 + P.tree_slots + nh1 + nh1 / 4 + 64, 14000);
+  const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::max(classes_ints, rounds_ints);
   hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), role_bytes, st, P, version, force_out, energy_out, components, role_bytes);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);

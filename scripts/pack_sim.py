@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Offline: the device's forest packing (pair_kernels.hip, packing_role) restated in numpy over measured subtree shapes
-(gpurun_out/shapes_<name>.npz from scripts/shape_dump.py), to try packing rules before they are built.  CPU only."""
+(profiles/r05/shapes_<name>.npz, dumped by scripts/shape_dump.py on the GPU box), to try packing rules before they are built.  CPU only."""
 import sys
 import numpy as np
 
@@ -52,7 +52,7 @@ def first_fit_decreasing(w, wn, wa, cap_w=1024, max_roots=8):
 
 
 for name in sys.argv[1:]:
-    d = np.load(f"gpurun_out/shapes_{name}.npz")
+    d = np.load(f"profiles/r05/shapes_{name}.npz")
     nodes, atoms = d["nodes"], d["atoms"]
     nh = len(nodes)
     roomy = 2 * nh <= SLOTS
@@ -94,7 +94,7 @@ def rounds_rule(w, F, max_roots=8, cap=1024, quantum=4):
 
 if __name__ == "__main__":
     for name in sys.argv[1:]:
-        d = np.load(f"gpurun_out/shapes_{name}.npz")
+        d = np.load(f"profiles/r05/shapes_{name}.npz")
         nodes, atoms = d["nodes"], d["atoms"]
         nh = len(nodes)
         roomy = 2 * nh <= SLOTS
