@@ -64,10 +64,24 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * platforms/opencl/src/OpenCLAGBNPKernels.cpp:541-556: forces and energy are ADDED to device
  * buffers, nothing is returned).  d_positions[3N], d_forces[3N], d_energy[1] are FP64 device
  * pointers on the context's device; `stream` is a hipStream_t (NULL = the context's own stream).
- * Asynchronous: six kernel launches for version 1 (seven on systems with more heavy atoms than two rounds of resident tree
- * workgroups, three for version 0), no host synchronisation, no allocation once the context has run on its
- * current capacity variant -- any number of evaluations may be queued, or captured into a HIP graph and replayed,
- * before agbnp_hip_finish().
+ * Asynchronous: FIVE kernel launches for version 1 (since round 5; six where the five-launch mode does not apply -- see
+ * below --, one more on systems whose forests do not fit one round of resident tree workgroups, three for version 0), no
+ * host synchronisation, no allocation once the context has run on its current capacity variant -- any number of
+ * evaluations may be queued, or captured into a HIP graph and replayed, before agbnp_hip_finish().
+ *
+ * Five-launch mode (version 1, FP64 row form of the pair stages, capacity variants 0-1; AGBNP_HIP_FIVE_LAUNCHES=0 turns it
+ * off).  There is no preparation launch: the tree launch reads d_positions itself and finds every heavy atom's level-2
+ * neighbours through masks that were laid down with a skin (0.08 nm, AGBNP_HIP_MASK_SKIN) at an earlier evaluation; the
+ * device renews the masks by itself when a heavy atom has used up a QUARTER of the skin (that evaluation is still exact).
+ * What a caller has to know: an evaluation whose positions differ from those of the evaluation before it by more than HALF
+ * the skin (0.04 nm) for some heavy atom -- a jump: a minimiser's long step, a Monte-Carlo move, unrelated geometries one
+ * after the other -- may have been built from masks that no longer cover it.  It is then WITHHELD exactly like an
+ * evaluation that overflowed (nothing added, logged, scalar 15 reports kind 16), the device has already renewed the masks
+ * at its positions, and the repeat is right: agbnp_hip_execute_host() repeats by itself, the other entry points' callers
+ * through the protocol they already have.  MD steps are two orders of magnitude below the threshold.  The mode ends for
+ * good, silently, where it cannot hold: a stream that is being captured (a replayed evaluation could not alternate
+ * between the two sets of accumulators the mode works with), agbnp_hip_execute_openmm(), the diagnostic self volumes,
+ * the deterministic / single-precision modes, a capacity variant beyond 1.  Scalar 16 says which path runs (5 or 6).
  *
  * Overflow contract.  The overlap-tree stage works in fixed-capacity LDS stores; an evaluation whose trees
  * outgrow them (or whose forest packing mispredicted) is INCOMPLETE.  Such an evaluation adds NOTHING to
@@ -193,6 +207,7 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms,
  *             32 / 64 a forest of several work items outgrew its nodes / its local atoms (the two kinds of 4);
  *             bits 8.. the part count of a lone work item that asked for its subtree to be shared further
+ *          16 kernel launches of a version-1 evaluation as the context runs now: 5 (five-launch mode) or 6
  *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation,
  *             default 16, or when the trees have drifted from the shapes it was planned for)
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor

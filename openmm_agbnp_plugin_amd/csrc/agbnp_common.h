@@ -73,18 +73,20 @@ enum StatusWord {
   kStatForestOverflow = 12,  // the part of kStatPackOverflow that IS a misprediction of the packing: forests of SEVERAL work items
                            // that outgrew their store (low half: by nodes, high half: by local atoms) (a lone splittable item is counted in kStatPackOverflow only: the
                            // capacity the packing assumes is not tightened for it)
-  kStatEvalWords = 13,     // ---- everything below is sticky
-  kStatEvalSeq = 13,       // evaluations enqueued since the last agbnp_hip_finish
-  kStatBadCount = 14,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
-  kStatStickyNode = 15,    // OR of the per-evaluation overflow words over those evaluations
-  kStatStickyAtom = 16,
-  kStatStickyPack = 17,
-  kStatStickyRow = 18,
-  kStatStickyOrder = 19,
-  kStatStickySplit = 20,   // MAX of kStatSplitWanted over those evaluations
-  kStatStickyForest = 21,  // bit 0: a forest of several items outgrew its NODES, bit 1: its local ATOMS (diagnostic: scalar 15)
-  kStatWords = 22,
-  kStatBadBitmap = 22,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatMaskAging = 13,     // five-launch mode: a heavy atom is more than a quarter of the neighbour masks' skin from where it was when
+                           // they were laid down (the evaluation is good; the masks are laid down anew in its Born launch)
+  kStatEvalWords = 14,     // ---- everything below is sticky
+  kStatEvalSeq = 14,       // evaluations enqueued since the last agbnp_hip_finish
+  kStatBadCount = 15,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
+  kStatStickyNode = 16,    // OR of the per-evaluation overflow words over those evaluations
+  kStatStickyAtom = 17,
+  kStatStickyPack = 18,
+  kStatStickyRow = 19,
+  kStatStickyOrder = 20,   // (bit 1: five-launch mode, the neighbour masks had gone stale)
+  kStatStickySplit = 21,   // MAX of kStatSplitWanted over those evaluations
+  kStatStickyForest = 22,  // bit 0: a forest of several items outgrew its NODES, bit 1: its local ATOMS (diagnostic: scalar 15)
+  kStatWords = 23,
+  kStatBadBitmap = 23,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
   kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };

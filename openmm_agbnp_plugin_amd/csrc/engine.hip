@@ -36,6 +36,7 @@ int tree_variant_atom_cap(int variant);
 int tree_variant_wgs_per_cu(int variant);
 hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A, hipStream_t st);
+hipError_t launch_tree_cavity_five(int variant, int slots, const TreeArgs& A, const PairArgs& P, hipStream_t st);
 }  // namespace agbnp
 
 using namespace agbnp;
@@ -95,8 +96,23 @@ struct agbnp_hip_context {
   DevBuf<unsigned long long> d_nbmask;
   DevBuf<double> d_charge, d_alpha, d_inv_rvdw, d_inv_vol_a;
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
+                           // (five-launch mode: TWO such tables, see below)
   size_t hstride = 64;
-  double* hrow(int r) const { return d_heavy.p + (size_t)r * hstride; }
+  // ---- five-launch mode (experimental, AGBNP_HIP_FIVE_LAUNCHES=1; version 1, capacity variants 0-1, FP64 [3n] positions, no
+  //      stream capture): no k_prep launch.  The trailing workgroups of the cavity launch do k_prep's per-atom work; what the
+  //      tree launch needs clean BEFORE it starts -- its accumulators, the subtree shapes, the per-evaluation status words --
+  //      exists twice and alternates with the evaluation's parity (the trailing workgroups clear the other set); the tree
+  //      reads the caller's positions itself; the level-2 neighbour masks carry a skin and are rebuilt (k_masks, a launch of
+  //      its own) when an evaluation has found a heavy atom more than half of it from where it was (that evaluation is void)
+  bool five = false;           // asked for
+  bool five_active = false;    // ... and in effect (switched off for good by a larger capacity variant, the OpenMM entry point, a stream capture)
+  int parity = 0;              // of the evaluation last enqueued
+  bool masks_valid = false;
+  double mask_skin = 0.08;     // nm; AGBNP_HIP_MASK_SKIN (0.06 and 0.08 cost the cavity launch the same; 0.04 renews the masks at every other evaluation of the headline's jitter)
+  DevBuf<int> d_estatus, d_row_atoms;
+  DevBuf<double> d_mask_ref;
+  double* htable(int p) const { return d_heavy.p + (size_t)p * kHvRows * hstride; }
+  double* hrow(int r) const { return htable(five_active ? parity : 0) + (size_t)r * hstride; }
   DevBuf<int2> d_ameta;
   DevBuf<double2> d_lut;
   // per-evaluation device data
@@ -237,7 +253,8 @@ int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
       for (int h = 0; h < nh; h++) g[h] = c->gamma[c->h2a[h]] / kRadiusIncrement;
       HIP_TRY(c, hipMemcpyAsync(c->d_charge.p, q, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->d_alpha.p, a, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-      if (nh > 0) HIP_TRY(c, hipMemcpyAsync(c->hrow(kHvGam), g, sizeof(double) * nh, hipMemcpyHostToDevice, c->stream));
+      for (int t = 0; t < (c->five ? 2 : 1) && nh > 0; t++)
+        HIP_TRY(c, hipMemcpyAsync(c->htable(t) + (size_t)kHvGam * c->hstride, g, sizeof(double) * nh, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       return AGBNP_HIP_OK;
     }
@@ -245,7 +262,8 @@ int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
     for (int h = 0; h < nh; h++) gam_cav[h] = c->gamma[c->h2a[h]] / kRadiusIncrement;
     HIP_TRY(c, c->d_charge.upload(c->charge));
     HIP_TRY(c, c->d_alpha.upload(c->alpha));
-    if (nh > 0) HIP_TRY(c, hipMemcpy(c->hrow(kHvGam), gam_cav.data(), sizeof(double) * nh, hipMemcpyHostToDevice));
+    for (int t = 0; t < (c->five ? 2 : 1) && nh > 0; t++)
+      HIP_TRY(c, hipMemcpy(c->htable(t) + (size_t)kHvGam * c->hstride, gam_cav.data(), sizeof(double) * nh, hipMemcpyHostToDevice));
     return AGBNP_HIP_OK;
   }
   std::vector<double> inv_rvdw(n), inv_vol_h(nh), gam_cav(nh), a_large(nh), v_large(nh), a_vdw(nh), v_vdw(nh);
@@ -273,11 +291,15 @@ int upload_parameters(agbnp_hip_context* c, bool changed_only = false) {
   }
   if (c->d_heavy.p == nullptr) {
     c->hstride = ((size_t)std::max(nh, 1) + 63) / 64 * 64;
-    HIP_TRY(c, c->d_heavy.alloc((size_t)kHvRows * c->hstride));
-    HIP_TRY(c, hipMemset(c->d_heavy.p, 0, sizeof(double) * kHvRows * c->hstride));
+    const size_t tables = c->five ? 2 : 1;
+    HIP_TRY(c, c->d_heavy.alloc(tables * kHvRows * c->hstride));
+    HIP_TRY(c, hipMemset(c->d_heavy.p, 0, sizeof(double) * tables * kHvRows * c->hstride));
   }
   auto put = [&](int row, const std::vector<double>& v) {  // in place: the addresses stay valid for captured graphs
-    return v.empty() ? hipSuccess : hipMemcpy(c->hrow(row), v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    for (int t = 0; t < (c->five ? 2 : 1) && !v.empty() && e == hipSuccess; t++)
+      e = hipMemcpy(c->htable(t) + (size_t)row * c->hstride, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice);
+    return e;
   };
   HIP_TRY(c, put(kHvInvVol, inv_vol_h));
   HIP_TRY(c, put(kHvGam, gam_cav));
@@ -320,6 +342,46 @@ int ensure_scratch(agbnp_hip_context* c) {
   c->T.scratch = c->d_scratch.p;
   c->T.scratch_stride = stride;
   return AGBNP_HIP_OK;
+}
+
+// Which of the two sets of {heavy-atom table, subtree shapes, per-evaluation status words} the launches of the next evaluation
+// use (five-launch mode: the evaluation's parity; otherwise set 0 and the one status array), and which one its trailing
+// workgroups clear for the evaluation after it.
+void apply_parity(agbnp_hip_context* c) {
+  PairArgs& P = c->P;
+  TreeArgs& T = c->T;
+  const bool five = c->five_active;
+  const int p = five ? c->parity : 0;
+  const size_t nhp = (size_t)std::max(c->nh, 1);
+  P.inv_vol_h = c->hrow(kHvInvVol);
+  P.gam_cav = c->hrow(kHvGam);
+  P.a_large = c->hrow(kHvALarge);
+  P.v_large = c->hrow(kHvVLarge);
+  P.hx = c->hrow(kHvX);
+  P.hy = c->hrow(kHvY);
+  P.hz = c->hrow(kHvZ);
+  P.gx = c->hrow(kHvGx);
+  P.gy = c->hrow(kHvGy);
+  P.gz = c->hrow(kHvGz);
+  P.sv_vdw = c->hrow(kHvSvVdw);
+  P.sv_large = c->hrow(kHvSvLarge);
+  T.hv = c->htable(p);
+  P.sizes = c->d_sizes.p + (size_t)p * nhp;
+  T.sizes = P.sizes;
+  P.estatus = five ? c->d_estatus.p + 16 * p : c->d_status.p;
+  T.status = P.estatus;  // (the tree kernels only touch words of their own evaluation)
+  P.five = five ? 1 : 0;
+  P.hstride = (unsigned)c->hstride;
+  P.next_hv = five ? c->htable(1 - p) : nullptr;
+  P.next_sizes = five ? c->d_sizes.p + (size_t)(1 - p) * nhp : nullptr;
+  P.next_estatus = five ? c->d_estatus.p + 16 * (1 - p) : nullptr;
+  P.mask_ref = c->d_mask_ref.p;
+  P.mask_move2 = 0.25 * c->mask_skin * c->mask_skin;
+  P.row_atoms = five ? c->d_row_atoms.p : nullptr;
+  T.row_atoms = P.row_atoms;
+  // the masks of that mode reach a skin further than the exact test of the level-2 search does
+  const double reach = sqrt(c->T.rcut2) + (five ? c->mask_skin : 0.0);
+  P.mask_rcut2 = five ? reach * reach : c->T.rcut2;
 }
 
 void wire_args(agbnp_hip_context* c) {
@@ -519,9 +581,9 @@ void wire_args(agbnp_hip_context* c) {
     T.packing = c->d_forest.p;
     T.slot_cap = c->slot_cap;
   }
-  T.status = c->d_status.p;
   T.scratch = c->d_scratch.p;
   T.scratch_stride = tree_variant_scratch_bytes(kGlobalVariant);
+  apply_parity(c);
 }
 
 int upload_identity_packing(agbnp_hip_context* c);
@@ -753,8 +815,16 @@ int allocate_work(agbnp_hip_context* c) {
   HIP_TRY(c, c->d_aposq.alloc(n));
   HIP_TRY(c, c->d_pbox.alloc(6 * c->d_pslot.count / 64));
   HIP_TRY(c, c->d_abox.alloc(6 * (size_t)nblk));
-  HIP_TRY(c, c->d_sizes.alloc(nhp));
-  HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * nhp));
+  HIP_TRY(c, c->d_sizes.alloc((c->five ? 2 : 1) * nhp));
+  HIP_TRY(c, hipMemset(c->d_sizes.p, 0, sizeof(int2) * (c->five ? 2 : 1) * nhp));
+  if (c->five) {
+    HIP_TRY(c, c->d_estatus.alloc(2 * 16));
+    HIP_TRY(c, hipMemset(c->d_estatus.p, 0, sizeof(int) * 2 * 16));  // (fast mode + single keep their own Born rows: no mask tiles there, see five_active)
+    static_assert(kStatEvalWords <= 16, "a parity's block of per-evaluation status words");
+    HIP_TRY(c, c->d_mask_ref.upload(std::vector<double>(3 * nhp, std::nan(""))));
+    HIP_TRY(c, c->d_row_atoms.alloc((size_t)kMaxItems * nslots));
+    HIP_TRY(c, hipMemset(c->d_row_atoms.p, 0, sizeof(int) * kMaxItems * nslots));
+  }
   HIP_TRY(c, c->d_born_part.alloc((size_t)n));
   HIP_TRY(c, c->d_born.alloc(n));
   HIP_TRY(c, c->d_born_fp.alloc(n));
@@ -797,12 +867,39 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   c->P.tree_atom_cap = tree_variant_atom_cap(c->variant);
   c->P.tree_slots = c->tree_slots[c->variant];
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
-  HIP_TRY(c, launch_prep(c->P, st, tl));
-  if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
+  if (c->five_active) {
+    // the mode ends for good where it cannot hold: a store beyond variant 1, positions that are not the caller's FP64 [3n]
+    // array, a stream that is being captured (a replayed evaluation would never change its parity)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    // (... or pair stages other than the FP64 row form: the renewal of the neighbour masks rides in the Born rows' launch)
+    // (... or the diagnostic pass-1 self volumes: a kernel instantiation of the six-launch path only)
+    if (c->variant > 1 || c->P.in.posq != nullptr || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics ||
+        (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)) {
+      c->five_active = false;
+      c->parity = 0;
+      apply_parity(c);
+      c->generation++;
+    }
+  }
   // workgroups of the tree launches: what the device keeps resident for this variant (they take forests from a queue);
   // fewer if there cannot be that many forests
   const int tree_grid = std::max(1, std::min(c->slot_cap, c->tree_slots[c->variant]));
-  HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
+  if (c->five_active) {
+    c->parity ^= 1;
+    apply_parity(c);
+    c->T.pos = d_pos;
+    c->T.out.h2a = c->d_h2a.p;  // (the forest workgroups find a candidate's atom through it)
+    if (!c->masks_valid) {  // a fresh context, or the evaluation before this one found its masks stale: lay them down anew
+      HIP_TRY(c, launch_masks(c->P, st, tl));
+      c->masks_valid = true;
+    }
+    if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
+    HIP_TRY(c, launch_tree_cavity_five(c->variant, tree_grid, c->T, c->P, st));
+  } else {
+    HIP_TRY(c, launch_prep(c->P, st, tl));
+    if (tl) HIP_TRY(c, tl->mark(kKTreeCavity, st));
+    HIP_TRY(c, launch_tree_cavity(c->variant, kGlobalGrid, tree_grid, c->T, st));
+  }
   if (c->version == 1) {
     HIP_TRY(c, launch_pair_stages(c->P, d_energy, c->d_components.p, st, tl));
     if (tl) HIP_TRY(c, tl->mark(kKTreePseudo, st));
@@ -863,6 +960,11 @@ int upload_identity_packing(agbnp_hip_context* c) {
     ident[(size_t)kRowStride * k + kMaxItems] = 1;
   }
   HIP_TRY(c, c->d_rows.upload(ident));
+  if (c->five) {  // (five-launch mode: the atom of every item's root, beside the rows)
+    std::vector<int> atoms((size_t)kMaxItems * nslots, 0);
+    for (size_t k = 0; k < nslots && c->nh > 0; k++) atoms[(size_t)kMaxItems * k] = c->h2a[std::min(k, nhp - 1) / parts];
+    HIP_TRY(c, c->d_row_atoms.upload(atoms));
+  }
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
   HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
   if (c->d_pack_items.p == nullptr) HIP_TRY(c, c->d_pack_items.upload(std::vector<int>(2 * nslots + 2, 0)));
@@ -897,6 +999,8 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   if (c->h_report) {
     agbnp_hip_context::HostReport* r = c->h_report;
     HIP_TRY(c, hipMemcpyAsync(r->status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost, st));
+    if (c->five_active)  // (the words of ONE evaluation live in its parity's block)
+      HIP_TRY(c, hipMemcpyAsync(r->status, c->d_estatus.p + 16 * c->parity, sizeof(int) * kStatEvalWords, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(r->components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     if (c->rows_capable) HIP_TRY(c, hipMemcpyAsync(r->rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(r->pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -922,6 +1026,7 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
     std::memcpy(c->last_pack, c->h_report->pack, sizeof(int) * 4);
   } else {
     HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
+    if (c->five_active) HIP_TRY(c, hipMemcpy(c->last_status, c->d_estatus.p + 16 * c->parity, sizeof(int) * kStatEvalWords, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
     if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost));
@@ -956,7 +1061,9 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
   c->forests_hint = 0;  // (one work item per slot again: the old rule decides)
-  if (s[kStatStickyOrder]) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
+  if (s[kStatStickyOrder] & 1) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
+  // (bit 1, five-launch mode: a heavy atom had left the neighbour masks' skin.  The device has laid the masks down anew in
+  // that very evaluation's Born launch: nothing for the host to do but repeat what was withheld)
   if (s[kStatStickyRow] && !c->rows_disabled) {
     // a neighbour list of the row-form pair stages outgrew what the launches walk of it: they walk twice as much from
     // here on -- or, if that already was the whole stride, the tile kernels take over (other launches either way: a
@@ -1023,6 +1130,9 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   c->cutoff = cutoff;
   c->device = device;
   c->fused_outputs = getenv("AGBNP_HIP_OUTPUT_LAUNCH") == nullptr;
+  c->five = version == 1 && !(getenv("AGBNP_HIP_FIVE_LAUNCHES") && atoi(getenv("AGBNP_HIP_FIVE_LAUNCHES")) == 0);  // (default since round 5; 0: six launches)
+  c->five_active = c->five;
+  if (getenv("AGBNP_HIP_MASK_SKIN")) c->mask_skin = std::min(0.5, std::max(0.0, atof(getenv("AGBNP_HIP_MASK_SKIN"))));
   c->r_vdw.assign(radius, radius + n);
   c->gamma.resize(n);
   c->alpha.assign(vdw_alpha, vdw_alpha + n);
@@ -1294,6 +1404,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 11: *value = c->last_pack[0]; break;    // forest packing: how far the assumed store capacity is tightened (0 = not)
     case 12: *value = c->last_pack[1]; break;    // ... evaluations since the packing in use was planned
     case 14: *value = c->last_pack[3]; break;    // ... packings planned so far
+    case 16: *value = c->five_active ? 5 : 6; break;  // five-launch mode in effect (version 1; see agbnp_hip.h)
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;
@@ -1334,7 +1445,7 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
     case 4:
     case 5: {  // overlap-tree shape: nodes / local atoms of the subtree rooted at every heavy atom (0 for hydrogens)
       std::vector<int2> sz(std::max(nh, 1));
-      HIP_TRY(c, hipMemcpy(sz.data(), c->d_sizes.p, sizeof(int2) * std::max(nh, 1), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(sz.data(), c->P.sizes, sizeof(int2) * std::max(nh, 1), hipMemcpyDeviceToHost));
       for (int i = 0; i < n; i++) out[i] = 0.0;
       for (int h = 0; h < nh; h++) out[c->h2a[h]] = which == 4 ? sz[h].x : sz[h].y;
       return AGBNP_HIP_OK;
@@ -1494,7 +1605,7 @@ int agbnp_debug_get_packing(agbnp_hip_context* c, int* order, int order_cap, int
     for (int k = 0; k < rows[(size_t)kRowStride * s + kMaxItems] && run < order_cap; k++) order[run++] = rows[(size_t)kRowStride * s + k];
     forest_start[s + 1] = run;
   }
-  if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->d_sizes.p, sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
+  if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->P.sizes, sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
   return AGBNP_HIP_OK;
 }
 // replaces the packing (same form) and (freeze != 0) stops the bookkeeping from planning new ones
@@ -1511,6 +1622,15 @@ int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, 
       for (int k = 0; k < count && forest_start[s] + k < norder; k++) rows[(size_t)kRowStride * s + k] = order[forest_start[s] + k];
     }
     HIP_TRY(c, hipMemcpy(c->d_rows.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
+    if (c->five) {  // (five-launch mode: the roots' atoms beside the rows)
+      std::vector<int> atoms((size_t)kMaxItems * c->slot_cap, 0);
+      for (int s = 0; s < nforests; s++)
+        for (int k = 0; k < kMaxItems; k++) {
+          const int item = rows[(size_t)kRowStride * s + k];
+          if (item >= 0 && work_item_root(item) < c->nh) atoms[(size_t)kMaxItems * s + k] = c->h2a[work_item_root(item)];
+        }
+      HIP_TRY(c, hipMemcpy(c->d_row_atoms.p, atoms.data(), sizeof(int) * atoms.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
   }
   c->P.pack_enabled = freeze ? 3 : c->P.pack_enabled;  // 3: the bookkeeping keeps its statistics but writes no packing

@@ -104,7 +104,22 @@ struct PairArgs {
   int split_fit;           // 1: subtrees whose items would not fit the store are shared among up to four items (AGBNP_HIP_SPLIT_FIT=0: off)
   int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 1000: every resident slot)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
-  int* status;
+  // ---- five-launch mode (experimental, AGBNP_HIP_FIVE_LAUNCHES=1; engine.hip): no k_prep launch.  The tree accumulators, the
+  //      subtree shapes and the per-evaluation status words exist TWICE and alternate with the evaluation's parity; the
+  //      trailing workgroups of the cavity launch (prep_role.h) clear the other set for the next evaluation
+  int five;                // 1: that mode
+  double* next_hv;         // heavy-atom table of the other parity
+  unsigned hstride;        // its row stride
+  int2* next_sizes;
+  int* next_estatus;
+  double mask_rcut2;       // squared reach of the neighbour masks: the conservative cutoff of the level-2 search (+ the skin, in that mode)
+  double* mask_ref;        // [3 nh] where the heavy atoms were when the neighbour masks were laid down
+  double mask_move2;       // (skin of the masks / 2)^2
+  int* row_atoms;          // [kMaxItems * slots] atom index of the root of every work item of a slot's row (the tree reads the
+                           // caller's positions itself in that mode); written with the rows
+  int* status;             // [kStatTotalWords]: the STICKY words (from kStatEvalSeq on) are addressed through this one,
+  int* estatus;            // the words of ONE evaluation ([0, kStatEvalWords)) through this one: the same array -- or, in the
+                           // five-launch mode, the block of the evaluation's parity (engine.hip)
   volatile int* host_status;  // pinned host memory, mapped: [0] evaluations completed since the last finish, [1] of them withheld --
                               // what agbnp_hip_poll reads without touching the device (written by the energy role)
   // ---- pair-stage intermediates
@@ -199,6 +214,7 @@ struct Timeline {
 };
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
+hipError_t launch_masks(const PairArgs& P, hipStream_t st, Timeline* tl);  // five-launch mode: the neighbour masks alone (with their skin) + their reference positions
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl);
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
                           Timeline* tl);

@@ -26,6 +26,7 @@
 #include "agbnp_common.h"
 #include "device_math.h"
 #include "pair_kernels.h"
+#include "prep_role.h"
 
 namespace agbnp {
 
@@ -135,38 +136,12 @@ __device__ __forceinline__ void lut_copy_rest(double2* __restrict__ s_lut, const
   for (int base = 1024; base < lut_entries; base += 1024) lut_store(s_lut, lut_fetch(lut, lut_entries, base), lut_entries, base);
 }
 
-// ---- where a position comes from: the caller's [3n] array, or an OpenMM context's posq (OpenmmSource) ------------------
-struct Pos3 {
-  double x, y, z;
-};
-__device__ __forceinline__ Pos3 slot_position(const PairArgs& P, int slot) {  // as k_adapt_positions reads it (adapter_kernels.hip)
-  if (P.in.is_double) {
-    const double4 p = static_cast<const double4*>(P.in.posq)[slot];
-    return Pos3{p.x, p.y, p.z};
-  }
-  const float4 p = static_cast<const float4*>(P.in.posq)[slot];
-  Pos3 r{(double)p.x, (double)p.y, (double)p.z};
-  if (P.in.correction) {  // mixed precision: position = posq + posqCorrection, both float
-    const float4 c = P.in.correction[slot];
-    r.x += (double)c.x, r.y += (double)c.y, r.z += (double)c.z;
-  }
-  return r;
-}
-__device__ __forceinline__ Pos3 atom_position(const PairArgs& P, int a) {
-  if (P.in.posq) return slot_position(P, P.omm.ctx_slot[a]);
-  return Pos3{P.pos[3 * a], P.pos[3 * a + 1], P.pos[3 * a + 2]};
-}
-__device__ __forceinline__ Pos3 heavy_position(const PairArgs& P, int h) {
-  if (P.in.posq) return slot_position(P, P.in.hslot[h]);
-  return atom_position(P, P.h2a[h]);
-}
-
 // ---- geometry in, accumulators cleared -------------------------------------------------------------------
 // Level-2 neighbour search, one workgroup per 64x64 tile of heavy atoms (I <= J), riding in the k_prep launch (it
 // reads the caller's positions directly, so it does not depend on the rest of k_prep): lane i of every wave tests a
 // quarter of block J against atom 64 I + i; the four 16-bit pieces meet in LDS and leave as 64 consecutive 64-bit
 // masks nbmask[J][64 I + i] (see agbnp_common.h).  Same test as the tree workgroup's own: d^2 < rcut2, j younger.
-__device__ void neighbor_tile(const PairArgs& P, int tile) {
+__device__ void neighbor_tile(const PairArgs& P, int tile, bool write_ref = false) {  // write_ref: five-launch mode, see k_rows
   __shared__ double s_x[128], s_y[128], s_z[128];
   __shared__ unsigned short s_bits[4][64];
   const int t = threadIdx.x;
@@ -186,6 +161,11 @@ __device__ void neighbor_tile(const PairArgs& P, int tile) {
     s_z[t] = r.z;
   }
   __syncthreads();
+  if (write_ref && I == J && t < 64 && 64 * I + t < P.nh) {  // the diagonal tile of a block also says where its atoms are now
+    P.mask_ref[3 * (64 * I + t)] = s_x[t];
+    P.mask_ref[3 * (64 * I + t) + 1] = s_y[t];
+    P.mask_ref[3 * (64 * I + t) + 2] = s_z[t];
+  }
   const int li = t & 63, jq = t >> 6, hi = 64 * I + li;
   const double xi = s_x[li], yi = s_y[li], zi = s_z[li];
   const int j0 = 16 * jq;  // each of the four waves takes a quarter of block J
@@ -194,7 +174,7 @@ __device__ void neighbor_tile(const PairArgs& P, int tile) {
   for (int jj = 0; jj < 16; jj++) {
     const int lj = j0 + jj, hj = 64 * J + lj;
     const double dx = s_x[64 + lj] - xi, dy = s_y[64 + lj] - yi, dz = s_z[64 + lj] - zi;
-    if (hj < P.nh && hj > hi && dx * dx + dy * dy + dz * dz < P.rcut2) hits |= 1u << jj;
+    if (hj < P.nh && hj > hi && dx * dx + dy * dy + dz * dz < P.mask_rcut2) hits |= 1u << jj;
   }
   s_bits[jq][li] = (unsigned short)hits;
   __syncthreads();
@@ -213,118 +193,19 @@ __global__ __launch_bounds__(256) void k_prep(PairArgs P, int prep_blocks) {
   if (AGBNP_TIMING_PREP == 3 && (int)blockIdx.x < prep_blocks) return;
 #endif
   if ((int)blockIdx.x >= prep_blocks) return neighbor_tile(P, blockIdx.x - prep_blocks);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // the status words of ONE evaluation start from zero; the sticky ones (overflow log since the last
-  // agbnp_hip_finish) are left alone, and the evaluation takes its running number
-  if (i < kStatEvalWords && blockIdx.x == 0) P.status[i] = 0;
-  if (i == 0) P.status[kStatEvalSeq] += 1;
-  if (i < P.nslots && !P.rows_on) {  // (the row form needs none of the tiles' records)
-    // bounding box of every block of 64 slots in pair order (one wave each) for the tile culling of the
-    // chain-rule stage; padding slots are neutral
-    const int a = P.pslot[i];
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    int2 sm = make_int2(0, 0);
-    if (a >= 0) {
-      const Pos3 r = atom_position(P, a);
-      sx = r.x, sy = r.y, sz = r.z, sm = P.ameta[a];
-    }
-    // the slot's record for the range-limited stages (a padding slot keeps a harmless position and says so)
-    P.prec[i] = make_double4(sx, sy, sz, __hiloint2double(a >= 0 ? 0 : -1, sm.x | ((sm.y & 0x7fff) << 16)));
-    P.ys[i] = 0.0;  // GB Y sums arrive through atomics
-    double lo[3] = {sx, sy, sz}, hi[3] = {sx, sy, sz};
-    for (int d = 0; d < 3; d++) {
-      lo[d] = a >= 0 ? lo[d] : 1e30;
-      hi[d] = a >= 0 ? hi[d] : -1e30;
-    }
-    for (int off = 32; off > 0; off >>= 1)
-      for (int d = 0; d < 3; d++) {
-        lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
-        hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
-      }
-    if ((i & 63) == 0) {
-      for (int d = 0; d < 3; d++) {
-        P.pbox[6 * (i >> 6) + d] = lo[d];
-        P.pbox[6 * (i >> 6) + 3 + d] = hi[d];
-      }
-    }
-  }
-  if (((P.fast && !P.gb_rows) || P.gb_far) && i < ((P.n + 63) & ~63)) {  // atom-order block boxes for the tile culling of the cut GB stage / the far-strip test
-    double lo[3], hi[3];
-    {
-      const Pos3 r = atom_position(P, i < P.n ? i : 0);
-      const double rr[3] = {r.x, r.y, r.z};
-      for (int d = 0; d < 3; d++) {
-        lo[d] = i < P.n ? rr[d] : 1e30;
-        hi[d] = i < P.n ? lo[d] : -1e30;
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1)
-      for (int d = 0; d < 3; d++) {
-        lo[d] = fmin(lo[d], __shfl_xor(lo[d], off, 64));
-        hi[d] = fmax(hi[d], __shfl_xor(hi[d], off, 64));
-      }
-    if ((i & 63) == 0)
-      for (int d = 0; d < 3; d++) {
-        P.abox[6 * (i >> 6) + d] = lo[d];
-        P.abox[6 * (i >> 6) + 3 + d] = hi[d];
-      }
-  }
-  if (P.rows_on) {
-    // Row form of the range-limited stages: its neighbour rows were built with a skin; they stay exact as long as no atom
-    // is further than half the skin from where it was then.  (NaN reference positions -- a fresh context -- fail the test.)
-    bool moved = false;
-    if (i < P.n) {
-      const Pos3 r = atom_position(P, i);
-      const double rx = r.x - P.nl_ref[3 * i], ry = r.y - P.nl_ref[3 * i + 1], rz = r.z - P.nl_ref[3 * i + 2];
-      moved = !(fma(rz, rz, fma(ry, ry, rx * rx)) <= P.nl_move2);
-    }
-    if (__ballot(moved) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&P.nl_flag[0], 1);
-    if (i < 3) P.nl_nitems[2 * i + ((P.nl_flag[1] + 1) & 1)] = 0;  // the work-item buffers that the next rebuild fills
-  }
-  if (i >= P.n) return;
-  if (P.zero_out) {  // (the evaluation's own outputs are added much later: the tree launch lies in between)
-    P.zero_out[3 * i] = 0.0;
-    P.zero_out[3 * i + 1] = 0.0;
-    P.zero_out[3 * i + 2] = 0.0;
-    if (i == 0) P.zero_out[3 * (size_t)P.n] = 0.0;
-  }
-  if (P.in.posq && P.in.atom_index && P.in.atom_index[P.omm.ctx_slot[i]] != i) P.status[kStatOrderStale] = 1;  // (the context has reordered its atoms)
-  const Pos3 r_i = atom_position(P, i);
-  const double x = r_i.x, y = r_i.y, z = r_i.z;
-  const double inv_vol_i = P.rows_on ? P.inv_vol_a[i] : 0.0;  // (asked for with everything else: no load waits for the heavy index)
-  const int screener_i = P.rows_on ? P.ameta[i].y : 0;
-  P.aposq[i] = make_double4(x, y, z, P.charge[i]);
-  if (P.rows_on) {
-    P.bw[i] = 0.0;  // brw + bru arrives through the GB stage's atomics
-    P.grec[i] = make_double4(0.0, 0.0, 0.0, 0.0);  // ... G through the Born rows'
-  }
-  P.gb_fx[i] = 0.0;  // GB sums arrive through atomics
-  P.gb_fy[i] = 0.0;
-  P.gb_fz[i] = 0.0;
-  P.born_part[i] = 0.0;  // Born sums and chain-rule sums arrive through atomics too
-  if (!P.rows_on) {      // (the row form assembles the chain-rule force from its G and H sums)
-    P.db_fx[i] = 0.0;
-    P.db_fy[i] = 0.0;
-    P.db_fz[i] = 0.0;
-  }
-  P.db_wu[i] = 0.0;
-  const int h = P.a2h[i];
-  if (h >= 0) {
-    P.hx[h] = x;
-    P.hy[h] = y;
-    P.hz[h] = z;
-    P.gx[h] = 0.0;
-    P.gy[h] = 0.0;
-    P.gz[h] = 0.0;
-    P.sv_vdw[h] = 0.0;
-    P.sv_large[h] = 0.0;
-    P.sizes[h] = make_int2(0, 0);  // subtree shapes are summed up by the tree workgroups (several may share a subtree)
-    if (P.rows_on) {
-      P.rec_h[h] = make_double4(x, y, z, inv_vol_i);
-      P.hrec[h] = make_double4(0.0, 0.0, 0.0, 0.0);  // H arrives through the chain-rule rows' atomics
-      P.hrow[h] = make_double4(x, y, z, __hiloint2double(0, i | (screener_i << 24)));
-    }
-  }
+  prep_atoms(P, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.x == 0, false);
+}
+
+// five-launch mode: the neighbour masks alone (a launch of its own, only when the masks in hand have gone stale), and where
+// the heavy atoms are while they are laid down
+__global__ __launch_bounds__(256) void k_masks(PairArgs P, int ref_blocks) {
+  if ((int)blockIdx.x >= ref_blocks) return neighbor_tile(P, blockIdx.x - ref_blocks);
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= P.nh) return;
+  const Pos3 r = heavy_position(P, h);
+  P.mask_ref[3 * h] = r.x;
+  P.mask_ref[3 * h + 1] = r.y;
+  P.mask_ref[3 * h + 2] = r.z;
 }
 
 // ---- GB pairs, symmetric 64x64 tiles (all pairs, no cutoff) ------------------------------------------------
@@ -404,9 +285,9 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         // in k_outputs the forces -- and it is entered in the sticky log that agbnp_hip_finish reports, so that
         // queued or graph-replayed evaluations cannot lose an overflow to the next evaluation's k_prep.  This
         // role runs exactly once per evaluation, after the tree stage.
-        const int node = P.status[kStatNodeOverflow], atom = P.status[kStatAtomOverflow], pack = P.status[kStatPackOverflow];
-        const int rowo = P.status[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
-        const int order = P.status[kStatOrderStale];
+        const int node = P.estatus[kStatNodeOverflow], atom = P.estatus[kStatAtomOverflow], pack = P.estatus[kStatPackOverflow];
+        const int rowo = P.estatus[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
+        const int order = P.estatus[kStatOrderStale];
         if ((node | atom | pack | rowo | order) == 0) {
           const double e = o0 + o1 + o2 + o3;
           if (P.omm.force_fixed == nullptr)
@@ -423,8 +304,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyPack] |= pack;
           P.status[kStatStickyRow] |= rowo;
           P.status[kStatStickyOrder] |= order;
-          P.status[kStatStickySplit] = max(P.status[kStatStickySplit], P.status[kStatSplitWanted]);
-          const int fo = P.status[kStatForestOverflow];
+          P.status[kStatStickySplit] = max(P.status[kStatStickySplit], P.estatus[kStatSplitWanted]);
+          const int fo = P.estatus[kStatForestOverflow];
           P.status[kStatStickyForest] |= ((fo & 0xffff) ? 1 : 0) | ((fo >> 16) ? 2 : 0);
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
@@ -498,8 +379,8 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   };
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
   // every control word is asked for here, together, underneath the shapes (one cold round trip for all of them)
-  const int st_node = P.status[kStatNodeOverflow], st_atom = P.status[kStatAtomOverflow], st_pack = P.status[kStatPackOverflow];
-  const int st_forest = P.status[kStatForestOverflow];
+  const int st_node = P.estatus[kStatNodeOverflow], st_atom = P.estatus[kStatAtomOverflow], st_pack = P.estatus[kStatPackOverflow];
+  const int st_forest = P.estatus[kStatForestOverflow];
   const int ps_level = P.pack_state[0], age = P.pack_state[1], ps_clean = P.pack_state[2];
   const int tot_planned = P.pack_state[4], max_planned = P.pack_state[5];
   const bool overflow = (st_node | st_atom | st_pack) != 0;
@@ -589,9 +470,9 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const bool plan = overflow || age + 1 >= P.replan_every || drifted;
   PAIR_STAMP(1, 7);
   if (t == 0) {
-    P.status[kStatTotalNodes] = tot_now;
-    P.status[kStatMaxNodes] = max_now;
-    P.status[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
+    P.estatus[kStatTotalNodes] = tot_now;
+    P.estatus[kStatMaxNodes] = max_now;
+    P.estatus[kStatMaxAtoms] = max(max(imax[4], imax[5]), max(imax[6], imax[7]));
     P.pack_state[0] = level;
     // (after an overflow the fallback written below is no plan: the next clean evaluation plans anew)
     if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
@@ -599,7 +480,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     if (plan) P.pack_state[3] += 1;  // (plans so far: a diagnostic)
     if (plan && !overflow) P.pack_state[4] = tot_now, P.pack_state[5] = max_now;  // (the shapes this plan is made for)
     if (!plan) {
-      P.status[kStatForests] = P.nforests[0];       // (the packing stays)
+      P.estatus[kStatForests] = P.nforests[0];       // (the packing stays)
       P.forest_time[P.tree_slot_cap] = 2;           // tells dealing_role that there is nothing to deal
     }
   }
@@ -732,7 +613,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     __syncthreads();
     if (t == 0) {
       P.nforests[0] = nf;
-      P.status[kStatForests] = nf;
+      P.estatus[kStatForests] = nf;
       P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;  // (word behind the times: are they there)
     }
     PAIR_STAMP(1, 9);
@@ -857,7 +738,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   __syncthreads();
   if (t == 0) {
     P.nforests[0] = nf_used;
-    P.status[kStatForests] = nf_used;
+    P.estatus[kStatForests] = nf_used;
     P.forest_time[P.tree_slot_cap] = rank_by_time ? 1 : 0;
   }
   PAIR_STAMP(1, 9);
@@ -919,6 +800,16 @@ __device__ void dealing_role(const PairArgs& P, char* scratch, int scratch_bytes
     int4* dst = reinterpret_cast<int4*>(P.rows + (size_t)kRowStride * slot);
     dst[0] = lo, dst[1] = hi;
     dst[2] = make_int4(m, 0, 0, 0);
+    if (P.row_atoms) {  // five-launch mode: the atoms of the items' roots (the tree reads the caller's positions itself)
+      const int it[kMaxItems] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      int4 a0, a1;
+      int at[kMaxItems];
+#pragma unroll
+      for (int k = 0; k < kMaxItems; k++) at[k] = it[k] >= 0 ? P.h2a[it[k] & 0xffffff] : 0;
+      a0 = make_int4(at[0], at[1], at[2], at[3]), a1 = make_int4(at[4], at[5], at[6], at[7]);
+      int4* da = reinterpret_cast<int4*>(P.row_atoms + (size_t)kMaxItems * slot);
+      da[0] = a0, da[1] = a1;
+    }
   };
   static_assert(kMaxItems == 8 && kRowStride >= kMaxItems + 4, "two 16-byte words of items, then the word with their number");
   if (!ranked) {  // as they come
@@ -1799,11 +1690,21 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
 // (launch bounds: six waves per SIMD = three workgroups per CU, 80 vector registers; the GB rows, whose pair terms and
 // bookkeeping role need more, four)
 // SINGLE: the Born / chain-rule rows with their pair terms in single precision (row_kernels.h; fast mode + AGBNP_HIP_MODE_SINGLE)
-template <int KIND, bool SINGLE = false>
+// MASKS (five-launch mode, Born rows only; `role_bytes` then carries the number of the first such workgroup): behind the row
+// and list-building workgroups the grid holds one workgroup per tile of the level-2 neighbour masks.  They leave on two scalar
+// loads unless the cavity launch of this evaluation found a heavy atom a quarter of the masks' skin (or more: then the
+// evaluation is void) from where it was when the masks were laid down; then they lay them down anew from this evaluation's
+// positions, for the next one: the masks heal on the device, whatever is queued behind.
+template <int KIND, bool SINGLE = false, bool MASKS = false>
 __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
   extern __shared__ double2 s_dyn[];
 
   int blk = blockIdx.x;
+  if (MASKS && KIND == kBornRows && blk >= role_bytes) {
+    if (threadIdx.x >= 256) return;
+    if (((P.estatus[kStatOrderStale] & 2) | P.estatus[kStatMaskAging]) == 0) return;
+    return neighbor_tile(P, blk - role_bytes, true);
+  }
   if (KIND == kChainRows) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
     if (blk < 2 && threadIdx.x >= 256) return;
     if (blk == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
@@ -1874,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
     fy += P.gb_fy[i] + P.db_fy[i];
     fz += P.gb_fz[i] + P.db_fz[i];
   }
-  if (evaluation_overflowed(P.status)) return;  // incomplete evaluation: withheld (see energy_role), the caller repeats it
+  if (evaluation_overflowed(P.estatus)) return;  // incomplete evaluation: withheld (see energy_role), the caller repeats it
   if (P.omm.force_fixed) {
     // an OpenMM context's force buffer: 64-bit fixed point, value * 2^32 rounded to nearest, three planes over the
     // padded atom count in the context's atom order, integer atomics (GVolReduceTree.cl:117-119)
@@ -1903,6 +1804,13 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
       if (m__ != hipSuccess) return m__;             \
     }                                                \
   } while (0)
+
+hipError_t launch_masks(const PairArgs& P, hipStream_t st, Timeline* tl) {
+  AGBNP_MARK(kKPrep);  // (booked as k_prep: it takes that launch's place in the evaluations that need it)
+  const int ref_blocks = (std::max(P.nh, 1) + 255) / 256;
+  hipLaunchKernelGGL(k_masks, dim3(ref_blocks + P.nb_tiles), dim3(256), 0, st, P, ref_blocks);
+  return hipGetLastError();
+}
 
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl) {
   AGBNP_MARK(kKPrep);
@@ -1933,6 +1841,9 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     AGBNP_MARK(kKBornRows);
     if (P.single)
       hipLaunchKernelGGL((k_rows<kBornRows, true>), dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    else if (P.five)  // (five-launch mode: + the conditional mask tiles)
+      hipLaunchKernelGGL((k_rows<kBornRows, false, true>), dim3(born_blocks + build_blocks + P.nb_tiles), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr,
+                         (double*)nullptr, born_blocks + build_blocks);
     else
       hipLaunchKernelGGL(k_rows<kBornRows>, dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
     AGBNP_CHECK_LAUNCH();

@@ -225,7 +225,7 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
   const RowLists L = row_lists<KIND>(P);
   if (sub >= L.groups * L.parts) return;
   if (!stale) {  // the list stands; is all of it walked?  (the walk may have been set up for a shorter reach, or narrowed)
-    if (lane == 0 && L.count[sub] > L.cap) P.status[kStatRowOverflow] = 1;
+    if (lane == 0 && L.count[sub] > L.cap) P.estatus[kStatRowOverflow] = 1;
     return;
   }
   const int g = sub / L.parts, part = sub - g * L.parts;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
     // the length is stored UNtruncated (it may exceed the stride) and clamped where it bounds a walk: every later evaluation
     // queued before the host reacts sees count > cap above and is withheld too, not just the one that rebuilt the list
     L.count[sub] = cnt;
-    if (cnt > L.cap) P.status[kStatRowOverflow] = 1;
+    if (cnt > L.cap) P.estatus[kStatRowOverflow] = 1;
     // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
     append_items<KIND>(P, sub, min(cnt, L.cap), KIND == kGbRows && part == 0);
   }
@@ -367,7 +367,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
     if (lane == 0 && slice == 0) {
       P.nlh_count[sub] = count;  // (untruncated, see build_list)
-      if (count > L.cap) P.status[kStatRowOverflow] = 1;
+      if (count > L.cap) P.estatus[kStatRowOverflow] = 1;
       append_items<kBornRows>(P, sub, min(count, L.cap), false);
     }
     if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
@@ -379,7 +379,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
-  if (KIND == kBornRows && active && slice == 0 && lane == 0 && !stale && listed_raw > L.cap) P.status[kStatRowOverflow] = 1;  // (not all of it is walked)
+  if (KIND == kBornRows && active && slice == 0 && lane == 0 && !stale && listed_raw > L.cap) P.estatus[kStatRowOverflow] = 1;  // (not all of it is walked)
   const int todo = active ? max(0, min(count - first, rs)) : 0;  // entries of this slice
   const int nsteps = (todo + 63) >> 6;
   double acc[4 * R];

@@ -106,6 +106,9 @@ struct TreeArgs {
   int* status;                 // [kStatTotalWords]
   char* scratch;               // GLOBAL variant: per-workgroup slab
   size_t scratch_stride;
+  // five-launch mode (engine.hip): the tree reads the caller's positions itself -- no k_prep has put them into the table
+  const double* pos;           // [3n] the caller's positions
+  const int* row_atoms;        // [kMaxItems * slots] atom of the root of item k of work slot s (beside `rows`)
 
   __device__ __forceinline__ double& hvat(int row, int h) const { return hv[(unsigned)row * hstride + (unsigned)h]; }
   __device__ __forceinline__ const int* forest_start() const { return packing; }
@@ -422,9 +425,11 @@ enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 
 // (level-2 node k <-> local atom k), then level 3 of all trees, and so on: levels are contiguous over the whole
 // forest, sibling lists never mix trees.  returns BuildResult (workgroup-uniform); on success *nnodes_out /
 // *natoms_out are set.
-template <int NCAP, int ACAP, int BS>
+template <int NCAP, int ACAP, int BS, bool FIVE = false>
 __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, int my_item, const int (&items)[kMaxRoots], int m,
-                            int* nnodes_out, int* natoms_out) {
+                            int* nnodes_out, int* natoms_out, int my_atom = 0) {
+  // FIVE (five-launch mode): positions come from the caller's array -- a root's through the atom index that arrived with its
+  // work item (my_atom), a candidate's through h2a (one more dependent load, on a table every workgroup of the CU shares)
   // my_item: work item number tid of the forest (lanes tid < m); items[]: all of them, wave-uniform (scalar registers)
   constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
   AGBNP_BUILD_STAMP_BEGIN();
@@ -458,7 +463,13 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
   if (tid < m) {
     const int item = my_item;
     const int hi = work_item_root(item);
-    const double rx = A.hvat(kHvX, hi), ry = A.hvat(kHvY, hi), rz = A.hvat(kHvZ, hi);
+    double rx, ry, rz;
+    if (FIVE) {
+      const double* __restrict__ pr = A.pos + 3 * (size_t)my_atom;
+      rx = pr[0], ry = pr[1], rz = pr[2];
+    } else {
+      rx = A.hvat(kHvX, hi), ry = A.hvat(kHvY, hi), rz = A.hvat(kHvZ, hi);
+    }
     const double ra = A.hvat(kHvALarge, hi), rv = A.hvat(kHvVLarge, hi), rg = A.hvat(kHvGam, hi);
     S.at[0][tid] = rx;
     S.at[1][tid] = ry;
@@ -544,8 +555,14 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       const int packed = __double2loint(S.nd[6][st]);
       const int q = mine ? packed >> 24 : 0;
       const int hjn = mine ? packed & 0xffffff : 0;
-      const double xj = A.hvat(kHvX, hjn), yj = A.hvat(kHvY, hjn), zj = A.hvat(kHvZ, hjn);
+      double xj, yj, zj;
       const double aj = A.hvat(kHvALarge, hjn), vj = A.hvat(kHvVLarge, hjn), gj = A.hvat(kHvGam, hjn);
+      if (FIVE) {
+        const double* __restrict__ pj = A.pos + 3 * (size_t)A.out.h2a[hjn];
+        xj = pj[0], yj = pj[1], zj = pj[2];
+      } else {
+        xj = A.hvat(kHvX, hjn), yj = A.hvat(kHvY, hjn), zj = A.hvat(kHvZ, hjn);
+      }
       double sv = 0.0, gvol = 0.0;
       if (mine) sv = dev_merge_volume2(S.at[0][q], S.at[1][q], S.at[2][q], S.at[3][q], S.at[4][q], xj, yj, zj, aj, vj, gvol);
       tree_barrier<NCAP>();  // the near records of this trip are in registers: accepted ones may take staging slots

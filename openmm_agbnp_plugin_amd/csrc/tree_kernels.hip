@@ -1,6 +1,8 @@
 // __global__ entry points of the overlap-tree stage (see tree_kernels.h for the algorithm).
 #include "tree_kernels.h"
 
+#include "pair_kernels.h"
+#include "prep_role.h"
 #include "row_kernels.h"
 
 namespace agbnp {
@@ -108,18 +110,19 @@ constexpr int tree_waves_per_simd(int ncap, int bs) {
 }
 
 // SV1: the launch also collects the self volumes of pass 1 (enlarged radii; a diagnostic: agbnp_hip_set_diagnostics)
-template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1>
-__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity(TreeArgs A) {
+// FIVE: the five-launch mode's instantiation (k_tree_cavity_five below): positions straight from the caller's array.
+template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1, bool FIVE>
+__device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree_blocks) {  // tree_blocks: forest workgroups of the launch
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;  // hand-off word of the work queue (in LDS for every variant)
   const int tid = threadIdx.x;
-  const int tree_blocks = (int)gridDim.x;  // forest workgroups of the launch
   // the row of the workgroup's own work slot is requested before anything is waited for (blockIdx.x < slot_cap: the
   // row exists whether or not the slot is in use)
-  int first_item = -1;
+  int first_item = -1, first_atom = 0;
   if ((tid & 63) < kMaxRoots) first_item = A.rows[(size_t)kRowStride * blockIdx.x + (tid & 63)];
+  if (FIVE && (tid & 63) < kMaxRoots) first_atom = A.row_atoms[(size_t)kMaxItems * blockIdx.x + (tid & 63)];
   const int nforests = min(A.nforests()[0], A.slot_cap);  // (never above the slots the per-slot arrays hold)
   if (blockIdx.x == 0 && tid == 0) A.cur_nforests()[0] = nforests;
   if ((int)blockIdx.x >= nforests && tid == 0) {  // an idle work slot: k_tree_pseudo's workgroup of the same slot finds nothing to replay
@@ -135,10 +138,11 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     // slot -> forest indirection in front of it): lanes 0..7 of every wave fetch one item each
     // (-1 = no item.  Counting the items with a ballot instead of reading the row's count word out of lane 8 makes
     // k_tree_cavity 1.6 us faster on 1dwc, A/B on one box -- same spill counts, different register allocation.)
-    int my_item = first_item;
+    int my_item = first_item, my_atom = first_atom;
     if (slot != (int)blockIdx.x) {  // (a forest from the queue)
       my_item = -1;
       if ((tid & 63) < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + (tid & 63)];
+      if (FIVE && (tid & 63) < kMaxRoots) my_atom = A.row_atoms[(size_t)kMaxItems * slot + (tid & 63)];
     }
     const int m = __popcll(__ballot(my_item >= 0));  // 1..kMaxRoots
     int items[kMaxRoots];
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     tree_barrier<NCAP>();
     CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
-    int rc = build_forest<NCAP, ACAP, BS>(S, A, tid, my_item, items, m, &nnodes, &natoms);
+    int rc = build_forest<NCAP, ACAP, BS, FIVE>(S, A, tid, my_item, items, m, &nnodes, &natoms, my_atom);
     CSTAMP(0);
     double e_sum = 0.0;
     int npairs = 0;
@@ -287,6 +291,25 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     if (!queued) break;
     slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, tree_blocks));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
   }
+}
+
+template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1>
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity(TreeArgs A) {
+  cavity_forests<NCAP, ACAP, BS, GLOBAL, SV1, false>(A, (int)gridDim.x);
+}
+
+// Five-launch mode (experimental; engine.hip): there is no k_prep launch.  The forest workgroups read the caller's positions
+// themselves; the workgroups BEHIND them in the grid -- dispatched when the first forests have left, done long before the last
+// ones are -- do k_prep's per-atom work for the launches that follow (prep_role.h) and clear the other parity's tree
+// accumulators, subtree shapes and status words for the NEXT evaluation.
+static_assert(kPrepHvGx == kHvGx && kPrepHvGx + 3 == kHvSvVdw && kPrepHvSvLarge == kHvSvLarge, "prep_role.h addresses the table's rows by number");
+template <int NCAP, int ACAP, int BS>
+__global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity_five(TreeArgs A, PairArgs P, int tree_blocks) {
+  if ((int)blockIdx.x >= tree_blocks) {
+    const int b = (int)blockIdx.x - tree_blocks;
+    return prep_atoms(P, b * BS + (int)threadIdx.x, b == 0, true);
+  }
+  cavity_forests<NCAP, ACAP, BS, false, false, true>(A, tree_blocks);
 }
 
 // ---- the forces leave with the last tree launch (TreeOutputs) ------------------------------------------------------
@@ -724,6 +747,20 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
     default: grid = global_grid < A.nh ? global_grid : A.nh; return AGBNP_CAVITY(kGlobalNodeCap, kGlobalAtomCap, kBS, true);
   }
 #undef AGBNP_CAVITY
+}
+
+hipError_t launch_tree_cavity_five(int variant, int slots, const TreeArgs& A, const PairArgs& P, hipStream_t st) {
+  if (A.nh <= 0 || variant > 1) return hipErrorInvalidValue;  // (the engine leaves the mode before it gets here)
+  const int work = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
+  const int prep_blocks = (work + kBS - 1) / kBS;
+  if (variant == 0) {
+    const size_t lds = TreeStore<AGBNP_SMALL_STORE>::kBytes;
+    hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+  } else {
+    const size_t lds = TreeStore<512, 64>::kBytes;
+    hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A0, hipStream_t st) {

@@ -12,12 +12,18 @@ fetch_csv, write_csv, tag, system = sys.argv[1:5]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def rows_name(name):
+    """k_rows<kind, single?, masks?> -> k_rows<kind>, + [single] for the FP32 variant (Born, chain-rule and GB rows are different kernels)"""
+    inner = name[name.index("<") + 1:name.index(">")].split(",")
+    return f"k_rows<{inner[0].strip()}>" + ("[single]" if len(inner) > 1 and inner[1].strip() == "true" else "")
+
+
 def per_kernel(path, counter):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "agbnp::" in r["Kernel_Name"]:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("agbnp::", "")
-            base = name.replace(", false>", ">").replace(", true>", ">[single]") if name.startswith("k_rows") else name.split("<")[0]  # (k_rows<0 | 1 | 2>: different kernels)
+            base = rows_name(name) if name.startswith("k_rows") else name.split("<")[0].replace("k_tree_cavity_five", "k_tree_cavity")  # (the five-launch mode's instantiation)
             d[base].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in d.items()}, {k: len(v) for k, v in d.items()}
 

@@ -10,10 +10,11 @@ for r in csv.DictReader(open(src)):
     if "agbnp::" not in r["Kernel_Name"]:
         continue
     name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("agbnp::", "")
-    if name.startswith("k_rows"):  # (k_rows<0 | 1 | 2>: Born, chain-rule and GB rows are different kernels; since round 4 a second
-        name = name.replace(", false>", ">").replace(", true>", ">[single]")  # template argument says whether the pair terms are FP32)
+    if name.startswith("k_rows"):  # (k_rows<kind, single?, masks?>: Born, chain-rule and GB rows are different kernels)
+        inner = name[name.index("<") + 1:name.index(">")].split(",")
+        name = f"k_rows<{inner[0].strip()}>" + ("[single]" if len(inner) > 1 and inner[1].strip() == "true" else "")
     else:
-        name = name.split("<")[0]
+        name = name.split("<")[0].replace("k_tree_cavity_five", "k_tree_cavity")  # (the five-launch mode's instantiation)
     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
         "SQ_LDS_BANK_CONFLICT"]

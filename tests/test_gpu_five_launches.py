@@ -1,0 +1,147 @@
+"""GPU box: the experimental five-launch mode (AGBNP_HIP_FIVE_LAUNCHES=1): no k_prep launch -- the cavity
+launch's trailing workgroups do its per-atom work, the tree accumulators / subtree shapes / per-evaluation status words
+alternate between two sets, the tree reads the caller's positions itself, the level-2 neighbour masks carry a skin and are
+laid down anew ON THE DEVICE when a heavy atom has used up a quarter of it.  Same numbers as the oracle, same contracts as the
+default mode (reference path: ReferenceAGBNPKernels.cpp:274-795)."""
+import os
+
+import numpy as np
+import pytest
+
+import openmm_agbnp_plugin_amd as P
+from oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-7
+
+
+@pytest.fixture()
+def five(monkeypatch):
+    monkeypatch.setenv("AGBNP_HIP_FIVE_LAUNCHES", "1")
+
+
+def _kernel(s, version=1):
+    k = P.HipCalcAGBNPForceKernel(device=0)
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=version))
+    return k
+
+
+def _close(e, f, eo, fo, tol=TIGHT):
+    assert abs(e - eo) < tol * max(1.0, abs(eo) * 1e-3), f"energy differs by {abs(e - eo):.3e}"
+    assert np.abs(f - fo).max() < tol, f"forces differ by {np.abs(f - fo).max():.3e}"
+
+
+@pytest.mark.parametrize("name", ["trpcage", "1dwc", "2clr", "fixture264"])
+def test_five_launches_match_the_oracle(gpu_required, systems, five, name):
+    """Unrelated geometries one after the other through the host entry point: every jump beyond the masks' skin voids an
+    evaluation, the device lays the masks down anew, the call repeats itself -- the caller sees the oracle's numbers."""
+    s = systems(name)
+    k = _kernel(s)
+    oracle = Oracle(*s.params(), version=1)
+    centre = s.pos.mean(axis=0)
+    for pos in (s.pos, s.jittered(1), s.jittered(2, sigma=0.02), centre + 0.97 * (s.pos - centre), s.pos):
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        _close(e, f, eo, fo)
+    times = k.kernel_times() if hasattr(k, "kernel_times") else {}
+    assert "k_prep" not in {n for n, v in times.items() if v[1] > 0}
+
+
+def test_five_launches_is_five_launches(gpu_required, systems, five):
+    """The per-kernel timeline of a settled 1dwc evaluation holds five kernels, none of them k_prep."""
+    s = systems("1dwc")
+    k = _kernel(s)
+    f = np.zeros((s.n, 3))
+    for step in range(4):
+        k.execute(s.jittered(step), f)
+    k.set_profiling(True)
+    for step in range(4, 8):
+        k.execute(s.jittered(step), f)
+    times = {n: v for n, v in k.kernel_times().items() if v[1] > 0}
+    k.set_profiling(False)
+    assert set(times) == {"k_tree_cavity", "k_born_rows", "k_gb_tiles", "k_dborn_rows", "k_tree_pseudo"}, times
+
+
+def test_masks_heal_on_the_device_along_a_queued_walk(gpu_required, systems, five):
+    """A cumulative random walk queued on the device-resident path (nobody reads the log in between): atoms use up the masks'
+    skin every few dozen steps, the masks are renewed by the evaluation that notices (a quarter of the skin: still exact),
+    no evaluation is withheld, and the sums are the oracle's."""
+    torch = pytest.importorskip("torch")
+    s = systems("trpcage")
+    k = _kernel(s)
+    oracle = Oracle(*s.params(), version=1)
+    rng = np.random.default_rng(7)
+    steps = 150
+    walk = s.pos + np.cumsum(rng.normal(0.0, 0.0015, (steps,) + s.pos.shape), axis=0)
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(walk, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    f0 = np.zeros((s.n, 3))
+    k.execute(s.pos, f0)  # (settles the capacity variant and the first masks)
+    for i in range(steps):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0, (k.withheld(), int(k.scalar("overflow_kinds")))
+    want = [oracle.execute(g) for g in walk]
+    assert abs(ene.item() - sum(w[0] for w in want)) < steps * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(w[1] for w in want)).max() < steps * TIGHT
+    assert float(np.linalg.norm(walk[-1] - s.pos, axis=1).max()) > 0.03  # (the walk did leave the first masks' skin)
+
+
+def test_a_jump_voids_one_queued_evaluation_only(gpu_required, systems, five):
+    """A geometry that jumps (every atom 0.05 nm away at once) in the middle of a queue: that evaluation is withheld (its trees
+    were built from masks that no longer cover it), the device renews the masks in the same evaluation, the ones queued
+    behind it are complete."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    k = _kernel(s)
+    oracle = Oracle(*s.params(), version=1)
+    f0 = np.zeros((s.n, 3))
+    k.execute(s.pos, f0)
+    k.execute(s.jittered(1), f0)
+    shifted = s.pos + np.random.default_rng(3).normal(0.0, 0.03, s.pos.shape)
+    geoms = [s.jittered(2), s.jittered(3), shifted, shifted + 0.001, s.jittered(4, sigma=0.001) + (shifted - s.pos)]
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(np.stack(geoms), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for i in range(len(geoms)):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 1 and list(k.withheld()) == [2]
+    assert int(k.scalar("overflow_kinds")) & 16  # (reported like a reordered context: the evaluation's inputs were stale)
+    want = [oracle.execute(g) for g in geoms]
+    clean = [0, 1, 3, 4]
+    assert abs(ene.item() - sum(want[i][0] for i in clean)) < 4 * TIGHT
+    assert np.abs(frc.cpu().numpy() - sum(want[i][1] for i in clean)).max() < 4 * TIGHT
+
+
+def test_a_captured_graph_leaves_the_mode(gpu_required, systems, five):
+    """A replayed evaluation would never change its parity: a stream capture switches the context back to six launches for
+    good, and the replayed numbers are right."""
+    torch = pytest.importorskip("torch")
+    s = systems("trpcage")
+    k = _kernel(s)
+    oracle = Oracle(*s.params(), version=1)
+    f0 = np.zeros((s.n, 3))
+    for step in range(3):
+        k.execute(s.jittered(step), f0)
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(s.pos, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        frc.zero_()
+        ene.zero_()
+        k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for step in (5, 6, 7):
+        geom = s.jittered(step)
+        pos.copy_(torch.tensor(geom, dtype=torch.float64))
+        g.replay()
+        torch.cuda.synchronize()
+        eo, fo = oracle.execute(geom)
+        assert abs(ene.item() - eo) < TIGHT and np.abs(frc.cpu().numpy() - fo).max() < TIGHT
+    assert k.finish(torch.cuda.current_stream().cuda_stream) == 0

@@ -22,6 +22,14 @@ TIGHT = 1e-7  # what FP64 on both sides actually delivers, with margin
 GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_vectors.npz"))
 
 
+@pytest.fixture()
+def six_launches(monkeypatch):
+    """The six-launch path (k_prep in front of every evaluation).  Tests of the overflow log that make the geometry JUMP (a
+    squeezed protein in the middle of a queue) count on it: in the default five-launch mode a jump beyond the neighbour
+    masks' skin voids an evaluation of its own (tests/test_gpu_five_launches.py holds that mode's version of these tests)."""
+    monkeypatch.setenv("AGBNP_HIP_FIVE_LAUNCHES", "0")
+
+
 def gpu_eval(system, version, pos=None, method=P.AGBNPForce.NoCutoff, cutoff=1.0):
     force = P.AGBNPForce.from_arrays(*system.params(), version=version)
     force.setNonbondedMethod(method)
@@ -540,7 +548,7 @@ def test_evaluation_is_graph_capturable(gpu_required, systems):
 
 
 @pytest.mark.parametrize("base_scale,bad_scale,variant_changes", [(1.3, 1.0, False), (1.0, 0.85, True)])
-def test_queued_evaluations_withhold_an_overflowed_one(gpu_required, systems, monkeypatch, base_scale, bad_scale, variant_changes):
+def test_queued_evaluations_withhold_an_overflowed_one(gpu_required, systems, monkeypatch, base_scale, bad_scale, variant_changes, six_launches):
     """Several evaluations are queued on a stream before agbnp_hip_finish; the middle one overflows.
     (1.3, 1.0): the packing is planned on a swollen molecule (largest subtree 58 nodes) and told not to spread the
     forests over the idle workgroups (tuning knob, read when the context is created): eight subtrees per forest; the
@@ -1240,7 +1248,7 @@ def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
     assert int(k.scalar("forests")) <= packed + 8  # back at the original packing density
 
 
-def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
+def test_poll_reports_the_log_without_synchronising(gpu_required, systems, six_launches):
     """agbnp_hip_poll reads pinned host memory that the device writes at the end of every evaluation: evaluations completed
     since the last finish() and how many of them were withheld -- the same numbers finish() then returns."""
     torch = pytest.importorskip("torch")
@@ -1263,7 +1271,7 @@ def test_poll_reports_the_log_without_synchronising(gpu_required, systems):
     assert k.poll() == (0, 0)
 
 
-def test_host_entry_short_cut_keeps_the_log_of_the_device_entry_points(gpu_required, systems):
+def test_host_entry_short_cut_keeps_the_log_of_the_device_entry_points(gpu_required, systems, six_launches):
     """agbnp_hip_execute_host skips the reads of the device for an evaluation that the pinned status words call complete and
     leaves the overflow log running; none of that may show through the device-resident protocol: poll / wait_verdict do not
     count the host path's evaluations, diagnostics asked for afterwards are those of the last evaluation, the indices that
