@@ -365,7 +365,10 @@ __device__ __forceinline__ void outputs_role(const TreeArgs& A, int blk, int bs)
 // Replay of a stored forest with vdW radii: reference steps K+L (ReferenceAGBNPKernels.cpp:718-747),
 // nu_i = (W_i+U_i)/V_i formed on the fly from the chain-rule sums, gradient only.  The reference does two passes
 // (W then U); the pass is linear in nu, so one pass with the sum gives the same gradient.
-template <int NCAP, int ACAP, int BS, bool GLOBAL>
+// PIPE: the instantiation whose replay of QUEUED forests is pipelined (round 4); it keeps the next forest's registers live
+// across the volume pass and spills one at the 128-register bound.  Launches whose forests fit one round (TreeOutputs::enabled:
+// the engine's own rule for fusing the forces) take the lean one; either handles any number of forests.
+template <int NCAP, int ACAP, int BS, bool GLOBAL, bool PIPE = true>
 __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseudo(TreeArgs A) {
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
   const int nforests = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
   // The workgroup's own work slot needs no test: k_tree_cavity leaves "nothing to replay" in the header of an idle slot,
   // so the forest's topology is requested straight away.
-  constexpr bool kPipelined = !GLOBAL && NCAP <= 8 * BS && ACAP <= BS && TreeStore<NCAP, ACAP>::kPairGather;
+  constexpr bool kPipelined = PIPE && !GLOBAL && NCAP <= 8 * BS && ACAP <= BS && TreeStore<NCAP, ACAP>::kPairGather;
   if constexpr (kPipelined) {
     // Round 4: the replay of QUEUED forests is pipelined (systems with more forests than resident workgroups: the 16.6 k-atom
     // lattice replays ~4 forests per workgroup).  A forest's two dependent trips to memory -- stored topology, then the
@@ -770,8 +773,12 @@ hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const Tre
   A.out.forest_blocks = variant <= 3 ? slots : (global_grid < A.nh ? global_grid : A.nh);
   const int grid = A.out.forest_blocks + (A.out.enabled ? (A.out.n + kBS - 1) / kBS : 0);
   switch (variant) {
-    case 0: return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
-    case 1: return launch_tree(k_tree_pseudo<512, 64, kBS, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
+    case 0:
+      if (A.out.enabled) return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
+      return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
+    case 1:
+      if (A.out.enabled) return launch_tree(k_tree_pseudo<512, 64, kBS, false, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
+      return launch_tree(k_tree_pseudo<512, 64, kBS, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
     case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);
     case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, grid, TreeStore<2048, 256>::kReplayBytes, A, st);
     default: return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, grid, 0, A, st);
