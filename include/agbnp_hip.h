@@ -78,10 +78,11 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * after the other -- may have been built from masks that no longer cover it.  It is then WITHHELD exactly like an
  * evaluation that overflowed (nothing added, logged, scalar 15 reports kind 16), the device has already renewed the masks
  * at its positions, and the repeat is right: agbnp_hip_execute_host() repeats by itself, the other entry points' callers
- * through the protocol they already have.  MD steps are two orders of magnitude below the threshold.  The mode ends for
- * good, silently, where it cannot hold: a stream that is being captured (a replayed evaluation could not alternate
- * between the two sets of accumulators the mode works with), agbnp_hip_execute_openmm(), the diagnostic self volumes,
- * the deterministic / single-precision modes, a capacity variant beyond 1.  Scalar 16 says which path runs (5 or 6).
+ * through the protocol they already have.  MD steps are two orders of magnitude below the threshold.  Captured graphs
+ * keep the mode: from a context's first stream capture on, the device itself names the set of accumulators an evaluation
+ * works on, so a replayed evaluation alternates like eager ones do (agbnp_hip_generation() changes once, at that capture).
+ * The mode ends for good, silently, where it cannot hold: agbnp_hip_execute_openmm(), the diagnostic self volumes, the
+ * deterministic / single-precision modes, a capacity variant beyond 1.  Scalar 16 says which path runs (5 or 6).
  *
  * Overflow contract.  The overlap-tree stage works in fixed-capacity LDS stores; an evaluation whose trees
  * outgrow them (or whose forest packing mispredicted) is INCOMPLETE.  Such an evaluation adds NOTHING to

@@ -106,10 +106,12 @@ struct agbnp_hip_context {
   //      its own) when an evaluation has found a heavy atom more than half of it from where it was (that evaluation is void)
   bool five = false;           // asked for
   bool five_active = false;    // ... and in effect (switched off for good by a larger capacity variant, the OpenMM entry point, a stream capture)
-  int parity = 0;              // of the evaluation last enqueued
+  int parity = 0;              // of the evaluation whose results the device holds (read back at every harvest)
+  int five_evals = 0;          // evaluations enqueued in the mode so far: evaluation k works on set k & 1
+  bool five_device = false;    // the device names the set (from the context's first stream capture on: see PairArgs::five)
   bool masks_valid = false;
   double mask_skin = 0.08;     // nm; AGBNP_HIP_MASK_SKIN (0.06 and 0.08 cost the cavity launch the same; 0.04 renews the masks at every other evaluation of the headline's jitter)
-  DevBuf<int> d_estatus, d_row_atoms;
+  DevBuf<int> d_estatus, d_row_atoms, d_epoch;  // d_epoch[0]: evaluations the device has been through in that mode (its parity names the set)
   DevBuf<double> d_mask_ref;
   double* htable(int p) const { return d_heavy.p + (size_t)p * kHvRows * hstride; }
   double* hrow(int r) const { return htable(five_active ? parity : 0) + (size_t)r * hstride; }
@@ -181,6 +183,7 @@ struct agbnp_hip_context {
     int status[kStatTotalWords];
     double components[4];
     int rows[4], pack[4];
+    int five[36];  // five-launch mode: the two blocks of per-evaluation status words, then the device's evaluation counter
   };
   HostReport* h_report = nullptr;
   double* h_xfer = nullptr;
@@ -344,37 +347,48 @@ int ensure_scratch(agbnp_hip_context* c) {
   return AGBNP_HIP_OK;
 }
 
-// Which of the two sets of {heavy-atom table, subtree shapes, per-evaluation status words} the launches of the next evaluation
-// use (five-launch mode: the evaluation's parity; otherwise set 0 and the one status array), and which one its trailing
-// workgroups clear for the evaluation after it.
+// The members of the argument blocks that name one of the two sets of {heavy-atom table, subtree shapes, per-evaluation status
+// words}.  Five-launch mode, eager (five == 1): the set of the evaluation about to be enqueued, five_evals & 1 -- the host
+// counts.  From a context's first stream capture on (five == 2): set 0, and every kernel moves them to the set the DEVICE's
+// count names (PairArgs::epoch, rebase_for_parity in pair_kernels.h).  The device counts in either form, so the two agree.
 void apply_parity(agbnp_hip_context* c) {
   PairArgs& P = c->P;
   TreeArgs& T = c->T;
   const bool five = c->five_active;
-  const int p = five ? c->parity : 0;
+  const int p = (five && !c->five_device) ? (c->five_evals & 1) : 0;
   const size_t nhp = (size_t)std::max(c->nh, 1);
-  P.inv_vol_h = c->hrow(kHvInvVol);
-  P.gam_cav = c->hrow(kHvGam);
-  P.a_large = c->hrow(kHvALarge);
-  P.v_large = c->hrow(kHvVLarge);
-  P.hx = c->hrow(kHvX);
-  P.hy = c->hrow(kHvY);
-  P.hz = c->hrow(kHvZ);
-  P.gx = c->hrow(kHvGx);
-  P.gy = c->hrow(kHvGy);
-  P.gz = c->hrow(kHvGz);
-  P.sv_vdw = c->hrow(kHvSvVdw);
-  P.sv_large = c->hrow(kHvSvLarge);
+  auto row = [&](int r) { return c->htable(p) + (size_t)r * c->hstride; };
+  P.inv_vol_h = row(kHvInvVol);  // (static rows: the same in both tables)
+  P.gam_cav = row(kHvGam);
+  P.a_large = row(kHvALarge);
+  P.v_large = row(kHvVLarge);
+  P.hx = row(kHvX);
+  P.hy = row(kHvY);
+  P.hz = row(kHvZ);
+  P.gx = row(kHvGx);
+  P.gy = row(kHvGy);
+  P.gz = row(kHvGz);
+  P.sv_vdw = row(kHvSvVdw);
+  P.sv_large = row(kHvSvLarge);
   T.hv = c->htable(p);
   P.sizes = c->d_sizes.p + (size_t)p * nhp;
   T.sizes = P.sizes;
   P.estatus = five ? c->d_estatus.p + 16 * p : c->d_status.p;
   T.status = P.estatus;  // (the tree kernels only touch words of their own evaluation)
-  P.five = five ? 1 : 0;
+  P.five = T.five = five ? (c->five_device ? 2 : 1) : 0;
+  // the counter exists twice, each copy beside what its readers read first (a cold scalar load of its own costs a launch
+  // 0.1-0.3 us): the pair launches' in the neighbour rows' flag line, the tree launches' behind the forest counts; the
+  // bookkeeping role advances both
+  P.epoch = c->d_nl_flag.p ? c->d_nl_flag.p + 3 : c->d_epoch.p;
+  P.epoch_tree = c->d_forest.p + (size_t)c->slot_cap + 9;
+  T.epoch = P.epoch_tree;
+  P.table_doubles = T.table_doubles = (size_t)kHvRows * c->hstride;
+  P.sizes_stride = T.sizes_stride = nhp;
   P.hstride = (unsigned)c->hstride;
-  P.next_hv = five ? c->htable(1 - p) : nullptr;
-  P.next_sizes = five ? c->d_sizes.p + (size_t)(1 - p) * nhp : nullptr;
-  P.next_estatus = five ? c->d_estatus.p + 16 * (1 - p) : nullptr;
+  // (five == 1: the host names the set the trailing workgroups clear, too; five == 2: rebase_for_parity does)
+  P.next_hv = (five && !c->five_device) ? c->htable(1 - p) : nullptr;
+  P.next_sizes = (five && !c->five_device) ? c->d_sizes.p + (size_t)(1 - p) * nhp : nullptr;
+  P.next_estatus = (five && !c->five_device) ? c->d_estatus.p + 16 * (1 - p) : nullptr;
   P.mask_ref = c->d_mask_ref.p;
   P.mask_move2 = 0.25 * c->mask_skin * c->mask_skin;
   P.row_atoms = five ? c->d_row_atoms.p : nullptr;
@@ -821,6 +835,7 @@ int allocate_work(agbnp_hip_context* c) {
     HIP_TRY(c, c->d_estatus.alloc(2 * 16));
     HIP_TRY(c, hipMemset(c->d_estatus.p, 0, sizeof(int) * 2 * 16));  // (fast mode + single keep their own Born rows: no mask tiles there, see five_active)
     static_assert(kStatEvalWords <= 16, "a parity's block of per-evaluation status words");
+    HIP_TRY(c, c->d_epoch.upload(std::vector<int>(4, 0)));
     HIP_TRY(c, c->d_mask_ref.upload(std::vector<double>(3 * nhp, std::nan(""))));
     HIP_TRY(c, c->d_row_atoms.alloc((size_t)kMaxItems * nslots));
     HIP_TRY(c, hipMemset(c->d_row_atoms.p, 0, sizeof(int) * kMaxItems * nslots));
@@ -869,12 +884,10 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   if (c->five_active) {
     // the mode ends for good where it cannot hold: a store beyond variant 1, positions that are not the caller's FP64 [3n]
-    // array, a stream that is being captured (a replayed evaluation would never change its parity)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    // (... or pair stages other than the FP64 row form: the renewal of the neighbour masks rides in the Born rows' launch)
-    // (... or the diagnostic pass-1 self volumes: a kernel instantiation of the six-launch path only)
-    if (c->variant > 1 || c->P.in.posq != nullptr || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics ||
-        (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)) {
+    // array, pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
+    // diagnostic pass-1 self volumes (a kernel instantiation of the six-launch path only).  (A stream capture is fine: the
+    // evaluation's parity lives on the device.)
+    if (c->variant > 1 || c->P.in.posq != nullptr || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
       c->five_active = false;
       c->parity = 0;
       apply_parity(c);
@@ -885,8 +898,15 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   // fewer if there cannot be that many forests
   const int tree_grid = std::max(1, std::min(c->slot_cap, c->tree_slots[c->variant]));
   if (c->five_active) {
-    c->parity ^= 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!c->five_device && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      // a replayed graph freezes its kernel arguments: from here on the kernels take the evaluation's set from the device's own
+      // count (which has kept step with the host's so far), for good -- the host cannot count replays
+      c->five_device = true;
+      c->generation++;
+    }
     apply_parity(c);
+    c->five_evals++;
     c->T.pos = d_pos;
     c->T.out.h2a = c->d_h2a.p;  // (the forest workgroups find a candidate's atom through it)
     if (!c->masks_valid) {  // a fresh context, or the evaluation before this one found its masks stale: lay them down anew
@@ -984,6 +1004,8 @@ int upload_identity_packing(agbnp_hip_context* c) {
     forest.push_back(0);  // [slots+6] packings planned so far (diagnostic: bench.py counts the plans inside a timed region)
     forest.push_back(0);  // [slots+7] total nodes and
     forest.push_back(0);  // [slots+8] largest subtree of the evaluation the packing in use was planned from (drift trigger)
+    forest.push_back(0);  // [slots+9] five-launch mode: the tree launches' copy of the device's evaluation counter (beside the
+                          // forest count they read first: the same cache line, no cold round trip of its own)
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
@@ -999,8 +1021,9 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   if (c->h_report) {
     agbnp_hip_context::HostReport* r = c->h_report;
     HIP_TRY(c, hipMemcpyAsync(r->status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost, st));
-    if (c->five_active)  // (the words of ONE evaluation live in its parity's block)
-      HIP_TRY(c, hipMemcpyAsync(r->status, c->d_estatus.p + 16 * c->parity, sizeof(int) * kStatEvalWords, hipMemcpyDeviceToHost, st));
+    if (c->five_active)  // (the words of ONE evaluation live in its parity's block: both blocks come along, the counter says which)
+      HIP_TRY(c, hipMemcpyAsync(r->five, c->d_estatus.p, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
+    if (c->five_active) HIP_TRY(c, hipMemcpyAsync(r->five + 32, c->P.epoch_tree, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(r->components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
     if (c->rows_capable) HIP_TRY(c, hipMemcpyAsync(r->rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(r->pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -1021,12 +1044,23 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   tl.used = 0;
   if (c->h_report) {
     std::memcpy(c->last_status, c->h_report->status, sizeof(int) * kStatTotalWords);
+    if (c->five_active) {
+      // (device count: the last evaluation took epoch & 1 BEFORE its bookkeeping role advanced the counter; the host's count is one ahead as well)
+      c->parity = c->five_device ? (c->h_report->five[32] + 1) & 1 : (c->five_evals + 1) & 1;
+      std::memcpy(c->last_status, c->h_report->five + 16 * c->parity, sizeof(int) * kStatEvalWords);
+    }
     std::memcpy(c->last_components, c->h_report->components, sizeof(double) * 4);
     if (c->rows_capable) std::memcpy(c->last_rows, c->h_report->rows, sizeof(int) * 3);
     std::memcpy(c->last_pack, c->h_report->pack, sizeof(int) * 4);
   } else {
     HIP_TRY(c, hipMemcpy(c->last_status, c->d_status.p, sizeof(int) * kStatTotalWords, hipMemcpyDeviceToHost));
-    if (c->five_active) HIP_TRY(c, hipMemcpy(c->last_status, c->d_estatus.p + 16 * c->parity, sizeof(int) * kStatEvalWords, hipMemcpyDeviceToHost));
+    if (c->five_active) {
+      int five[33];
+      HIP_TRY(c, hipMemcpy(five, c->d_estatus.p, sizeof(int) * 32, hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(five + 32, c->P.epoch_tree, sizeof(int), hipMemcpyDeviceToHost));
+      c->parity = c->five_device ? (five[32] + 1) & 1 : (c->five_evals + 1) & 1;  // (either count is one ahead of the last evaluation)
+      std::memcpy(c->last_status, five + 16 * c->parity, sizeof(int) * kStatEvalWords);
+    }
     HIP_TRY(c, hipMemcpy(c->last_components, c->d_components.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
     if (c->rows_capable) HIP_TRY(c, hipMemcpy(c->last_rows, c->d_nl_flag.p, sizeof(int) * 3, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(c->last_pack, c->d_forest.p + c->slot_cap + 3, sizeof(int) * 4, hipMemcpyDeviceToHost));
@@ -1445,7 +1479,7 @@ int agbnp_hip_get_vector(agbnp_hip_context* c, int which, double* out) {
     case 4:
     case 5: {  // overlap-tree shape: nodes / local atoms of the subtree rooted at every heavy atom (0 for hydrogens)
       std::vector<int2> sz(std::max(nh, 1));
-      HIP_TRY(c, hipMemcpy(sz.data(), c->P.sizes, sizeof(int2) * std::max(nh, 1), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(sz.data(), c->d_sizes.p + (size_t)(c->five_active ? c->parity : 0) * std::max(nh, 1), sizeof(int2) * std::max(nh, 1), hipMemcpyDeviceToHost));
       for (int i = 0; i < n; i++) out[i] = 0.0;
       for (int h = 0; h < nh; h++) out[c->h2a[h]] = which == 4 ? sz[h].x : sz[h].y;
       return AGBNP_HIP_OK;
@@ -1605,7 +1639,7 @@ int agbnp_debug_get_packing(agbnp_hip_context* c, int* order, int order_cap, int
     for (int k = 0; k < rows[(size_t)kRowStride * s + kMaxItems] && run < order_cap; k++) order[run++] = rows[(size_t)kRowStride * s + k];
     forest_start[s + 1] = run;
   }
-  if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->P.sizes, sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
+  if (sizes) HIP_TRY(c, hipMemcpy(sizes, c->d_sizes.p + (size_t)(c->five_active ? c->parity : 0) * std::max(c->nh, 1), sizeof(int2) * std::max(c->nh, 1), hipMemcpyDeviceToHost));
   return AGBNP_HIP_OK;
 }
 // replaces the packing (same form) and (freeze != 0) stops the bookkeeping from planning new ones

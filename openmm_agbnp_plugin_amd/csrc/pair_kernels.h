@@ -107,9 +107,21 @@ struct PairArgs {
   // ---- five-launch mode (experimental, AGBNP_HIP_FIVE_LAUNCHES=1; engine.hip): no k_prep launch.  The tree accumulators, the
   //      subtree shapes and the per-evaluation status words exist TWICE and alternate with the evaluation's parity; the
   //      trailing workgroups of the cavity launch (prep_role.h) clear the other set for the next evaluation
-  int five;                // 1: that mode
-  double* next_hv;         // heavy-atom table of the other parity
-  unsigned hstride;        // its row stride
+  int five;                // 0: six launches.  1: that mode, the HOST names the evaluation's set (eager launches: the pointers of this
+                           // block are those of the set, the kernels take them as they are).  2: the DEVICE does (below)
+  // Evaluation k of a context works on set k & 1.  The device counts the evaluations too: `epoch`, advanced once per
+  // evaluation by the bookkeeping role (the first workgroup of the GB launch) in either form of the mode, so that host and
+  // device always agree.  five == 2 (every evaluation of a context from its first stream capture on: a replayed graph freezes
+  // its kernel arguments): the pointers of this block are those of set 0 and every kernel moves them itself
+  // (rebase_for_parity) -- the launches in front of the GB launch by epoch & 1, the launches behind it by (epoch + 1) & 1; the
+  // GB launch's own workgroups other than the role touch nothing that exists twice.  It costs each launch one more cold scalar
+  // load (+0.5-1 us per evaluation of 1dwc, A/B on one box), which is why eager contexts let the host do it.
+  int* epoch;              // (the pair launches' copy; the tree launches read epoch_tree: engine.hip, apply_parity)
+  int* epoch_tree;
+  size_t table_doubles;    // doubles from one heavy-atom table to the other
+  size_t sizes_stride;     // shapes from one array to the other
+  double* next_hv;         // (after rebase_for_parity) heavy-atom table of the other parity
+  unsigned hstride;        // row stride of a table
   int2* next_sizes;
   int* next_estatus;
   double mask_rcut2;       // squared reach of the neighbour masks: the conservative cutoff of the level-2 search (+ the skin, in that mode)
@@ -177,6 +189,22 @@ struct PairArgs {
   const double2 *pw_a, *pw_b;    // power-form spline coefficients {c0, c1}, {c2, c3} by [screened][screener][15 intervals]
   const double2 *pwt_a, *pwt_b;  // the same by [screener][screened][15]
 };
+// Five-launch mode: point the parity-dependent members of a kernel's own copy of the argument block at the evaluation's set.
+// after_role: 0 in the launches in front of the GB launch and in its bookkeeping role, 1 behind it.
+__device__ __forceinline__ void rebase_for_parity(PairArgs& P, int after_role) {
+  if (P.five != 2) return;
+  const int par = (P.epoch[0] + after_role) & 1;
+  const size_t toff = (size_t)par * P.table_doubles, noff = (size_t)(1 - par) * P.table_doubles;
+  P.next_hv = P.hx + noff;  // (hx is row 0 of set 0's table)
+  P.next_sizes = P.sizes + (size_t)(1 - par) * P.sizes_stride;
+  P.next_estatus = P.estatus + 16 * (1 - par);
+  P.hx += toff, P.hy += toff, P.hz += toff;
+  P.gx += toff, P.gy += toff, P.gz += toff;
+  P.sv_vdw += toff, P.sv_large += toff;
+  P.sizes += (size_t)par * P.sizes_stride;
+  P.estatus += 16 * par;
+}
+
 constexpr int kRowGroup = 4;    // row atoms that share a neighbour list (pair_kernels.hip, k_rows)
 constexpr int kRowSlice = 256, kRowWaves = 8;  // entries of the shortest slice of a list (what the launch grids are laid out for); waves per workgroup
 // The GB rows keep no table in LDS, so their workgroups can be small: the launch (fast mode, 1dwc: 2840 one-wave items) is

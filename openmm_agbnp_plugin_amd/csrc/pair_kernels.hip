@@ -246,9 +246,15 @@ __device__ __forceinline__ double block_sum_256(double v, double* red4) {
   return r;
 }
 
+// DEVPAR: the instantiation of the five-launch mode's device-side parity (PairArgs::five == 2; the host launches it instead)
+template <bool DEVPAR = false>
 __device__ void energy_role(const PairArgs& P, int version, double* __restrict__ energy_out, double* __restrict__ components,
                             char* scratch) {  // scratch: kRoleScratchBytes of LDS
   const int t = threadIdx.x;
+  // (five-launch mode: P is NOT rebased for this role -- the evaluation counter is asked for with the role's first loads and
+  // used where the status block is, at its end; a rebase at the kernel's head put a cold round trip in front of the sums and
+  // 0.3 us on the chain-rule launch)
+  const int epoch_now = DEVPAR ? P.epoch[0] : -1;  // (otherwise the host has named the set: the offset below is 0)
     double* red4 = reinterpret_cast<double*>(scratch);
       // strided partial sums with 8 independent loads in flight per thread (a dependent load per trip would
       // cost one HBM/L2 latency each); the per-thread order is fixed, so the result is reproducible
@@ -285,9 +291,10 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         // in k_outputs the forces -- and it is entered in the sticky log that agbnp_hip_finish reports, so that
         // queued or graph-replayed evaluations cannot lose an overflow to the next evaluation's k_prep.  This
         // role runs exactly once per evaluation, after the tree stage.
-        const int node = P.estatus[kStatNodeOverflow], atom = P.estatus[kStatAtomOverflow], pack = P.estatus[kStatPackOverflow];
-        const int rowo = P.estatus[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
-        const int order = P.estatus[kStatOrderStale];
+        const int* es = P.estatus + (DEVPAR ? 16 * ((epoch_now + 1) & 1) : 0);  // (behind the GB launch: the counter has moved on)
+        const int node = es[kStatNodeOverflow], atom = es[kStatAtomOverflow], pack = es[kStatPackOverflow];
+        const int rowo = es[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
+        const int order = es[kStatOrderStale];
         if ((node | atom | pack | rowo | order) == 0) {
           const double e = o0 + o1 + o2 + o3;
           if (P.omm.force_fixed == nullptr)
@@ -304,8 +311,8 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
           P.status[kStatStickyPack] |= pack;
           P.status[kStatStickyRow] |= rowo;
           P.status[kStatStickyOrder] |= order;
-          P.status[kStatStickySplit] = max(P.status[kStatStickySplit], P.estatus[kStatSplitWanted]);
-          const int fo = P.estatus[kStatForestOverflow];
+          P.status[kStatStickySplit] = max(P.status[kStatStickySplit], es[kStatSplitWanted]);
+          const int fo = es[kStatForestOverflow];
           P.status[kStatStickyForest] |= ((fo & 0xffff) ? 1 : 0) | ((fo >> 16) ? 2 : 0);
           if (seq >= 0 && seq < kStatBadBits) P.status[kStatBadBitmap + (seq >> 5)] |= 1 << (seq & 31);
         }
@@ -430,6 +437,14 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     return (unsigned)fminf(w, 2047.0f);
   };
   __syncthreads();
+  // Five-launch mode: this role is the one place where the device's evaluation counter advances (every thread of the
+  // workgroup has taken its parity from it by now -- rebase_for_parity at the kernel's head; no other workgroup of this
+  // launch reads it): the launches behind this one see the new value and count back by one, the next evaluation's first
+  // launches see it as it is.
+  if (P.five && t == 0) {
+    atomicAdd(P.epoch, 1);
+    atomicAdd(P.epoch_tree, 1);
+  }
   // the tree statistics of THIS evaluation: plain reads, no histogram yet (three evaluations in four, or fifteen in sixteen,
   // need nothing else of this role)
   int tot = 0, mx = 0, ma = 0;
@@ -1239,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__
   __shared__ int s_bmax[4];  // (kFar: the blocks' largest Born radii)
   if (blockIdx.x == 0) {
     PAIR_STAMP(1, 0);
+    rebase_for_parity(P, 0);
     packing_role<true>(P, s_area, (int)sizeof(StripSums));
     PAIR_STAMP(1, 3);
     return;
@@ -1695,19 +1711,25 @@ __global__ __launch_bounds__(256) void k_dborn_tiles(int n, int nhb, int ntj, in
 // loads unless the cavity launch of this evaluation found a heavy atom a quarter of the masks' skin (or more: then the
 // evaluation is void) from where it was when the masks were laid down; then they lay them down anew from this evaluation's
 // positions, for the next one: the masks heal on the device, whatever is queued behind.
-template <int KIND, bool SINGLE = false, bool MASKS = false>
+// DEVPAR: the evaluation's set of accumulators is named by the device's own count (PairArgs::five == 2, contexts that have
+// been captured into a graph); a launch of its own instantiation, so that eager launches carry no trace of it.
+template <int KIND, bool SINGLE = false, bool MASKS = false, bool DEVPAR = false>
 __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void k_rows(PairArgs P, double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
   extern __shared__ double2 s_dyn[];
 
   int blk = blockIdx.x;
   if (MASKS && KIND == kBornRows && blk >= role_bytes) {
     if (threadIdx.x >= 256) return;
+    if (DEVPAR) rebase_for_parity(P, 0);
     if (((P.estatus[kStatOrderStale] & 2) | P.estatus[kStatMaskAging]) == 0) return;
     return neighbor_tile(P, blk - role_bytes, true);
   }
+  // (five-launch mode: the Born rows read this evaluation's self volumes and write its status block -- rows_workgroup asks for
+  // the device's evaluation counter with its first loads and moves the two pointers when it first needs them: a rebase HERE
+  // would put one more cold scalar round trip in front of every workgroup's prologue, +0.6 us on the launch)
   if (KIND == kChainRows) {  // the chain-rule launch carries the two single-workgroup roles (see k_dborn_tiles): four waves each
     if (blk < 2 && threadIdx.x >= 256) return;
-    if (blk == 0) return energy_role(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
+    if (blk == 0) return energy_role<DEVPAR>(P, 1, energy_out, components, reinterpret_cast<char*>(s_dyn));
     if (blk == 1) return dealing_role(P, reinterpret_cast<char*>(s_dyn), role_bytes);
     blk -= 2;
   }
@@ -1716,6 +1738,7 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
       static_assert(kGbRowWaves >= 4, "the bookkeeping role is written for 256 lanes");
       if (threadIdx.x >= 256) return;
       PAIR_STAMP(1, 0);
+      rebase_for_parity(P, 0);
       packing_role<false>(P, reinterpret_cast<char*>(s_dyn), role_bytes);
       PAIR_STAMP(1, 3);
       return;
@@ -1723,7 +1746,7 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
     blk -= 1;
   }
   __shared__ int s_busy;
-  rows_workgroup<KIND, row_waves(KIND), SINGLE>(P, blk, s_dyn, &s_busy);
+  rows_workgroup<KIND, row_waves(KIND), SINGLE, MASKS && DEVPAR>(P, blk, s_dyn, &s_busy);
 }
 
 // ---- outputs: one launch, three concurrent roles ---------------------------------------------------------
@@ -1736,6 +1759,7 @@ __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double
   // version 0 has no pair stages to carry the two single-workgroup roles: they are the first two workgroups here
   extern __shared__ char s_role[];  // role_bytes when version != 1
   int blk = blockIdx.x;
+  rebase_for_parity(P, 1);  // (five-launch mode with an output launch of its own: behind the GB launch)
   if (version != 1) {
     if (blk == 0) return energy_role(P, version, energy_out, components, s_role);
     if (blk == 1) {  // both halves of the bookkeeping, one after the other
@@ -1841,6 +1865,9 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     AGBNP_MARK(kKBornRows);
     if (P.single)
       hipLaunchKernelGGL((k_rows<kBornRows, true>), dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
+    else if (P.five == 2)  // (five-launch mode, device-side parity: + the conditional mask tiles)
+      hipLaunchKernelGGL((k_rows<kBornRows, false, true, true>), dim3(born_blocks + build_blocks + P.nb_tiles), dim3(64 * kRowWaves), born_lds, st, P,
+                         (double*)nullptr, (double*)nullptr, born_blocks + build_blocks);
     else if (P.five)  // (five-launch mode: + the conditional mask tiles)
       hipLaunchKernelGGL((k_rows<kBornRows, false, true>), dim3(born_blocks + build_blocks + P.nb_tiles), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr,
                          (double*)nullptr, born_blocks + build_blocks);
@@ -1859,6 +1886,8 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     AGBNP_MARK(kKDbornRows);
     if (P.single)
       hipLaunchKernelGGL((k_rows<kChainRows, true>), dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
+    else if (P.five == 2)
+      hipLaunchKernelGGL((k_rows<kChainRows, false, false, true>), dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
     else
       hipLaunchKernelGGL(k_rows<kChainRows>, dim3(2 + chain_blocks), dim3(64 * kRowWaves), chain_lds, st, P, energy_out, components, (int)chain_lds);
     AGBNP_CHECK_LAUNCH();

@@ -221,11 +221,11 @@ __device__ __forceinline__ void append_items(const PairArgs& P, int sub, int ent
 // one wave builds list `sub` of kind KIND (the lists of the later launches are built in the Born launch: both see the same
 // positions, and an overflowing list is known before the energy is added up)
 template <int KIND>
-__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane, int stale) {
+__device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane, int stale, int* estatus) {  // estatus: the evaluation's status block
   const RowLists L = row_lists<KIND>(P);
   if (sub >= L.groups * L.parts) return;
   if (!stale) {  // the list stands; is all of it walked?  (the walk may have been set up for a shorter reach, or narrowed)
-    if (lane == 0 && L.count[sub] > L.cap) P.estatus[kStatRowOverflow] = 1;
+    if (lane == 0 && L.count[sub] > L.cap) estatus[kStatRowOverflow] = 1;
     return;
   }
   const int g = sub / L.parts, part = sub - g * L.parts;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
     // the length is stored UNtruncated (it may exceed the stride) and clamped where it bounds a walk: every later evaluation
     // queued before the host reacts sees count > cap above and is withheld too, not just the one that rebuilt the list
     L.count[sub] = cnt;
-    if (cnt > L.cap) P.estatus[kStatRowOverflow] = 1;
+    if (cnt > L.cap) estatus[kStatRowOverflow] = 1;
     // (GB rows: the first slice of a group's first list also publishes the per-atom results, neighbours or not)
     append_items<KIND>(P, sub, min(cnt, L.cap), KIND == kGbRows && part == 0);
   }
@@ -248,7 +248,9 @@ __device__ __forceinline__ void build_list(const PairArgs& P, int sub, int lane,
 // the reference's GPU platform computes them (AGBNPBornRadii.cl:181-430 is all-float): the table in LDS as one 16-byte
 // float4 {c0, c1, c2, c3} per entry (half the copy, one look-up per pair instead of two), distances from positions relative
 // to the group's first row atom, hardware rsqrt, the sums of a slice in FP32; everything that leaves a wave stays FP64.
-template <int KIND, int WAVES, bool SINGLE = false>
+// PARITY (five-launch mode, Born rows): the self volumes and the status block are those of the evaluation's set (pair_kernels.h,
+// rebase_for_parity); the counter that names it is loaded with the first loads and used where the two pointers are.
+template <int KIND, int WAVES, bool SINGLE = false, bool PARITY = false>
 __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, double2* s_dyn, int* s_busy_word) {
   static_assert(!SINGLE || KIND != kGbRows, "the GB rows choose their precision at run time (P.single)");
   constexpr int R = kRowGroup;
@@ -259,17 +261,19 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   const int NP = L.parts, stride = L.stride;
   const int nlists = L.groups * NP, lists_pad = (nlists + WAVES - 1) / WAVES * WAVES;
   const int stale = P.nl_flag[0];
+  const int epoch_now = PARITY ? P.epoch[0] : 0;  // (device-side parity, pair_kernels.h: in flight with the flags; else the host has moved the pointers)
   const int rs = row_slice_length(P);
   const int walk_blocks = lists_pad / WAVES * ((L.cap + kRowSlice - 1) / kRowSlice);  // (as the host lays the grid out)
+  auto flag_row_overflow = [&]() { P.estatus[(PARITY ? 16 * (epoch_now & 1) : 0) + kStatRowOverflow] = 1; };
   if (KIND == kBornRows && blk >= walk_blocks) {
     // The lists of the later launches are built here, in the Born launch, by workgroups that only look at the lists'
     // lengths in an evaluation whose lists are still good.
     const int sub = (blk - walk_blocks) * WAVES + wave;
     const int chain_lists = row_lists<kChainRows>(P).groups * kChainParts;
     if (sub < chain_lists)
-      build_list<kChainRows>(P, sub, lane, stale);
+      build_list<kChainRows>(P, sub, lane, stale, P.estatus + (PARITY ? 16 * (epoch_now & 1) : 0));
     else if (P.gb_rows)
-      build_list<kGbRows>(P, sub - chain_lists, lane, stale);
+      build_list<kGbRows>(P, sub - chain_lists, lane, stale, P.estatus + (PARITY ? 16 * (epoch_now & 1) : 0));
     return;
   }
   PAIR_STAMP((KIND == kChainRows ? 2 : KIND == kGbRows ? 1 : 0), 0);
@@ -367,7 +371,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     count = row_build(A, P.hperm, P.hperm_n, part, NP, static_cast<const double4*>(P.rec_h), P.nl_build2, P.nlh + (size_t)sub * stride, stride, lane);
     if (lane == 0 && slice == 0) {
       P.nlh_count[sub] = count;  // (untruncated, see build_list)
-      if (count > L.cap) P.estatus[kStatRowOverflow] = 1;
+      if (count > L.cap) flag_row_overflow();
       append_items<kBornRows>(P, sub, min(count, L.cap), false);
     }
     if (slice == 0 && part == 0 && lane < A.rows) {  // where the atoms were when the lists were built
@@ -379,7 +383,7 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the wave's own stores, read back by other lanes)
     e1 = list[min(first + lane, stride - 1)], e2 = list[min(first + 64 + lane, stride - 1)];
   }
-  if (KIND == kBornRows && active && slice == 0 && lane == 0 && !stale && listed_raw > L.cap) P.estatus[kStatRowOverflow] = 1;  // (not all of it is walked)
+  if (KIND == kBornRows && active && slice == 0 && lane == 0 && !stale && listed_raw > L.cap) flag_row_overflow();  // (not all of it is walked)
   const int todo = active ? max(0, min(count - first, rs)) : 0;  // entries of this slice
   const int nsteps = (todo + 63) >> 6;
   double acc[4 * R];
@@ -390,7 +394,8 @@ __device__ __forceinline__ void rows_workgroup(const PairArgs& P, int blk, doubl
   double beta_r[R];     // GB rows: beta of the row atoms (see bw_beta)
   if (KIND != kGbRows) {
     const double4* __restrict__ rec = KIND == kChainRows ? static_cast<const double4*>(P.aposq) : static_cast<const double4*>(P.rec_h);
-    const double* __restrict__ wsrc = KIND == kChainRows ? static_cast<const double*>(P.bw) : static_cast<const double*>(P.sv_vdw);
+    const double* __restrict__ wsrc = KIND == kChainRows ? static_cast<const double*>(P.bw)
+                                                          : static_cast<const double*>(P.sv_vdw) + (PARITY ? (size_t)(epoch_now & 1) * P.table_doubles : 0);
     // two steps ahead: the list entry; one step ahead: the neighbour's record and weight.  (Every load is unconditional, its
     // index clamped into the list's stride: a load under a condition makes the compiler wait for everything in flight.)
     double4 r1 = rec[e1 & 0xffffffu];

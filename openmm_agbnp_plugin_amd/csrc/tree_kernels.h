@@ -109,12 +109,26 @@ struct TreeArgs {
   // five-launch mode (engine.hip): the tree reads the caller's positions itself -- no k_prep has put them into the table
   const double* pos;           // [3n] the caller's positions
   const int* row_atoms;        // [kMaxItems * slots] atom of the root of item k of work slot s (beside `rows`)
+  // ... and works on the set of {heavy-atom table, subtree shapes, status block} that the parity of the device's evaluation
+  // counter names (PairArgs::epoch, pair_kernels.h); hv / sizes / status are those of set 0
+  int five;
+  const int* epoch;
+  size_t table_doubles, sizes_stride;
 
   __device__ __forceinline__ double& hvat(int row, int h) const { return hv[(unsigned)row * hstride + (unsigned)h]; }
   __device__ __forceinline__ const int* forest_start() const { return packing; }
   __device__ __forceinline__ const int* nforests() const { return packing + slot_cap + 1; }
   __device__ __forceinline__ int* cur_nforests() const { return const_cast<int*>(packing) + slot_cap + 2; }
 };
+
+// (see rebase_for_parity, pair_kernels.h)
+__device__ __forceinline__ void rebase_tree_for_parity(TreeArgs& A, int after_role) {
+  if (A.five != 2) return;
+  const int par = (A.epoch[0] + after_role) & 1;
+  A.hv += (size_t)par * A.table_doubles;
+  A.sizes += (size_t)par * A.sizes_stride;
+  A.status += 16 * par;
+}
 
 constexpr int kTreeBlock = 256;  // lanes per subtree workgroup (upper bound of the BS template parameter)
 // A workgroup builds a FOREST: up to kMaxRoots subtrees (of different heavy atoms) side by side in one store, level

@@ -303,12 +303,15 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
 // ones are -- do k_prep's per-atom work for the launches that follow (prep_role.h) and clear the other parity's tree
 // accumulators, subtree shapes and status words for the NEXT evaluation.
 static_assert(kPrepHvGx == kHvGx && kPrepHvGx + 3 == kHvSvVdw && kPrepHvSvLarge == kHvSvLarge, "prep_role.h addresses the table's rows by number");
-template <int NCAP, int ACAP, int BS>
+// DEVPAR: the evaluation's set is named by the device's own count (contexts that have been captured into a graph: pair_kernels.h)
+template <int NCAP, int ACAP, int BS, bool DEVPAR = false>
 __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity_five(TreeArgs A, PairArgs P, int tree_blocks) {
   if ((int)blockIdx.x >= tree_blocks) {
     const int b = (int)blockIdx.x - tree_blocks;
+    if (DEVPAR) rebase_for_parity(P, 0);
     return prep_atoms(P, b * BS + (int)threadIdx.x, b == 0, true);
   }
+  if (DEVPAR) rebase_tree_for_parity(A, 0);
   cavity_forests<NCAP, ACAP, BS, false, false, true>(A, tree_blocks);
 }
 
@@ -368,8 +371,9 @@ __device__ __forceinline__ void outputs_role(const TreeArgs& A, int blk, int bs)
 // PIPE: the instantiation whose replay of QUEUED forests is pipelined (round 4); it keeps the next forest's registers live
 // across the volume pass and spills one at the 128-register bound.  Launches whose forests fit one round (TreeOutputs::enabled:
 // the engine's own rule for fusing the forces) take the lean one; either handles any number of forests.
-template <int NCAP, int ACAP, int BS, bool GLOBAL, bool PIPE = true>
+template <int NCAP, int ACAP, int BS, bool GLOBAL, bool PIPE = true, bool DEVPAR = false>
 __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseudo(TreeArgs A) {
+  if (DEVPAR) rebase_tree_for_parity(A, 1);  // (five-launch mode, device-side parity: the set of this evaluation; behind the GB launch, see pair_kernels.h)
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
   __shared__ int s_next;
@@ -756,12 +760,19 @@ hipError_t launch_tree_cavity_five(int variant, int slots, const TreeArgs& A, co
   if (A.nh <= 0 || variant > 1) return hipErrorInvalidValue;  // (the engine leaves the mode before it gets here)
   const int work = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
   const int prep_blocks = (work + kBS - 1) / kBS;
+  const bool dev = A.five == 2;
   if (variant == 0) {
     const size_t lds = TreeStore<AGBNP_SMALL_STORE>::kBytes;
-    hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    if (dev)
+      hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS, true>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    else
+      hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
   } else {
     const size_t lds = TreeStore<512, 64>::kBytes;
-    hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    if (dev)
+      hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS, true>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    else
+      hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
   }
   return hipGetLastError();
 }
@@ -774,9 +785,13 @@ hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const Tre
   const int grid = A.out.forest_blocks + (A.out.enabled ? (A.out.n + kBS - 1) / kBS : 0);
   switch (variant) {
     case 0:
+      if (A.five == 2 && A.out.enabled) return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false, false, true>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
+      if (A.five == 2) return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false, true, true>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
       if (A.out.enabled) return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
       return launch_tree(k_tree_pseudo<AGBNP_SMALL_STORE, kBS, false>, grid, TreeStore<AGBNP_SMALL_STORE>::kReplayBytes, A, st);
     case 1:
+      if (A.five == 2 && A.out.enabled) return launch_tree(k_tree_pseudo<512, 64, kBS, false, false, true>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
+      if (A.five == 2) return launch_tree(k_tree_pseudo<512, 64, kBS, false, true, true>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
       if (A.out.enabled) return launch_tree(k_tree_pseudo<512, 64, kBS, false, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
       return launch_tree(k_tree_pseudo<512, 64, kBS, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
     case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);

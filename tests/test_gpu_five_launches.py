@@ -118,9 +118,10 @@ def test_a_jump_voids_one_queued_evaluation_only(gpu_required, systems, five):
     assert np.abs(frc.cpu().numpy() - sum(want[i][1] for i in clean)).max() < 4 * TIGHT
 
 
-def test_a_captured_graph_leaves_the_mode(gpu_required, systems, five):
-    """A replayed evaluation would never change its parity: a stream capture switches the context back to six launches for
-    good, and the replayed numbers are right."""
+def test_a_captured_evaluation_replays_in_the_mode(gpu_required, systems, five):
+    """A captured graph replays the same kernel arguments every time; which of the two sets of accumulators an evaluation
+    works on is decided on the device (the parity of a counter that the bookkeeping role advances), so a ONE-evaluation graph
+    alternates like eager launches do -- also with eager evaluations between its replays."""
     torch = pytest.importorskip("torch")
     s = systems("trpcage")
     k = _kernel(s)
@@ -137,11 +138,17 @@ def test_a_captured_graph_leaves_the_mode(gpu_required, systems, five):
         frc.zero_()
         ene.zero_()
         k.execute_device(pos.data_ptr(), frc.data_ptr(), ene.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    for step in (5, 6, 7):
+    for step in (5, 6, 7, 8, 9):
         geom = s.jittered(step)
         pos.copy_(torch.tensor(geom, dtype=torch.float64))
         g.replay()
         torch.cuda.synchronize()
         eo, fo = oracle.execute(geom)
         assert abs(ene.item() - eo) < TIGHT and np.abs(frc.cpu().numpy() - fo).max() < TIGHT
+        if step in (6, 8):  # an eager evaluation between two replays (an odd number of them: the parities still alternate)
+            fe = np.zeros((s.n, 3))
+            ee = k.execute(s.jittered(20 + step), fe)
+            eo2, fo2 = oracle.execute(s.jittered(20 + step))
+            _close(ee, fe, eo2, fo2)
     assert k.finish(torch.cuda.current_stream().cuda_stream) == 0
+    assert int(k.scalar("launches")) == 5
