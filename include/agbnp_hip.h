@@ -81,6 +81,8 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * through the protocol they already have.  MD steps are two orders of magnitude below the threshold.  Captured graphs
  * keep the mode: from a context's first stream capture on, the device itself names the set of accumulators an evaluation
  * works on, so a replayed evaluation alternates like eager ones do (agbnp_hip_generation() changes once, at that capture).
+ * (Run one eager evaluation before the first capture, as for the capacity variant: a context that has never evaluated lays
+ * its first masks down with a launch of its own, and a graph that captured that launch repeats it at every replay.)
  * The mode ends for good, silently, where it cannot hold: agbnp_hip_execute_openmm(), the diagnostic self volumes, the
  * deterministic / single-precision modes, a capacity variant beyond 1.  Scalar 16 says which path runs (5 or 6).
  *
