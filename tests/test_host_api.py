@@ -188,3 +188,27 @@ def test_bench_instruction_table_tracks_the_counters():
             continue  # (a kernel that the profiled configuration does not launch)
         model = sum(steps[kernel][kind] * valu for kind, (valu, _) in kinds.items())
         assert abs(model / counters[kernel]["valu"] - 1.0) < 0.03, (kernel, model, counters[kernel]["valu"], source)
+
+
+def test_profiles_say_what_they_were_measured_on():
+    """the newest committed profile carries its own head (git + the library's build id = SHA-256 of the
+    engine's sources), bench.py repeats it in the line, and the summaries' kernel names are the engine's (a template argument
+    more or less does not split a kernel's rows)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    d = bench.newest_profile_dir()
+    assert d is not None and os.path.exists(os.path.join(d, "profile_head.json")), d
+    head = json.load(open(os.path.join(d, "profile_head.json")))
+    assert len(head["library_build_id"]) == 16 and head["git_head"]
+    rec = bench.profile_head()
+    assert rec["library_build_id"] == head["library_build_id"] and rec["profile"].startswith("profiles/r")
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic_pmc.json")))
+    assert traffic["profile_head"]["library_build_id"] == head["library_build_id"] and traffic["kernel"] == "k_tree_cavity"
+    import csv
+    kernels = {r["kernel"] for r in csv.DictReader(open(os.path.join(d, "pmc_utilization.csv")))}
+    assert {"k_tree_cavity", "k_gb_tiles", "k_rows<0>", "k_rows<1>", "k_tree_pseudo"} <= kernels, kernels
+    counters, source = bench.counter_valu_instructions("1dwc")
+    assert counters and {"k_gb_tiles", "k_born_rows", "k_dborn_rows"} <= set(counters) and os.path.basename(d) in source
