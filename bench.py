@@ -909,6 +909,10 @@ def worker(args):
         # the other evaluation modes on the headline workload (each has a line of its own with --mode; here for the record)
         result["other_modes"] = [dict(mode=m, **secondary_entry(dev, "1dwc", 1, 200, 20, 0, cutoff=1.0, mode=m))
                                  for m in ("fast", "fast+single", "deterministic")]
+        # the headline's own configuration with the preparation launch of rounds 1-4 (six launches), same box, same protocol:
+        # what the five-launch mode is worth in THIS run
+        result["other_modes"].append(dict(mode="reference, six launches (AGBNP_HIP_FIVE_LAUNCHES=0)",
+                                          **_with_env({"AGBNP_HIP_FIVE_LAUNCHES": "0"}, lambda: secondary_entry(dev, "1dwc", 1, 200, 20, 0))))
         result["concurrent_replicas_on_one_gpu"] = [concurrent_replicas_entry(dev, "1dwc", r, 200, 20) for r in (2, 4)]
         result["openmm_entry"] = openmm_entry(dev, "1dwc", 200, 20)
         result["md_loop"] = md_loop_entry(dev, "1dwc", 3000)
