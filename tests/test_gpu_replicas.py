@@ -89,3 +89,41 @@ def test_a_rank_that_dies_mid_pass_ends_the_job_and_frees_the_gpu(gpu_required):
     assert "injected failure" in p.stderr and "the job ends on every rank" in p.stderr
     assert len(pids) == 2 and all(_gone(pid) for pid in pids), pids
     assert took < 90, took
+
+
+def _errors(node, path="line"):
+    """Every {"error": ...} entry anywhere inside the line, with its path."""
+    found = []
+    if isinstance(node, dict):
+        if "error" in node:
+            found.append((path, node["error"]))
+        for k, v in node.items():
+            found += _errors(v, f"{path}.{k}")
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            found += _errors(v, f"{path}[{i}]")
+    return found
+
+
+def test_the_drivers_own_command_line_prints_a_complete_line(gpu_required):
+    """The driver's exact command -- `python3 bench.py --gpus 1 --steps 20 --warmup 5`, a fresh child process, every optional
+    record behind the headline included (BENCH_r05 died in one of them: no `-m gpu` test ran this command line): exit code 0,
+    ONE JSON line with `roofline` and `cpu_baseline`, BASELINE.json's configurations in `secondary`, and no record that
+    reports an error or was cut off by the watchdog."""
+    p, lines, pids, took = _bench({}, "--gpus", "1", "--steps", "20", "--warmup", "5", timeout=500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = lines[0]
+    assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 5 and r["unit"] == "ns/day"
+    assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["avg_launch_us"] > 0
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["ms_per_eval"] > 50
+    assert r["parity_on_sample"]["max_abs_dF_kJmolnm"] <= 1e-7
+    assert "optional_records_aborted" not in r and "roofline_error" not in r and "cpu_baseline_error" not in r
+    assert _errors(r) == [], _errors(r)
+    assert [s["workload"] for s in r["secondary"]] == ["trpcage", "trpcage", "1dwc_x4", "2clr"]
+    for s in r["secondary"]:
+        assert s["parity_on_sample"]["max_abs_dF_kJmolnm"] <= 1e-7, s
+    assert {"drift", "other_modes", "concurrent_replicas_on_one_gpu", "openmm_entry", "md_loop"} <= set(r)
+    assert "did not settle" not in p.stderr
+    assert all(_gone(pid) for pid in pids)
+    assert took < 240, took

@@ -149,7 +149,9 @@ def test_one_rank_withheld_makes_every_rank_repeat():
     results = _run_world({0: [], 1: [0, 0, 1]})
     assert [r[1] for r in results] == ["ok", "ok"], results
     assert [r[2] for r in results] == [2, 2], results  # equal try counts
-    assert results[0][3] == results[1][3] == 4         # settle, pre-heat, two timed tries: finish() read on every rank every time
+    # settle, pre-heat, the first timed try, the untimed recovery pass between two tries (Replica.recover: every rank runs it,
+    # the verdict was the job's), the second try: finish() read on every rank every time
+    assert results[0][3] == results[1][3] == 5
 
 
 def test_a_rank_that_never_settles_ends_the_job_on_every_rank():
@@ -261,3 +263,48 @@ def test_bench_main_under_torch_distributed_run():
     assert r["n_gpus"] == 2 and len(r["ranks"]) == 2 and r["distinct_devices"] == 2
     assert r["launcher"] == "torch.distributed.run" and r["collectives"] == "gloo"
     assert "roofline" in r and "cpu_baseline" in r
+
+
+# ---- the contract's line never depends on an optional record (BENCH_r05: a secondary that would not settle took the line with it) ----
+def test_an_optional_record_that_fails_becomes_an_error_entry_and_the_line_is_printed_once(capsys):
+    import json
+
+    import bench
+
+    line = bench.Line({"metric": "m", "value": 1.0, "secondary": []})
+
+    def never_settles():
+        raise bench.NotSettled("2clr", {"phase": "timed", "tries": 4, "history": [{"withheld": 1, "overflow_kinds": 36, "pack_level": 1, "forests": 2560,
+                                                                                  "variant": 0, "withheld_indices": [152], "try_number": 4}]})
+
+    entry = line.optional("secondary: 2clr", never_settles)
+    assert entry["error"].startswith("NotSettled: bench: tree capacity did not settle (2clr): timed try 4; last withheld 1 kinds 36 level 1 forests 2560")
+    assert entry["report"]["history"][0]["withheld_indices"] == [152]
+    line.append("secondary", dict(config="x", **entry))
+    assert line.optional("fine", lambda: {"ms_per_eval": 0.1}) == {"ms_per_eval": 0.1}
+    line.emit()
+    line.emit()  # (the watchdog and the `finally` may both get here: one line)
+    out, err = capsys.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["secondary"][0]["error"].startswith("NotSettled")
+    assert "record 'secondary: 2clr' failed and is reported inside the line" in err
+
+
+def test_bench_main_prints_the_line_when_the_optional_records_overrun_their_budget():
+    """The driver's one-GPU command shape on the CPU double: headline, roofline and cpu_baseline are in the line, the optional
+    records behind them get 0.2 s and are cut off by the watchdog -- exit code 0, one line, which says so."""
+    pytest.importorskip("torch")
+    import json
+    import subprocess
+
+    env = dict(os.environ, AGBNP_BENCH_BACKEND="gloo", AGBNP_BENCH_BACKEND_MODULE="tests.fake_bench_backend")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat-ms", "0",
+                        "--cpu-evals", "1", "--secondary-budget-s", "0.2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = lines[0]
+    assert r["n_gpus"] == 1 and "roofline" in r and "cpu_baseline" in r and r["config"]["workload"].startswith("1dwc")
+    assert r["optional_records_aborted"].startswith("watchdog") and "overran their budget" in p.stderr
