@@ -203,14 +203,16 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *          5 total tree nodes  6 kernel variant  7 max local atoms  8 work slots (forests) planned for the next evaluation
  *          9 1 if the range-limited pair stages run in row form (neighbour rows with a skin, rebuilt on the device when an
  *            atom has moved more than half the skin; Reference mode, version 1)  10 builds of those rows so far
- *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; every overflow of a packed forest
- *             adds one step of 15 %, clean plans in a row give one back)  12 evaluations since the packing was planned
+ *          11 forest packing: how far the assumed store capacity is tightened (0 = not at all; one step of 15 % when healed
+ *             forests keep coming or one could not be healed, given back after clean plans in a row -- more of them every time)  12 evaluations since the packing was planned
  *          13 entries per slice of a neighbour row (one wave of a row launch walks one slice; tuned on the device)
  *          15 why the last agbnp_hip_finish() withheld evaluations: 1 a subtree outgrew the store's nodes, 2 its local atoms,
  *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms,
  *             32 / 64 a forest of several work items outgrew its nodes / its local atoms (the two kinds of 4);
  *             bits 8.. the part count of a lone work item that asked for its subtree to be shared further
  *          16 kernel launches of a version-1 evaluation as the context runs now: 5 (five-launch mode) or 6
+ *          17 forests that outgrew their store and were healed inside the tree launch (built again in smaller sets: the
+ *             evaluation is complete, nothing is withheld for them) over the evaluations the last agbnp_hip_finish() covered
  *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation,
  *             default 16, or when the trees have drifted from the shapes it was planned for)
  * vectors (length N, atom order): 0 self volume (vdW radii)  1 Born radius  2 volume scaling factor

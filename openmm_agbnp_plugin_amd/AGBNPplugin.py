@@ -286,7 +286,7 @@ class HipCalcAGBNPForceKernel:
             raise OpenMMException(_lib.last_error(self._h))
 
     # ---- diagnostics (test support) -------------------------------------------------------------
-    SCALARS = dict(e_vol1=0, e_vol2=1, e_atom=2, e_gb_pair=3, max_subtree_nodes=4, total_nodes=5, variant=6, max_local_atoms=7, forests=8, rows_on=9, row_builds=10, pack_level=11, pack_age=12, row_slice=13, pack_plans=14, overflow_kinds=15, launches=16)
+    SCALARS = dict(e_vol1=0, e_vol2=1, e_atom=2, e_gb_pair=3, max_subtree_nodes=4, total_nodes=5, variant=6, max_local_atoms=7, forests=8, rows_on=9, row_builds=10, pack_level=11, pack_age=12, row_slice=13, pack_plans=14, overflow_kinds=15, launches=16, healed_forests=17)
     VECTORS = dict(selfvol_vdw=0, born=1, scale=2, selfvol_large=3, subtree_nodes=4, subtree_atoms=5)
 
     def scalar(self, name):

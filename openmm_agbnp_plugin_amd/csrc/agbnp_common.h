@@ -75,18 +75,23 @@ enum StatusWord {
                            // capacity the packing assumes is not tightened for it)
   kStatMaskAging = 13,     // five-launch mode: a heavy atom is more than a quarter of the neighbour masks' skin from where it was when
                            // they were laid down (the evaluation is good; the masks are laid down anew in its Born launch)
-  kStatEvalWords = 14,     // ---- everything below is sticky
-  kStatEvalSeq = 14,       // evaluations enqueued since the last agbnp_hip_finish
-  kStatBadCount = 15,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
-  kStatStickyNode = 16,    // OR of the per-evaluation overflow words over those evaluations
-  kStatStickyAtom = 17,
-  kStatStickyPack = 18,
-  kStatStickyRow = 19,
-  kStatStickyOrder = 20,   // (bit 1: five-launch mode, the neighbour masks had gone stale)
-  kStatStickySplit = 21,   // MAX of kStatSplitWanted over those evaluations
-  kStatStickyForest = 22,  // bit 0: a forest of several items outgrew its NODES, bit 1: its local ATOMS (diagnostic: scalar 15)
-  kStatWords = 23,
-  kStatBadBitmap = 23,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
+  kStatSpareForests = 14,  // forests that outgrew their store inside k_tree_cavity and were HEALED there: the workgroup built the forest's
+                           // work items again in smaller sets, the sets behind the first into spare work slots (numbered from
+                           // max(forests, forest workgroups of the launch) on; k_tree_pseudo replays them through its queue).  The
+                           // evaluation is complete; the packing's bookkeeping reads the word as "plan anew"
+  kStatEvalWords = 15,     // ---- everything below is sticky
+  kStatEvalSeq = 15,       // evaluations enqueued since the last agbnp_hip_finish
+  kStatBadCount = 16,      // ... of which this many overflowed: their forces and energy were WITHHELD from the caller
+  kStatStickyNode = 17,    // OR of the per-evaluation overflow words over those evaluations
+  kStatStickyAtom = 18,
+  kStatStickyPack = 19,
+  kStatStickyRow = 20,
+  kStatStickyOrder = 21,   // (bit 1: five-launch mode, the neighbour masks had gone stale)
+  kStatStickySplit = 22,   // MAX of kStatSplitWanted over those evaluations
+  kStatStickyForest = 23,  // bit 0: a forest of several items outgrew its NODES, bit 1: its local ATOMS (diagnostic: scalar 15)
+  kStatStickyHealed = 24,  // forests healed inside k_tree_cavity over those evaluations (diagnostic: scalar 17; nothing was withheld for them)
+  kStatWords = 25,
+  kStatBadBitmap = 25,     // bit k of the bitmap: evaluation k since the last finish was withheld (k < kStatBadBits)
   kStatBadBits = 2048,
   kStatTotalWords = kStatBadBitmap + kStatBadBits / 32
 };

@@ -166,9 +166,10 @@ struct agbnp_hip_context {
   unsigned generation = 1;     // bumped whenever kernel arguments a captured graph has frozen go stale
   int fallback_parts = 1;      // the packing an overflowed evaluation is repeated on: every subtree shared among this many work items, each
                                // alone in its slot (1, or 4 once a lone item has outgrown the store; never lowered)
+  bool heal = true;            // AGBNP_HIP_HEAL=0: a forest that outgrows its store voids the evaluation (rounds 2-5) instead of being built again in smaller sets
   bool split_fit = true;       // AGBNP_HIP_SPLIT_FIT=0: a lone subtree that outgrows the store moves the system to the next variant at once
   int tree_slots[5] = {1280, 1024, 512, 256, 256};  // resident tree workgroups per variant (CUs x workgroups per CU by LDS)
-  int slot_cap = 1024;  // work slots of the tree kernels: max(2 x subtrees, resident workgroups of the smallest variant)
+  int slot_cap = 1024;  // work slots of the tree kernels: 4 x subtrees + resident workgroups of the smallest variant
   double last_components[4] = {0, 0, 0, 0};
   std::vector<int> carried;     // withheld evaluations of execute_device harvested by an execute_host call in between (see there)
   int carried_count = 0, carried_seq = 0;
@@ -591,7 +592,10 @@ void wire_args(agbnp_hip_context* c) {
     P.split_permille = std::max(50, split_permille);
     c->split_fit = !(getenv("AGBNP_HIP_SPLIT_FIT") && atoi(getenv("AGBNP_HIP_SPLIT_FIT")) == 0) && c->slot_cap >= 4 * std::max(c->nh, 1);
     P.split_fit = c->split_fit ? 1 : 0;
-    T.split_fit = P.split_fit;
+    // (the tree launches' word: bit 0 the above, bit 1 = forests that outgrow their store are healed inside the launch -- round 6;
+    // AGBNP_HIP_HEAL=0: they void the evaluation as in rounds 2-5, for the tests of the withheld-evaluation protocol and A/B runs)
+    c->heal = !(getenv("AGBNP_HIP_HEAL") && atoi(getenv("AGBNP_HIP_HEAL")) == 0);
+    T.split_fit = P.split_fit | (c->heal ? 2 : 0);
     T.packing = c->d_forest.p;
     T.slot_cap = c->slot_cap;
   }
@@ -822,7 +826,9 @@ int allocate_work(agbnp_hip_context* c) {
     HIP_TRY(c, c->d_nbmask.alloc(std::max<size_t>(words, 64)));
     HIP_TRY(c, hipMemset(c->d_nbmask.p, 0, sizeof(unsigned long long) * std::max<size_t>(words, 64)));
   }
-  c->slot_cap = std::max(4 * std::max(nh, 1), c->tree_slots[0]);  // up to four work items per subtree (shared subtrees)
+  // up to four work items per subtree (shared subtrees), plus a launch's worth of slots: the spare slots that k_tree_cavity heals an
+  // overgrown forest into are numbered from max(forests, forest workgroups of the launch) on, and at most 4 nh sets exist in all
+  c->slot_cap = 4 * std::max(nh, 1) + c->tree_slots[0];
   const size_t nslots = (size_t)c->slot_cap;
   HIP_TRY(c, c->d_epart.alloc(2 * nslots));
   HIP_TRY(c, hipMemset(c->d_epart.p, 0, sizeof(double) * 2 * nslots));
@@ -1006,6 +1012,8 @@ int upload_identity_packing(agbnp_hip_context* c) {
     forest.push_back(0);  // [slots+8] largest subtree of the evaluation the packing in use was planned from (drift trigger)
     forest.push_back(0);  // [slots+9] five-launch mode: the tree launches' copy of the device's evaluation counter (beside the
                           // forest count they read first: the same cache line, no cold round trip of its own)
+    forest.push_back(0);  // [slots+10] the packing's `heat`: a leaky count of evaluations with healed forests (packing_role)
+    forest.push_back(0);  // [slots+11] ... and `need`: clean plans in a row before a tightened level is given back (its memory)
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));
@@ -1419,6 +1427,10 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     const int* s = c->last_status;
     *value = (s[kStatStickyNode] ? 1 : 0) | (s[kStatStickyAtom] ? 2 : 0) | (s[kStatStickyPack] ? 4 : 0) | (s[kStatStickyRow] ? 8 : 0) |
              (s[kStatStickyOrder] ? 16 : 0) | (s[kStatStickyForest] << 5) | (s[kStatStickySplit] << 8);  // (32 / 64: a forest's nodes / local atoms)
+    return AGBNP_HIP_OK;
+  }
+  if (which == 17) {  // forests healed inside the tree launch over the evaluations the last agbnp_hip_finish covered (none withheld for them)
+    *value = c->last_status[kStatStickyHealed];
     return AGBNP_HIP_OK;
   }
   if (!c->have_results) return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "no completed evaluation yet");

@@ -295,6 +295,7 @@ __device__ void energy_role(const PairArgs& P, int version, double* __restrict__
         const int node = es[kStatNodeOverflow], atom = es[kStatAtomOverflow], pack = es[kStatPackOverflow];
         const int rowo = es[kStatRowOverflow];  // (final before the chain-rule launch: every row is built in the Born launch)
         const int order = es[kStatOrderStale];
+        P.status[kStatStickyHealed] += es[kStatSpareForests];  // (forests healed inside k_tree_cavity: nothing withheld, a diagnostic)
         if ((node | atom | pack | rowo | order) == 0) {
           const double e = o0 + o1 + o2 + o3;
           if (P.omm.force_fixed == nullptr)
@@ -387,19 +388,30 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   for (int k = t; k < kBins; k += 256) comb[k] = 0ull;
   // every control word is asked for here, together, underneath the shapes (one cold round trip for all of them)
   const int st_node = P.estatus[kStatNodeOverflow], st_atom = P.estatus[kStatAtomOverflow], st_pack = P.estatus[kStatPackOverflow];
-  const int st_forest = P.estatus[kStatForestOverflow];
+  const int st_forest = P.estatus[kStatForestOverflow], st_spare = P.estatus[kStatSpareForests];
   const int ps_level = P.pack_state[0], age = P.pack_state[1], ps_clean = P.pack_state[2];
   const int tot_planned = P.pack_state[4], max_planned = P.pack_state[5];
+  const int ps_heat = P.pack_state[7], ps_need = P.pack_state[8];
   const bool overflow = (st_node | st_atom | st_pack) != 0;
-  // level: how often the assumed capacity has been tightened by 15 % (a FOREST outgrew its store: a misprediction of the
-  // packing; a lone item of a subtree that can still be shared is not one -- its subtree is shared among more items, the
-  // capacity assumed for everybody else stays).  It relaxes again: after kPackRelax plans in a row without a misprediction
-  // one step is given back, so a run with the occasional overflow does not drift to one subtree per slot for the life of
-  // the context.  Never beyond 6 (= packing off): whatever is queued behind a run of overflows, kPackRelax clean plans give
-  // a step back.
-  constexpr int kPackRelax = 4;  // (x the replan period of 16 evaluations = the 64 evaluations of round 4's 16 plans x 4)
-  const bool relax = st_pack == 0 && ps_level > 0 && ps_clean >= kPackRelax;
-  const int level = min(6, ps_level + (st_forest != 0 ? 1 : 0) - (relax ? 1 : 0));
+  // level: how often the assumed capacity has been tightened by 15 %.  Round 6: a forest that outgrows its store is HEALED
+  // inside k_tree_cavity (built again in smaller sets; kStatSpareForests counts them) and costs that one evaluation a few tens
+  // of microseconds -- a tightened level can cost EVERY evaluation a whole round of forests (2clr: one round at level 0, two at
+  // level 1: 139 -> 189 us).  So a healed forest only makes this role plan anew, from this evaluation's shapes, and adds to a
+  // leaky counter (`heat`: + 16 per evaluation with healed forests, - 1 per evaluation); the level goes up when the counter says
+  // that heals keep coming at more than about one evaluation in eight (128), or when a forest could NOT be healed (st_forest: no
+  // spare slot left).  The level has a MEMORY: the clean plans asked for before a step is given back (`need`, at least
+  // kPackRelax) double every time the level has to go up again (cap 64 plans = 1024 evaluations) and halve after four times
+  // that many clean plans in a row -- round 5 gave a step back after four plans whatever had happened before, and a packing
+  // that mispredicted was tried again, identically, 64 evaluations later.
+  constexpr int kPackRelax = 4;  // (x the replan period of 16 evaluations)
+  const int need = max(ps_need, kPackRelax);
+  int heat = max(ps_heat - 1, 0) + (st_spare != 0 ? 16 : 0);
+  const bool hot = heat >= 128;
+  if (hot) heat = 0;
+  const bool tighten = st_forest != 0 || hot;
+  const bool relax = st_pack == 0 && st_spare == 0 && !tighten && ps_level > 0 && ps_clean >= need;
+  const int level = min(6, ps_level + (tighten ? 1 : 0) - (relax ? 1 : 0));
+  const int need_next = tighten ? min(2 * need, 64) : (ps_clean >= 4 * need ? max(need / 2, kPackRelax) : need);
   const bool pack = P.pack_enabled && !overflow && level < 6;
   float share = 0.9f;
   for (int k = 0; k < level; k++) share *= 0.85f;
@@ -482,7 +494,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   // latency (a plan ends ~5 us after the GB launch's own work items on 1dwc) that small systems and version 0 (whose
   // k_outputs launch lasts as long as this role) cannot hide at all.
   const bool drifted = abs(tot_now - tot_planned) * 64 > tot_planned || max_now * 16 > max_planned * 17;
-  const bool plan = overflow || age + 1 >= P.replan_every || drifted;
+  const bool plan = overflow || age + 1 >= P.replan_every || drifted || st_spare != 0;  // (a healed forest: the shapes have left the plan behind)
   PAIR_STAMP(1, 7);
   if (t == 0) {
     P.estatus[kStatTotalNodes] = tot_now;
@@ -491,7 +503,9 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     P.pack_state[0] = level;
     // (after an overflow the fallback written below is no plan: the next clean evaluation plans anew)
     if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
-    if (plan) P.pack_state[2] = (st_forest != 0 || relax) ? 0 : ps_clean + 1;
+    if (plan) P.pack_state[2] = (tighten || relax || st_spare != 0) ? 0 : ps_clean + 1;
+    P.pack_state[7] = heat;
+    P.pack_state[8] = need_next;
     if (plan) P.pack_state[3] += 1;  // (plans so far: a diagnostic)
     if (plan && !overflow) P.pack_state[4] = tot_now, P.pack_state[5] = max_now;  // (the shapes this plan is made for)
     if (!plan) {

@@ -86,7 +86,8 @@ struct TreeArgs {
   double* hv;                  // [kHvRows][hstride]
   int want_sv_large;           // collect the enlarged-radius self volumes too (diagnostic: extra HBM atomics)
   int det;                     // deterministic mode: order-dependent sums only take quantized terms (device_math.h)
-  int split_fit;               // 1: a lone work item that outgrows the store asks for its subtree to be shared (kStatSplitWanted)
+  int split_fit;               // bit 0: a lone work item that outgrows the store asks for its subtree to be shared (kStatSplitWanted);
+                               // bit 1: a forest that outgrows its store is healed inside the launch (cavity_forests, tree_kernels.hip)
   const int* rows;             // [kRowStride * slots] work items: item k of work slot s at kRowStride * s + k, their number at + kMaxItems
   const int* packing;          // [slot_cap + 1] forest_start (bookkeeping's own),
                                // [slot_cap + 1] work slots in use (rewritten for the NEXT evaluation while this one's

@@ -109,6 +109,7 @@ constexpr int tree_waves_per_simd(int ncap, int bs) {
   return bs >= 256 ? (ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2)) : (ncap <= 192 ? 3 : 2);  // (one-wave workgroups: ~10 per CU for the small store)
 }
 
+constexpr int kPendCap = 16;  // work items that may wait while a forest that outgrew its store is built again in smaller sets
 // SV1: the launch also collects the self volumes of pass 1 (enlarged radii; a diagnostic: agbnp_hip_set_diagnostics)
 // FIVE: the five-launch mode's instantiation (k_tree_cavity_five below): positions straight from the caller's array.
 template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1, bool FIVE>
@@ -117,6 +118,11 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
   TreeStore<NCAP, ACAP> S;
   S.carve(GLOBAL ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : smem);
   __shared__ int s_next;  // hand-off word of the work queue (in LDS for every variant)
+  // healing (below): work items of the slot's row that wait for another set, their number, and the work slot the set in hand
+  // writes its topology to -- in LDS, not in registers: the build keeps ~190 scalar values live as it is
+  __shared__ int s_pend[kPendCap + 2];
+  int& s_npend = s_pend[kPendCap];
+  int& s_out = s_pend[kPendCap + 1];
   const int tid = threadIdx.x;
   // the row of the workgroup's own work slot is requested before anything is waited for (blockIdx.x < slot_cap: the
   // row exists whether or not the slot is in use)
@@ -131,9 +137,10 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
   }
 
   const bool queued = nforests > tree_blocks;  // otherwise every forest has a workgroup of its own
+  const int lane = tid & 63;
   for (int slot = blockIdx.x; slot < nforests;) {
-    int ticket = nforests;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
-    do {
+    constexpr int kNotAsked = 0x3fffffff;  // (a forest that fails before it asks ends the workgroup's run: the evaluation is void anyway)
+    int ticket = kNotAsked;  // lane 0: the queue is asked for the forest after this one ONCE per slot, however many sets it takes
     // the slot's row of work items (written in slot order by the bookkeeping of the previous evaluation: no
     // slot -> forest indirection in front of it): lanes 0..7 of every wave fetch one item each
     // (-1 = no item.  Counting the items with a ballot instead of reading the row's count word out of lane 8 makes
@@ -141,9 +148,19 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     int my_item = first_item, my_atom = first_atom;
     if (slot != (int)blockIdx.x) {  // (a forest from the queue)
       my_item = -1;
-      if ((tid & 63) < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + (tid & 63)];
-      if (FIVE && (tid & 63) < kMaxRoots) my_atom = A.row_atoms[(size_t)kMaxItems * slot + (tid & 63)];
+      if (lane < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + lane];
+      if (FIVE && lane < kMaxRoots) my_atom = A.row_atoms[(size_t)kMaxItems * slot + lane];
     }
+    // HEALING (round 6).  A forest that outgrows its store -- the packing was planned from an earlier geometry's shapes -- used
+    // to void the whole evaluation (kStatPackOverflow: withheld, repeated by the host on one subtree per slot, the packing
+    // tightened for everybody).  A failed build has touched nothing outside this workgroup's store, so the workgroup simply
+    // builds the row's items again in smaller SETS: the first half now, the items left over (s_pend) afterwards, each later set
+    // into a SPARE work slot (numbered from max(forests, forest workgroups of the launch) on: no workgroup of either tree launch
+    // has such a slot as its own; k_tree_pseudo reaches them through its queue).  Likewise a LONE item that outgrows the store
+    // while its subtree is whole or shared two ways is built again as the parts of a four-way share that cover it (part p of 2 =
+    // parts p and 3 - p of 4: level2_owner).  The evaluation stays complete; kStatSpareForests tells the bookkeeping to plan anew.
+    if (tid == 0) s_npend = 0, s_out = slot;  // (visible behind the barrier in front of the build)
+    for (;;) {        // the sets of the slot's row: ONE, unless a forest outgrew its store
     const int m = __popcll(__ballot(my_item >= 0));  // 1..kMaxRoots
     int items[kMaxRoots];
 #pragma unroll
@@ -173,13 +190,49 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     if (rc == kBuildOk && !volume_pass<NCAP, ACAP, BS, true, true>(S, tid, m, nnodes, natoms, want_sv1, &e_sum, &npairs, det))
       rc = kBuildNodeOverflow;  // the membership list does not fit: same protocol as a node overflow
     if (rc != kBuildOk) {
+      const int parts0 = work_item_parts(items[0]);
+      // ---- healed here if it can be (see above): a forest of several items in two halves, a lone splittable item as the
+      // parts of a four-way share
+      const bool refine = m == 1 && rc == kBuildNodeOverflow && (A.split_fit & 1) != 0 && parts0 <= 2;
+      const int more = (A.split_fit & 2) == 0 ? 0 : (m > 1 ? m - m / 2 : (refine ? 4 / parts0 - 1 : 0));  // items this set hands to s_pend
+      const int npend = s_npend;
+      if (more > 0 && npend + more <= kPendCap) {
+        tree_barrier<NCAP>();  // (everybody has read the count)
+        if (m > 1) {
+          // (the lane's item again from the store's root words, its root's atom again through h2a: nothing is kept alive
+          // across the build for this path)
+          const int keep = m / 2;
+          int mine = -1;
+          if (lane < m) {
+            const int pp = S.rt[kRtPart + lane];
+            mine = S.rt[kRtHeavy + lane] | ((pp & 0xff) << 24) | (((pp >> 8) - 1) << 26);
+          }
+          if (tid < 64 && lane >= keep && lane < m) s_pend[npend + lane - keep] = mine;
+          my_item = lane < keep ? mine : -1;
+          if (FIVE) my_atom = my_item >= 0 ? A.out.h2a[work_item_root(my_item)] : 0;
+        } else {
+          const int root = work_item_root(items[0]), p = work_item_part(items[0]);
+          auto part_of_four = [&](int q) { return root | (q << 24) | (3 << 26); };
+          if (tid == 0) {
+            if (parts0 == 1) {
+              s_pend[npend] = part_of_four(1), s_pend[npend + 1] = part_of_four(2), s_pend[npend + 2] = part_of_four(3);
+            } else {
+              s_pend[npend] = part_of_four(3 - p);
+            }
+          }
+          my_item = lane == 0 ? part_of_four(parts0 == 1 ? 0 : p) : -1;
+          if (FIVE) my_atom = lane == 0 ? A.out.h2a[root] : 0;
+        }
+        if (tid == 0) s_npend = npend + more;
+        continue;  // the same slot again, with the smaller set (the barrier in front of the build orders the list)
+      }
       if (tid == 0) {
         // a forest that does not fit is a packing misprediction (repeat unpacked), and so is a lone work item whose nodes
         // do not fit while its subtree can still be shared among more items (each expands a residue class of the level-2
         // branches; every item holds all level-2 atoms, so an ATOM overflow is not helped by sharing); a lone item of a
         // subtree that is shared four ways already needs the next capacity variant
-        const int parts0 = work_item_parts(items[0]);
-        const bool splittable = m == 1 && rc == kBuildNodeOverflow && parts0 < 4 && A.split_fit != 0;
+        // (round 6: what gets here is what could not be healed above: a three-way share, the waiting list full)
+        const bool splittable = m == 1 && rc == kBuildNodeOverflow && parts0 < 4 && (A.split_fit & 1) != 0;
         atomicAdd(&A.status[(m > 1 || splittable) ? kStatPackOverflow : (rc == kBuildNodeOverflow ? kStatNodeOverflow : kStatAtomOverflow)], 1);
         if (m > 1) atomicAdd(&A.status[kStatForestOverflow], rc == kBuildNodeOverflow ? 1 : 0x10000);  // (what tightens the packing's assumed capacity)
         if (splittable) {
@@ -190,22 +243,27 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
           // (its level-2 count is left at what the other items of the subtree report, or 0: the conservative side)
           atomicAdd(reinterpret_cast<int*>(&A.sizes[work_item_root(items[0])]), 4 * NCAP);
         }
-        A.hdr[slot].nnodes = 0;
-        A.hdr[slot].natoms = 0;
+        A.hdr[s_out].nnodes = 0;
+        A.hdr[s_out].natoms = 0;
       }
       tree_barrier<NCAP>();
-      break;  // on to the next forest
+      break;  // on to the next forest (the evaluation is void: what waits is dropped)
     }
     CSTAMP(1);
     // Take delivery of the prefetched vdW parameters HERE, while nothing else is in flight: the memory counter is in
     // order, so a wait placed after the topology stores below would also wait for every one of them.
     asm volatile("" ::"v"(a_vdw_mine), "v"(v_vdw_mine));
-    if (queued && tid == 0) ticket = atomicAdd(&A.status[kStatCavityQueue], 1);  // the forest AFTER this one
+    if (queued && tid == 0 && ticket == kNotAsked) ticket = atomicAdd(&A.status[kStatCavityQueue], 1);  // the forest AFTER this one
+    const int out = s_out;  // (== slot unless this is a later set of a healed row)
     if (tid == 0) {
       // level-1 nodes: volume V_i, coefficient +1 (gaussvol.cpp:138-141); once per subtree (its part 0)
       double e1 = e_sum;
       for (int q = 0; q < m; q++) e1 += (S.rt[kRtPart + q] & 0xff) == 0 ? quantize(S.at[5][q] * S.at[4][q], kQEnergy, det) : 0.0;
-      A.epart[2 * slot] = e1;
+      // (cavity energies are summed per work slot of the packing: a later set of a healed row adds to its slot's word)
+      if (out == slot)
+        A.epart[2 * slot] = e1;
+      else
+        A.epart[2 * slot] += e1;
     }
     if (want_sv1) {  // diagnostics: enlarged-radius self volumes
       for (int la = tid; la < natoms; la += BS) {
@@ -217,12 +275,12 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     // ---- topology out for the pseudo-volume pass: the atom paths (8 B/node), the membership list and the local
     // atom list are all a replay needs; fixed stride per work slot, no allocation traffic
     {
-      const size_t pool_off = (size_t)slot * NCAP, atom_off = (size_t)slot * ACAP;
+      const size_t pool_off = (size_t)out * NCAP, atom_off = (size_t)out * ACAP;
       const unsigned long long* path = reinterpret_cast<const unsigned long long*>(S.nd[6]);
       for (int n = m + tid; n < nnodes; n += BS) A.node_pool[pool_off + n] = path[n];
       for (int la = tid; la < natoms; la += BS) A.atom_pool[atom_off + la] = S.at_gidx[la];
       if (TreeStore<NCAP, ACAP>::kPairGather) {
-        const size_t pair_off = (size_t)slot * TreeStore<NCAP, ACAP>::PCAP;
+        const size_t pair_off = (size_t)out * TreeStore<NCAP, ACAP>::PCAP;
         for (int k = tid; k < npairs; k += BS) A.pair_pool[pair_off + k] = S.pairs[k];
       }
       if (tid == 0) {
@@ -232,7 +290,7 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
         h.nroots = m;
         h.npairs = npairs;
         for (int q = 0; q < kMaxRoots; q++) h.partners[q] = q < m ? S.rt[kRtCount + q] : 0;
-        A.hdr[slot] = h;
+        A.hdr[out] = h;
       }
       // per-subtree shape for the next evaluation's packing and the statistics (zeroed by k_prep; the work items
       // of a shared subtree add their own nodes, part 0 the root and the partner count)
@@ -282,12 +340,36 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     if (tid == 0) {
       double e2 = e_sum;
       for (int q = 0; q < m; q++) e2 += (S.rt[kRtPart + q] & 0xff) == 0 ? quantize(S.at[5][q] * S.at[4][q], kQEnergy, det) : 0.0;
-      A.epart[2 * slot + 1] = e2;
+      if (out == slot)
+        A.epart[2 * slot + 1] = e2;
+      else
+        A.epart[2 * slot + 1] += e2;
     }
     tree_barrier<NCAP>();
     CSTAMP(6);
     CSTAMP_FLUSH();
-    } while (false);
+    const int npend = s_npend;
+    if (npend == 0) break;
+    // ---- the next set of a healed row: the items that wait (at most kMaxRoots of them), into a spare work slot
+    {
+      if (tid == 0) s_next = atomicAdd(&A.status[kStatSpareForests], 1);
+      lds_barrier();
+      const int spare = max(nforests, tree_blocks) + s_next;
+      lds_barrier();
+      if (spare >= A.slot_cap) {  // no spare slot left (never seen: the pools hold four slots per subtree): the evaluation is void
+        if (tid == 0) {
+          atomicAdd(&A.status[kStatPackOverflow], 1);
+          atomicAdd(&A.status[kStatForestOverflow], 1);
+        }
+        break;
+      }
+      const int take = min(npend, kMaxRoots);
+      my_item = lane < take ? s_pend[npend - take + lane] : -1;
+      if (FIVE) my_atom = my_item >= 0 ? A.out.h2a[work_item_root(my_item)] : 0;
+      lds_barrier();  // (the list is read: the next set may add to it)
+      if (tid == 0) s_npend = npend - take, s_out = spare;
+    }
+    }
     if (!queued) break;
     slot = __builtin_amdgcn_readfirstlane(next_forest(tid, &s_next, ticket, tree_blocks));  // (wave-uniform by construction: keeps everything derived from it in scalar registers)
   }
@@ -386,7 +468,12 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_pseu
   const int block = (int)blockIdx.x - out_blocks;  // number of the forest workgroup
   S.carve_replay(GLOBAL ? (A.scratch + (size_t)block * A.scratch_stride) : smem);
   const bool write_forces = A.out.enabled != 0;
-  const int nforests = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
+  // forests to replay: those of the packing -- and, when k_tree_cavity healed a forest that had outgrown its store (it built the
+  // row's items in several sets), the sets it put into spare work slots, numbered from max(forests, forest workgroups) on: no
+  // workgroup's own slot, so the queue is what reaches them (a one-round launch turns into a queued one for that evaluation)
+  const int nspare = A.status[kStatSpareForests];
+  const int nplanned = A.cur_nforests()[0];  // (consumed when the first forest's loads are on their way)
+  const int nforests = nspare > 0 ? max(nplanned, grid) + nspare : nplanned;
   // The workgroup's own work slot needs no test: k_tree_cavity leaves "nothing to replay" in the header of an idle slot,
   // so the forest's topology is requested straight away.
   constexpr bool kPipelined = PIPE && !GLOBAL && NCAP <= 8 * BS && ACAP <= BS && TreeStore<NCAP, ACAP>::kPairGather;
@@ -681,8 +768,8 @@ constexpr int kGlobalAtomCap = 256;  // one byte per atom in the path words
 constexpr int kBS = AGBNP_TREE_BLOCK;  // lanes per subtree (compile-time knob, default kTreeBlock)
 static_assert(kBS <= kTreeBlock && kBS % 64 == 0, "tree block size");
 // LDS is handed out in granules of 1280 bytes on gfx950: five workgroups per CU need <= 25 granules each
-static_assert((TreeStore<432, 64>::kBytes + 16 + 1279) / 1280 * 5 <= 128, "five build workgroups per CU");
-static_assert((TreeStore<512, 64>::kBytes + 1279) / 1280 * 4 <= 128, "four build workgroups per CU");
+static_assert((TreeStore<432, 64>::kBytes + 16 + sizeof(int) * kPendCap + 1279) / 1280 * 5 <= 128, "five build workgroups per CU");
+static_assert((TreeStore<512, 64>::kBytes + 16 + sizeof(int) * kPendCap + 1279) / 1280 * 4 <= 128, "four build workgroups per CU");
 // Experimental build (-DAGBNP_TREE_BLOCK=64): one-wave workgroups, one subtree (or part of one) each, in a small store
 #if AGBNP_TREE_BLOCK == 64
 #define AGBNP_SMALL_STORE 192, 48
@@ -695,8 +782,8 @@ size_t tree_variant_lds_bytes(int variant);
 int tree_variant_node_cap(int variant);
 // workgroups of the build kernel that a CU holds: LDS granules of 1280 B (128 per CU), 32 waves, the register budget
 int tree_variant_wgs_per_cu(int variant) {
-  const size_t bytes = tree_variant_lds_bytes(variant) + 16;
-  if (bytes <= 16) return 1;
+  const size_t bytes = tree_variant_lds_bytes(variant) + 16 + sizeof(int) * kPendCap;  // (+ the kernels' static LDS)
+  if (tree_variant_lds_bytes(variant) == 0) return 1;
   const int by_lds = (int)(128 / ((bytes + 1279) / 1280));
   const int waves = kBS / 64;
   const int by_regs = 4 * tree_waves_per_simd(tree_variant_node_cap(variant), kBS) / waves;
