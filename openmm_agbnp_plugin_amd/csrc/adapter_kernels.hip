@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "adapter_kernels.h"
+#include "agbnp_common.h"
 
 namespace agbnp {
 
@@ -56,6 +57,19 @@ __global__ __launch_bounds__(256) void k_order_maps(int n, const int* __restrict
 
 hipError_t launch_order_maps(int n, const int* atom_index, const int* a2h, int* ctx_slot, int* hslot, hipStream_t st) {
   hipLaunchKernelGGL(k_order_maps, dim3((n + 255) / 256), dim3(256), 0, st, n, atom_index, a2h, ctx_slot, hslot);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_row_atoms(int nwords, const int* __restrict__ rows, const int* __restrict__ map, int* __restrict__ row_atoms) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;  // item k of work slot s: w = kMaxItems * s + k
+  if (w >= nwords) return;
+  const int item = rows[(size_t)kRowStride * (w / kMaxItems) + (w % kMaxItems)];
+  row_atoms[w] = item >= 0 ? map[item & 0xffffff] : 0;
+}
+
+hipError_t launch_row_atoms(int nslots, const int* rows, const int* map, int* row_atoms, hipStream_t st) {
+  const int nwords = nslots * kMaxItems;
+  hipLaunchKernelGGL(k_row_atoms, dim3((nwords + 255) / 256), dim3(256), 0, st, nwords, rows, map, row_atoms);
   return hipGetLastError();
 }
 

@@ -197,6 +197,8 @@ struct agbnp_hip_context {
   // caller repeats (AGBNP_HIP_ADAPTER_LAUNCH=1: the adapter launch of rounds 1-2 instead)
   DevBuf<int> d_hslot;
   bool order_valid = false;
+  int row_atoms_kind = 0;       // five-launch mode: what d_row_atoms holds for the packing in use -- 0 atom indices (the caller's
+                                // [3n] positions), 1 slots of an OpenMM context's order (posq), -1 stale (the context reordered)
   const int* order_ptr = nullptr;
   bool adapter_launch = false;
   int lazy_evals = 0;           // evaluations of execute_host since the log was last read and cleared: the FIRST entries of the
@@ -889,11 +891,10 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   c->P.tree_slots = c->tree_slots[c->variant];
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   if (c->five_active) {
-    // the mode ends for good where it cannot hold: a store beyond variant 1, positions that are not the caller's FP64 [3n]
-    // array, pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
+    // the mode ends for good where it cannot hold: a store beyond variant 1, pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
     // diagnostic pass-1 self volumes (a kernel instantiation of the six-launch path only).  (A stream capture is fine: the
     // evaluation's parity lives on the device.)
-    if (c->variant > 1 || c->P.in.posq != nullptr || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
+    if (c->variant > 1 || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
       c->five_active = false;
       c->parity = 0;
       apply_parity(c);
@@ -915,7 +916,20 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     c->five_evals++;
     c->T.pos = d_pos;
     c->T.out.h2a = c->d_h2a.p;  // (the forest workgroups find a candidate's atom through it)
-    if (!c->masks_valid) {  // a fresh context, or the evaluation before this one found its masks stale: lay them down anew
+    // ... or an OpenMM context's posq (agbnp_hip_execute_openmm, round 6): the POSQ instantiation of the cavity launch reads it at
+    // the context's slots; the words beside the rows must then hold SLOTS -- the dealing role writes them for the entry point of
+    // the evaluation it runs in, so they are rewritten here when this evaluation comes through the other one, or when the
+    // context's order has changed since (one small launch, never in a steady run)
+    const int want_kind = c->P.in.posq ? 1 : 0;
+    c->T.posq = c->P.in.posq;
+    c->T.posq_corr = c->P.in.correction;
+    c->T.posq_double = c->P.in.is_double;
+    c->T.hslot = c->P.in.hslot;
+    if (c->row_atoms_kind != want_kind) {
+      HIP_TRY(c, launch_row_atoms(c->slot_cap, c->d_rows.p, want_kind ? c->d_hslot.p : c->d_h2a.p, c->d_row_atoms.p, st));
+      c->row_atoms_kind = want_kind;
+    }
+    if (!c->masks_valid) {  // a fresh context, or an OpenMM context that has reordered its atoms (harvest): lay them down anew
       HIP_TRY(c, launch_masks(c->P, st, tl));
       c->masks_valid = true;
     }
@@ -990,6 +1004,7 @@ int upload_identity_packing(agbnp_hip_context* c) {
     std::vector<int> atoms((size_t)kMaxItems * nslots, 0);
     for (size_t k = 0; k < nslots && c->nh > 0; k++) atoms[(size_t)kMaxItems * k] = c->h2a[std::min(k, nhp - 1) / parts];
     HIP_TRY(c, c->d_row_atoms.upload(atoms));
+    c->row_atoms_kind = 0;
   }
   HIP_TRY(c, c->d_order.upload(std::vector<int>((size_t)kMaxItems * nslots + 8, 0)));  // (the bookkeeping's working copies)
   HIP_TRY(c, c->d_ftime.upload(std::vector<int>(nslots + 1, 0)));
@@ -1103,7 +1118,12 @@ int harvest(agbnp_hip_context* c, int* repeat, hipStream_t st) {
   int rc = upload_identity_packing(c);
   if (rc != AGBNP_HIP_OK) return rc;
   c->forests_hint = 0;  // (one work item per slot again: the old rule decides)
-  if (s[kStatStickyOrder] & 1) c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
+  if (s[kStatStickyOrder] & 1) {
+    c->order_valid = false;  // the context has reordered its atoms: the next agbnp_hip_execute_openmm rebuilds the maps
+    // (five-launch mode: the device has renewed the neighbour masks in that evaluation -- from positions read through the STALE
+    // maps, i.e. other atoms' positions: laid down anew by a launch of their own in front of the next evaluation)
+    c->masks_valid = false;
+  }
   // (bit 1, five-launch mode: a heavy atom had left the neighbour masks' skin.  The device has laid the masks down anew in
   // that very evaluation's Born launch: nothing for the host to do but repeat what was withheld)
   if (s[kStatStickyRow] && !c->rows_disabled) {
@@ -1301,6 +1321,7 @@ int agbnp_hip_execute_openmm(agbnp_hip_context* c, const void* d_posq, int posq_
   if (fused) {
     if (!c->order_valid || c->order_ptr != d_atom_index) {
       HIP_TRY(c, launch_order_maps(c->n, d_atom_index, c->d_a2h.p, c->d_ctx_slot.p, c->d_hslot.p, st));
+      if (c->row_atoms_kind == 1) c->row_atoms_kind = -1;  // (slots of the old order: enqueue rewrites them)
       c->order_valid = true;
       c->order_ptr = d_atom_index;
     }
@@ -1676,6 +1697,7 @@ int agbnp_debug_set_packing(agbnp_hip_context* c, const int* order, int norder, 
           if (item >= 0 && work_item_root(item) < c->nh) atoms[(size_t)kMaxItems * s + k] = c->h2a[work_item_root(item)];
         }
       HIP_TRY(c, hipMemcpy(c->d_row_atoms.p, atoms.data(), sizeof(int) * atoms.size(), hipMemcpyHostToDevice));
+      c->row_atoms_kind = 0;
     }
     HIP_TRY(c, hipMemcpy(c->d_forest.p + c->slot_cap + 1, &nforests, sizeof(int), hipMemcpyHostToDevice));
   }

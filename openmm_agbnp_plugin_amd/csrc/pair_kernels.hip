@@ -833,8 +833,11 @@ __device__ void dealing_role(const PairArgs& P, char* scratch, int scratch_bytes
       const int it[kMaxItems] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       int4 a0, a1;
       int at[kMaxItems];
+      // (an OpenMM context's posq: the root's SLOT in the context's order -- the next evaluation is taken to come through the same
+      // entry point; the host rewrites the words when it does not, engine.hip sync_row_atoms)
+      const int* __restrict__ where = P.in.posq ? P.in.hslot : P.h2a;
 #pragma unroll
-      for (int k = 0; k < kMaxItems; k++) at[k] = it[k] >= 0 ? P.h2a[it[k] & 0xffffff] : 0;
+      for (int k = 0; k < kMaxItems; k++) at[k] = it[k] >= 0 ? where[it[k] & 0xffffff] : 0;
       a0 = make_int4(at[0], at[1], at[2], at[3]), a1 = make_int4(at[4], at[5], at[6], at[7]);
       int4* da = reinterpret_cast<int4*>(P.row_atoms + (size_t)kMaxItems * slot);
       da[0] = a0, da[1] = a1;

@@ -123,7 +123,7 @@ __device__ __forceinline__ void prep_atoms(const PairArgs& P, int i, bool first_
     P.zero_out[3 * i + 2] = 0.0;
     if (i == 0) P.zero_out[3 * (size_t)P.n] = 0.0;
   }
-  if (P.in.posq && P.in.atom_index && P.in.atom_index[P.omm.ctx_slot[i]] != i) P.estatus[kStatOrderStale] = 1;  // (the context has reordered its atoms)
+  if (P.in.posq && P.in.atom_index && P.in.atom_index[P.omm.ctx_slot[i]] != i) atomicOr(&P.estatus[kStatOrderStale], 1);  // (the context has reordered its atoms)
   const Pos3 r_i = atom_position(P, i);
   const double x = r_i.x, y = r_i.y, z = r_i.z;
   const double inv_vol_i = P.rows_on ? P.inv_vol_a[i] : 0.0;  // (asked for with everything else: no load waits for the heavy index)

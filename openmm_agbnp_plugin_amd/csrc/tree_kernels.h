@@ -110,6 +110,13 @@ struct TreeArgs {
   // five-launch mode (engine.hip): the tree reads the caller's positions itself -- no k_prep has put them into the table
   const double* pos;           // [3n] the caller's positions
   const int* row_atoms;        // [kMaxItems * slots] atom of the root of item k of work slot s (beside `rows`)
+  // ... or an OpenMM context's posq (agbnp_hip_execute_openmm in the five-launch mode; the POSQ instantiations,
+  // OpenCLAGBNPKernels.cpp:541-556 for the conventions): positions by the context's SLOT -- row_atoms then holds the slot of
+  // every item's root (engine.hip keeps it so), a candidate's slot comes through hslot
+  const void* posq;            // [padded] double4, or float4 ...
+  const float4* posq_corr;     // ... + float4 correction (mixed precision), or null
+  int posq_double;
+  const int* hslot;            // [nh] heavy index -> context slot
   // ... and works on the set of {heavy-atom table, subtree shapes, status block} that the parity of the device's evaluation
   // counter names (PairArgs::epoch, pair_kernels.h); hv / sizes / status are those of set 0
   int five;
@@ -440,7 +447,26 @@ enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 
 // (level-2 node k <-> local atom k), then level 3 of all trees, and so on: levels are contiguous over the whole
 // forest, sibling lists never mix trees.  returns BuildResult (workgroup-uniform); on success *nnodes_out /
 // *natoms_out are set.
-template <int NCAP, int ACAP, int BS, bool FIVE = false>
+// position `idx` of the caller's [3n] array, or of an OpenMM context's posq (as slot_position reads it, prep_role.h)
+template <bool POSQ>
+__device__ __forceinline__ void tree_position(const TreeArgs& A, int idx, double& x, double& y, double& z) {
+  if (!POSQ) {
+    const double* __restrict__ pr = A.pos + 3 * (size_t)idx;
+    x = pr[0], y = pr[1], z = pr[2];
+  } else if (A.posq_double) {
+    const double4 p = static_cast<const double4*>(A.posq)[idx];
+    x = p.x, y = p.y, z = p.z;
+  } else {
+    const float4 p = static_cast<const float4*>(A.posq)[idx];
+    x = (double)p.x, y = (double)p.y, z = (double)p.z;
+    if (A.posq_corr) {  // mixed precision: position = posq + posqCorrection, both float
+      const float4 c = A.posq_corr[idx];
+      x += (double)c.x, y += (double)c.y, z += (double)c.z;
+    }
+  }
+}
+
+template <int NCAP, int ACAP, int BS, bool FIVE = false, bool POSQ = false>
 __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, int tid, int my_item, const int (&items)[kMaxRoots], int m,
                             int* nnodes_out, int* natoms_out, int my_atom = 0) {
   // FIVE (five-launch mode): positions come from the caller's array -- a root's through the atom index that arrived with its
@@ -480,8 +506,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
     const int hi = work_item_root(item);
     double rx, ry, rz;
     if (FIVE) {
-      const double* __restrict__ pr = A.pos + 3 * (size_t)my_atom;
-      rx = pr[0], ry = pr[1], rz = pr[2];
+      tree_position<POSQ>(A, my_atom, rx, ry, rz);  // (POSQ: my_atom is the root's slot in the context's order)
     } else {
       rx = A.hvat(kHvX, hi), ry = A.hvat(kHvY, hi), rz = A.hvat(kHvZ, hi);
     }
@@ -573,8 +598,7 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       double xj, yj, zj;
       const double aj = A.hvat(kHvALarge, hjn), vj = A.hvat(kHvVLarge, hjn), gj = A.hvat(kHvGam, hjn);
       if (FIVE) {
-        const double* __restrict__ pj = A.pos + 3 * (size_t)A.out.h2a[hjn];
-        xj = pj[0], yj = pj[1], zj = pj[2];
+        tree_position<POSQ>(A, POSQ ? A.hslot[hjn] : A.out.h2a[hjn], xj, yj, zj);
       } else {
         xj = A.hvat(kHvX, hjn), yj = A.hvat(kHvY, hjn), zj = A.hvat(kHvZ, hjn);
       }

@@ -112,7 +112,8 @@ constexpr int tree_waves_per_simd(int ncap, int bs) {
 constexpr int kPendCap = 16;  // work items that may wait while a forest that outgrew its store is built again in smaller sets
 // SV1: the launch also collects the self volumes of pass 1 (enlarged radii; a diagnostic: agbnp_hip_set_diagnostics)
 // FIVE: the five-launch mode's instantiation (k_tree_cavity_five below): positions straight from the caller's array.
-template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1, bool FIVE>
+// POSQ: FIVE with the positions in an OpenMM context's posq (TreeArgs::posq; row_atoms holds slots)
+template <int NCAP, int ACAP, int BS, bool GLOBAL, bool SV1, bool FIVE, bool POSQ = false>
 __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree_blocks) {  // tree_blocks: forest workgroups of the launch
   extern __shared__ __align__(16) char smem[];
   TreeStore<NCAP, ACAP> S;
@@ -174,7 +175,7 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     tree_barrier<NCAP>();
     CSTAMP_BEGIN();
     int nnodes = 0, natoms = 0;
-    int rc = build_forest<NCAP, ACAP, BS, FIVE>(S, A, tid, my_item, items, m, &nnodes, &natoms, my_atom);
+    int rc = build_forest<NCAP, ACAP, BS, FIVE, POSQ>(S, A, tid, my_item, items, m, &nnodes, &natoms, my_atom);
     CSTAMP(0);
     double e_sum = 0.0;
     int npairs = 0;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
           }
           if (tid < 64 && lane >= keep && lane < m) s_pend[npend + lane - keep] = mine;
           my_item = lane < keep ? mine : -1;
-          if (FIVE) my_atom = my_item >= 0 ? A.out.h2a[work_item_root(my_item)] : 0;
+          if (FIVE) my_atom = my_item >= 0 ? (POSQ ? A.hslot : A.out.h2a)[work_item_root(my_item)] : 0;
         } else {
           const int root = work_item_root(items[0]), p = work_item_part(items[0]);
           auto part_of_four = [&](int q) { return root | (q << 24) | (3 << 26); };
@@ -221,7 +222,7 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
             }
           }
           my_item = lane == 0 ? part_of_four(parts0 == 1 ? 0 : p) : -1;
-          if (FIVE) my_atom = lane == 0 ? A.out.h2a[root] : 0;
+          if (FIVE) my_atom = lane == 0 ? (POSQ ? A.hslot : A.out.h2a)[root] : 0;
         }
         if (tid == 0) s_npend = npend + more;
         continue;  // the same slot again, with the smaller set (the barrier in front of the build orders the list)
@@ -365,7 +366,7 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
       }
       const int take = min(npend, kMaxRoots);
       my_item = lane < take ? s_pend[npend - take + lane] : -1;
-      if (FIVE) my_atom = my_item >= 0 ? A.out.h2a[work_item_root(my_item)] : 0;
+      if (FIVE) my_atom = my_item >= 0 ? (POSQ ? A.hslot : A.out.h2a)[work_item_root(my_item)] : 0;
       lds_barrier();  // (the list is read: the next set may add to it)
       if (tid == 0) s_npend = npend - take, s_out = spare;
     }
@@ -386,7 +387,10 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
 // accumulators, subtree shapes and status words for the NEXT evaluation.
 static_assert(kPrepHvGx == kHvGx && kPrepHvGx + 3 == kHvSvVdw && kPrepHvSvLarge == kHvSvLarge, "prep_role.h addresses the table's rows by number");
 // DEVPAR: the evaluation's set is named by the device's own count (contexts that have been captured into a graph: pair_kernels.h)
-template <int NCAP, int ACAP, int BS, bool DEVPAR = false>
+// POSQ: the instantiation of agbnp_hip_execute_openmm (round 6): the forest workgroups read the context's posq (double4, float4,
+// float4 + correction) at the context's slots; the trailing workgroups read it through the same maps (prep_role.h) and check
+// every particle's entry against atomIndex (kStatOrderStale: the context has reordered its atoms, the evaluation is void)
+template <int NCAP, int ACAP, int BS, bool DEVPAR = false, bool POSQ = false>
 __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavity_five(TreeArgs A, PairArgs P, int tree_blocks) {
   if ((int)blockIdx.x >= tree_blocks) {
     const int b = (int)blockIdx.x - tree_blocks;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
     return prep_atoms(P, b * BS + (int)threadIdx.x, b == 0, true);
   }
   if (DEVPAR) rebase_tree_for_parity(A, 0);
-  cavity_forests<NCAP, ACAP, BS, false, false, true>(A, tree_blocks);
+  cavity_forests<NCAP, ACAP, BS, false, false, true, POSQ>(A, tree_blocks);
 }
 
 // ---- the forces leave with the last tree launch (TreeOutputs) ------------------------------------------------------
@@ -847,20 +851,23 @@ hipError_t launch_tree_cavity_five(int variant, int slots, const TreeArgs& A, co
   if (A.nh <= 0 || variant > 1) return hipErrorInvalidValue;  // (the engine leaves the mode before it gets here)
   const int work = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
   const int prep_blocks = (work + kBS - 1) / kBS;
-  const bool dev = A.five == 2;
+  const bool dev = A.five == 2, posq = A.posq != nullptr;
+  const dim3 grid(slots + prep_blocks), block(kBS);
+#define AGBNP_FIVE(NC, AC, lds)                                                                                                       \
+  do {                                                                                                                               \
+    if (dev && posq) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, true, true>), grid, block, lds, st, A, P, slots);            \
+    else if (dev) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, true, false>), grid, block, lds, st, A, P, slots);              \
+    else if (posq) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, false, true>), grid, block, lds, st, A, P, slots);             \
+    else hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, false, false>), grid, block, lds, st, A, P, slots);                      \
+  } while (0)
   if (variant == 0) {
     const size_t lds = TreeStore<AGBNP_SMALL_STORE>::kBytes;
-    if (dev)
-      hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS, true>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
-    else
-      hipLaunchKernelGGL((k_tree_cavity_five<AGBNP_SMALL_STORE, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    AGBNP_FIVE(kSmallNodes, kSmallAtoms, lds);
   } else {
     const size_t lds = TreeStore<512, 64>::kBytes;
-    if (dev)
-      hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS, true>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
-    else
-      hipLaunchKernelGGL((k_tree_cavity_five<512, 64, kBS>), dim3(slots + prep_blocks), dim3(kBS), lds, st, A, P, slots);
+    AGBNP_FIVE(512, 64, lds);
   }
+#undef AGBNP_FIVE
   return hipGetLastError();
 }
 

@@ -152,3 +152,95 @@ def test_a_captured_evaluation_replays_in_the_mode(gpu_required, systems, five):
             _close(ee, fe, eo2, fo2)
     assert k.finish(torch.cuda.current_stream().cuda_stream) == 0
     assert int(k.scalar("launches")) == 5
+
+
+@pytest.mark.parametrize("precision", ["double", "mixed"])
+def test_the_openmm_entry_point_runs_in_the_mode(gpu_required, systems, five, precision):
+    """Round 6: agbnp_hip_execute_openmm -- the entry the OpenMM glue calls (openmm_glue/HipAGBNPKernels.cpp, mirror of
+    OpenCLAGBNPKernels.cpp:3510-4216) -- stays in the five-launch mode: the forest workgroups read the context's posq (double4, or
+    float4 + correction) at the context's slots, the trailing workgroups check the atom order.  A queue of jittered geometries in
+    a shuffled, padded context order: five launches, no k_prep, the oracle's sums in the fixed-point planes; then the SAME
+    context through agbnp_hip_execute_device and back (the words beside the work-slot rows are rewritten for the other entry
+    point), then a reorder of the context's atoms (that evaluation alone is withheld, the repeat is right)."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    n, padded = s.n, (s.n + 31) // 32 * 32
+    rng = np.random.default_rng(11)
+    oracle = Oracle(*s.params(), version=1)
+    k = _kernel(s)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    index = torch.zeros(padded, dtype=torch.int32, device=dev)
+    fixed = torch.zeros(3 * padded, dtype=torch.int64, device=dev)
+    ebuf = torch.zeros(8, dtype=torch.float64, device=dev)
+    state = {}
+
+    def set_order():
+        order = rng.permutation(n).astype(np.int32)
+        index.copy_(torch.tensor(np.concatenate([order, np.arange(n, padded, dtype=np.int32)])))  # same address, new contents
+        state["order"] = order
+
+    def context_arrays(pos):  # -> posq (+ correction) tensors in the context's order, and the positions the engine really sees
+        host = np.zeros((padded, 4))
+        host[:n, :3] = pos[state["order"]]
+        if precision == "double":
+            return torch.tensor(host, dtype=torch.float64, device=dev), None, pos
+        hi = host.astype(np.float32)
+        lo = (host - hi.astype(np.float64)).astype(np.float32)
+        seen = np.zeros((n, 3))
+        seen[state["order"]] = (hi.astype(np.float64) + lo.astype(np.float64))[:n, :3]
+        return torch.tensor(hi, device=dev), torch.tensor(lo, device=dev), seen
+
+    def run_openmm(geoms):
+        keep, want_e, want_f = [], 0.0, np.zeros((n, 3))
+        for g in geoms:
+            posq, corr, seen = context_arrays(g)
+            keep.append((posq, corr))
+            k.execute_openmm(posq.data_ptr(), precision == "double", corr.data_ptr() if corr is not None else 0, index.data_ptr(), padded,
+                             fixed.data_ptr(), ebuf.data_ptr(), True, 3, stream)
+            eo, fo = oracle.execute(seen)
+            want_e, want_f = want_e + eo, want_f + fo
+        return keep, want_e, want_f
+
+    def check(want_e, want_f, evaluations):
+        torch.cuda.synchronize()
+        got = fixed.cpu().numpy().reshape(3, padded).astype(np.float64) / 2.0 ** 32
+        assert not got[:, n:].any()
+        assert np.abs(got[:, :n].T - want_f[state["order"]]).max() < evaluations * 1e-6  # (the fixed point resolves 2^-32 per add)
+        assert abs(ebuf.cpu().numpy()[3] - want_e) < evaluations * TIGHT * max(1.0, abs(want_e) * 1e-3 / evaluations)
+        fixed.zero_()
+        ebuf.zero_()
+
+    set_order()
+    torch.cuda.synchronize()
+    k.set_profiling(True)
+    keep, we, wf = run_openmm([s.jittered(200 + i) for i in range(5)])
+    assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
+    assert int(k.scalar("launches")) == 5
+    times = {name for name, v in k.kernel_times().items() if v[1] > 0}
+    assert "k_prep" not in times and len(times) == 5, times
+    k.set_profiling(False)
+    check(we, wf, 5)
+    # the same context through the device-resident entry point (positions in particle order), and back
+    pos = torch.tensor(np.stack([s.jittered(205), s.jittered(206)]), dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    for i in range(2):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0
+    w = [oracle.execute(s.jittered(205 + i)) for i in range(2)]
+    _close(ene.item(), frc.cpu().numpy(), w[0][0] + w[1][0], w[0][1] + w[1][1], tol=2 * TIGHT)
+    keep, we, wf = run_openmm([s.jittered(207), s.jittered(208)])
+    assert k.finish(stream) == 0 and int(k.scalar("launches")) == 5
+    check(we, wf, 2)
+    # OpenMM's reorderAtoms(): same arrays, new contents
+    set_order()
+    torch.cuda.synchronize()
+    keep, we, wf = run_openmm([s.jittered(209)])
+    assert k.finish(stream) == 1 and list(k.withheld()) == [0]
+    torch.cuda.synchronize()
+    assert not fixed.cpu().numpy().any() and not ebuf.cpu().numpy().any()  # nothing of the stale evaluation arrived
+    keep, we, wf = run_openmm([s.jittered(209), s.jittered(210)])
+    assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
+    assert int(k.scalar("launches")) == 5
+    check(we, wf, 2)
