@@ -69,9 +69,12 @@ ISSUE_BOUND_KERNELS = ("k_gb_tiles", "k_born_tiles", "k_dborn_tiles", "k_born_ro
 
 
 def newest_profile_dir():
+    """The newest profiles/rNN that holds a counter pass (pmc_utilization.csv): a round's directory exists from its first log on,
+    the counters arrive with scripts/profile_round.sh."""
     root = os.path.join(ROOT, "profiles")
     tags = sorted(d for d in os.listdir(root) if d.startswith("r") and d[1:].isdigit() and os.path.isdir(os.path.join(root, d))) if os.path.isdir(root) else []
-    return os.path.join(root, tags[-1]) if tags else None
+    full = [t for t in tags if os.path.exists(os.path.join(root, t, "pmc_utilization.csv"))]
+    return os.path.join(root, (full or tags)[-1]) if tags else None
 
 
 def profile_head(directory=None):

@@ -442,6 +442,129 @@ __device__ __forceinline__ unsigned long long kept_bits(const unsigned long long
 
 enum BuildResult { kBuildOk = 0, kBuildNodeOverflow = 1, kBuildAtomOverflow = 2 };
 
+// ---- EXPERIMENT (compile-time, -DAGBNP_WAVE_TAIL=<nodes>, 0 = off = the product): a wave-local tail of the
+// expansion.  1dwc's levels 5-7 hold 25 / 5 / 0.1 nodes per forest, yet each still pays three workgroup-barrier-delimited
+// phases (~6.8 k cycles per level whatever its width: profiles/r05/stamps_tree_five_vs_six_launches.txt).  When a level (from
+// level 3 on: the ownership of level-2 nodes is the workgroup path's business) has at most AGBNP_WAVE_TAIL nodes, wave 0
+// finishes the remaining levels alone -- the same three phases per batch, the same arithmetic and the same node order, with
+// `s_waitcnt lgkmcnt(0)` where the workgroup path has `s_barrier` (a wave's LDS traffic is in order) -- while the other
+// waves wait at the barrier behind the build.  Returns false if the store overflowed.
+#ifndef AGBNP_WAVE_TAIL
+#define AGBNP_WAVE_TAIL 0
+#endif
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+template <int NCAP, int ACAP>
+__device__ __forceinline__ bool expand_tail_wave(const TreeStore<NCAP, ACAP>& S, int lane, int L, int level_begin, int& tail_io) {
+  constexpr int TCAP = TreeStore<NCAP, ACAP>::TCAP;
+  unsigned char* tmap = reinterpret_cast<unsigned char*>(S.cand_vol);
+  double* tvol = S.nd[6];
+  int tail = tail_io;
+  for (; L < kMaxOrder; L++) {
+    const int lb = level_begin, le = tail;
+    level_begin = le;
+    if (lb >= le) break;
+    for (int nb = lb; nb < le;) {
+      // phase 0 (as the workgroup path's narrow form)
+      const int k = nb + lane;
+      const bool has = k < le;
+      const int cnt = has ? (int)S.ncs[k] - k - 1 : 0;
+      const int incl = wave_inclusive_scan(cnt);
+      const bool inb = has && (incl <= TCAP);
+      const int nin = __popcll(__ballot(inb));
+      const int T = __builtin_amdgcn_readlane(incl, nin - 1);
+      if (inb) {
+        const int excl = incl - cnt;
+        S.tstart[lane] = (unsigned short)excl;
+        for (int i = 0; i < cnt; i++) tmap[excl + i] = (unsigned char)lane;
+      }
+      if (lane == 0) S.tstart[nin] = (unsigned short)T;
+      wave_sync();
+      // phase 1
+      int keep_j = 0, keep_ts = 0, keep_te = 0, keep_la = 0;
+      double keep_v = 0.0;
+      for (int t = lane; t < T; t += 64) {
+        const int j = tmap[t];
+        const int kk = nb + j;
+        const int tsj = S.tstart[j], tej = S.tstart[j + 1];
+        const int s = kk + 1 + (t - tsj);
+        const int la = S.nla[s];
+        double gv;
+        const double v = dev_merge_volume2(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.nd[4][kk], S.at[0][la],
+                                           S.at[1][la], S.at[2][la], S.at[3][la], S.at[4][la], gv);
+        const bool kept = v > kMinGvol;
+        tvol[t] = kept ? gv : 0.0;
+        if (t == lane) keep_j = j, keep_ts = tsj, keep_te = tej, keep_la = la, keep_v = kept ? gv : 0.0;
+        const unsigned long long km = __ballot(kept);
+        if (lane == 0) S.kmask[t >> 6] = km;
+      }
+      wave_sync();
+      // phases 2 + 3
+      const int nwords = (T + 63) >> 6;
+      int created = 0;
+      for (int w = 0; w < nwords; w++) created += __popcll(S.kmask[w]);
+      if (tail + created > NCAP) return false;
+      auto kept_before = [&](int ts) {
+        const int wi = ts >> 6;
+        int c = __popcll(S.kmask[wi] & ((1ull << (ts & 63)) - 1ull));
+        for (int w = 0; w < wi; w++) c += __popcll(S.kmask[w]);
+        return c;
+      };
+      auto create = [&](int t, double v, int j, int ts, int te, int la_known) {
+        const int kk = nb + j;
+        if (v > 0.0 || t == ts) {
+          int rank = 0, c = 0;
+          for (int s0 = ts; s0 < te; s0 += 63) {
+            const int s1 = (ACAP <= 64 || s0 + 63 >= te) ? te : s0 + 63;
+            unsigned long long m = kept_bits(S.kmask, s0, s1);
+            c += __popcll(m);
+            if (v > 0.0)
+              for (; m; m &= m - 1) {
+                const int u = s0 + __builtin_ctzll(m);
+                const double vu = tvol[u];
+                rank += (vu > v || (vu == v && u < t)) ? 1 : 0;
+              }
+            if (ACAP <= 64) break;
+          }
+          const int cb = tail + kept_before(ts);
+          if (t == ts && c > 0) {
+            S.ncs[kk] = (unsigned short)cb;
+            S.ncc[kk] = (unsigned short)c;
+          }
+          if (v > 0.0) {
+            const int slot = cb + rank;
+            const int la = la_known >= 0 ? la_known : (int)S.nla[kk + 1 + (t - ts)];
+            double mx, my, mz, ma;
+            dev_merge_known(S.nd[0][kk], S.nd[1][kk], S.nd[2][kk], S.nd[3][kk], S.at[0][la], S.at[1][la], S.at[2][la], S.at[3][la], v,
+                            mx, my, mz, ma);
+            S.nd[0][slot] = mx;
+            S.nd[1][slot] = my;
+            S.nd[2][slot] = mz;
+            S.nd[3][slot] = ma;
+            S.nd[4][slot] = v;
+            S.nla[slot] = (unsigned short)la;
+            S.npar[slot] = (unsigned short)kk;
+            S.ncs[slot] = (unsigned short)(cb + c);
+            S.ncc[slot] = 0;
+          }
+        }
+      };
+      if (lane < T) create(lane, keep_v, keep_j, keep_ts, keep_te, keep_la);
+      for (int t = lane + 64; t < T; t += 64) {
+        const int j = tmap[t];
+        create(t, tvol[t], j, S.tstart[j], S.tstart[j + 1], -1);
+      }
+      wave_sync();
+      tail += created;
+      nb += nin;
+    }
+  }
+  tail_io = tail;
+  return true;
+}
+
 // ---- build the forest of the heavy atoms roots[0..m) (large radii) -----------------------------------------
 // Node and local-atom numbering: 0..m-1 are the roots (level 1), then the level-2 nodes of root 0, of root 1, ...
 // (level-2 node k <-> local atom k), then level 3 of all trees, and so on: levels are contiguous over the whole
@@ -729,10 +852,19 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
 #pragma unroll
   for (int q = 0; q < kMaxRoots; q++) any_shared = any_shared || (q < m && work_item_parts(items[q]) > 1);
   int level_begin = m;  // first node of level L (level 2 follows the roots)
+#if AGBNP_WAVE_TAIL > 0
+  int tail_from = -1;
+#endif
   for (; L < kMaxOrder; L++) {
     const int lb = level_begin, le = tail;  // nodes of level L; their children go to level L+1 starting at `tail`
     level_begin = le;
     if (lb >= le) break;
+#if AGBNP_WAVE_TAIL > 0
+    if (L >= 3 && le - lb <= AGBNP_WAVE_TAIL && NCAP <= 2048) {  // the experiment above: wave 0 alone from here on
+      tail_from = lb;
+      break;
+    }
+#endif
     // a level-2 node is expanded by the work item that owns its rank (see kRtPart); deeper nodes by whoever created them
     auto owned_level2 = [&](int k) {
       if (L != 2 || !any_shared) return true;
@@ -898,6 +1030,17 @@ __device__ int build_forest(const TreeStore<NCAP, ACAP>& S, const TreeArgs& A, i
       nb += nin;
     }
   }
+#if AGBNP_WAVE_TAIL > 0
+  if (tail_from >= 0) {  // (every wave gets here behind the barrier that ended the level before)
+    if (tid < 64) {
+      const bool fits = expand_tail_wave<NCAP, ACAP>(S, tid, L, tail_from, tail);
+      if (tid == 0) S.ctl[1] = fits ? tail : -1;
+    }
+    tree_barrier<NCAP>();
+    tail = S.ctl[1];
+    if (tail < 0) return kBuildNodeOverflow;
+  }
+#endif
   tree_barrier<NCAP>();
   *nnodes_out = tail;
   *natoms_out = m + ncand;

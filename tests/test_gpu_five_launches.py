@@ -213,6 +213,9 @@ def test_the_openmm_entry_point_runs_in_the_mode(gpu_required, systems, five, pr
 
     set_order()
     torch.cuda.synchronize()
+    keep, we, wf = run_openmm([s.jittered(199)])  # (a fresh context lays its first neighbour masks down with a launch of its own)
+    assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
+    check(we, wf, 1)
     k.set_profiling(True)
     keep, we, wf = run_openmm([s.jittered(200 + i) for i in range(5)])
     assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
