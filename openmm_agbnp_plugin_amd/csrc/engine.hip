@@ -98,14 +98,18 @@ struct agbnp_hip_context {
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
                            // (five-launch mode: TWO such tables, see below)
   size_t hstride = 64;
-  // ---- five-launch mode (experimental, AGBNP_HIP_FIVE_LAUNCHES=1; version 1, capacity variants 0-1, FP64 [3n] positions, no
-  //      stream capture): no k_prep launch.  The trailing workgroups of the cavity launch do k_prep's per-atom work; what the
-  //      tree launch needs clean BEFORE it starts -- its accumulators, the subtree shapes, the per-evaluation status words --
-  //      exists twice and alternates with the evaluation's parity (the trailing workgroups clear the other set); the tree
-  //      reads the caller's positions itself; the level-2 neighbour masks carry a skin and are rebuilt (k_masks, a launch of
-  //      its own) when an evaluation has found a heavy atom more than half of it from where it was (that evaluation is void)
+  // ---- five-launch mode (the default for version 1 since round 5; AGBNP_HIP_FIVE_LAUNCHES=0 keeps the k_prep launch; capacity
+  //      variants 0-1, the FP64 row form of the pair stages; the caller's FP64 [3n] positions or -- round 6 -- an OpenMM context's
+  //      posq; inside stream captures the device names the evaluation's set): no k_prep launch.  The trailing workgroups of the
+  //      cavity launch do k_prep's per-atom work; what the tree launch needs clean BEFORE it starts -- its accumulators, the
+  //      subtree shapes, the per-evaluation status words -- exists twice and alternates with the evaluation's parity (the
+  //      trailing workgroups clear the other set); the tree reads the caller's positions itself; the level-2 neighbour masks
+  //      carry a skin and are laid down anew ON THE DEVICE, by tiles at the tail of the Born-rows launch, when a heavy atom has
+  //      used a quarter of it (beyond half the evaluation is void: a jump of more than 0.04 nm costs one withheld evaluation,
+  //      include/agbnp_hip.h); a launch of their own (k_masks) lays them down for a fresh context and after an OpenMM context
+  //      has reordered its atoms
   bool five = false;           // asked for
-  bool five_active = false;    // ... and in effect (switched off for good by a larger capacity variant, the OpenMM entry point, a stream capture)
+  bool five_active = false;    // ... and in effect (switched off for good by a capacity variant beyond 1, pair stages other than the FP64 row form, the diagnostic pass-1 self volumes)
   int parity = 0;              // of the evaluation whose results the device holds (read back at every harvest)
   int five_evals = 0;          // evaluations enqueued in the mode so far: evaluation k works on set k & 1
   bool five_device = false;    // the device names the set (from the context's first stream capture on: see PairArgs::five)

@@ -104,7 +104,7 @@ struct PairArgs {
   int split_fit;           // 1: subtrees whose items would not fit the store are shared among up to four items (AGBNP_HIP_SPLIT_FIT=0: off)
   int round_permille;      // share of the resident workgroups that the packing fills (tuning knob, default 1000: every resident slot)
   int tree_slot_cap;       // work slots the tree kernels are launched with (>= subtrees; bounds the sharing of subtrees)
-  // ---- five-launch mode (experimental, AGBNP_HIP_FIVE_LAUNCHES=1; engine.hip): no k_prep launch.  The tree accumulators, the
+  // ---- five-launch mode (the default for version 1; AGBNP_HIP_FIVE_LAUNCHES=0 switches it off; engine.hip): no k_prep launch.  The tree accumulators, the
   //      subtree shapes and the per-evaluation status words exist TWICE and alternate with the evaluation's parity; the
   //      trailing workgroups of the cavity launch (prep_role.h) clear the other set for the next evaluation
   int five;                // 0: six launches.  1: that mode, the HOST names the evaluation's set (eager launches: the pointers of this

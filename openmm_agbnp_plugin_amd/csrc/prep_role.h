@@ -1,5 +1,5 @@
-// The per-atom half of the preparation of an evaluation, shared by k_prep (pair_kernels.hip) and -- in the experimental
-// five-launch mode -- by the trailing workgroups of the cavity launch (tree_kernels.hip): the caller's positions into the
+// The per-atom half of the preparation of an evaluation, shared by k_prep (pair_kernels.hip) and -- in the five-launch mode,
+// the default for version 1 -- by the trailing workgroups of the cavity launch (tree_kernels.hip): the caller's positions into the
 // heavy-atom table and the pair stages' records, the pair stages' accumulators cleared, the evaluation counted in, the
 // neighbour rows' staleness test.
 #pragma once
@@ -47,7 +47,8 @@ __device__ __forceinline__ Pos3 heavy_position(const PairArgs& P, int h) {
 // accumulators and overflow words at the same time): those of the NEXT evaluation are -- the other parity's table, shapes and
 // status block (PairArgs::next_*), which nobody touches while this evaluation runs -- and the neighbour masks this evaluation's
 // trees were built from are checked against where the heavy atoms are now (PairArgs::mask_ref): one of them further than half
-// the masks' skin away voids the evaluation (kStatOrderStale, bit 1), the host rebuilds the masks and repeats it.
+// the masks' skin away voids the evaluation (kStatOrderStale, bit 1); the device lays the masks down anew in that evaluation's
+// Born-rows launch, the host only repeats it.
 __device__ __forceinline__ void prep_atoms(const PairArgs& P, int i, bool first_block, bool five) {
   // the status words of ONE evaluation start from zero; the sticky ones (overflow log since the last
   // agbnp_hip_finish) are left alone, and the evaluation takes its running number

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BS, tree_waves_per_simd(NCAP, BS)) void k_tree_cavi
   cavity_forests<NCAP, ACAP, BS, GLOBAL, SV1, false>(A, (int)gridDim.x);
 }
 
-// Five-launch mode (experimental; engine.hip): there is no k_prep launch.  The forest workgroups read the caller's positions
+// Five-launch mode (the default for version 1; engine.hip): there is no k_prep launch.  The forest workgroups read the caller's positions
 // themselves; the workgroups BEHIND them in the grid -- dispatched when the first forests have left, done long before the last
 // ones are -- do k_prep's per-atom work for the launches that follow (prep_role.h) and clear the other parity's tree
 // accumulators, subtree shapes and status words for the NEXT evaluation.

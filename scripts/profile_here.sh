@@ -12,7 +12,7 @@ make -C openmm_agbnp_plugin_amd/csrc > /dev/null
 /usr/local/graft/bin/gpurun --timeout 1100 -- "bash scripts/profile_round.sh $tag" > gpurun_out/profile_${tag}_call.log 2>&1 || true
 tail -5 gpurun_out/profile_${tag}_call.log
 mkdir -p profiles/$tag
-for f in bench_1dwc_kernel_stats.csv bench_1dwc_line_under_rocprof.json pmc_summary.csv pmc_utilization.csv profile_head.json; do
+for f in bench_1dwc_kernel_stats.csv bench_1dwc_kernel_outliers.txt bench_1dwc_line_under_rocprof.json pmc_summary.csv pmc_utilization.csv profile_head.json; do
   [ -f gpurun_out/prof_$tag/$f ] && cp gpurun_out/prof_$tag/$f profiles/$tag/$f
 done
 [ -f gpurun_out/prof_$tag/traffic_pmc.json ] && cp gpurun_out/prof_$tag/traffic_pmc.json profiles/traffic_pmc.json

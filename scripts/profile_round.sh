@@ -30,6 +30,9 @@ echo "pmc sq done"
 find $out -name "*.csv" | head -40
 stats=$(find $out/stats -name "*kernel_stats.csv" | head -1)
 cp "$stats" profiles/$tag/bench_1dwc_kernel_stats.csv
+# which launches are the maxima of that summary: from the kernel trace of the same run
+trace=$(find $out/stats -name "*kernel_trace.csv" | head -1)
+python3 scripts/trace_outliers.py "$trace" 3 > profiles/$tag/bench_1dwc_kernel_outliers.txt 2>&1 || true
 grep '^{"metric"' $out/stats_bench.log | tail -1 > profiles/$tag/bench_1dwc_line_under_rocprof.json
 fetch=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 write=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)

@@ -1,4 +1,4 @@
-"""GPU box: the experimental five-launch mode (AGBNP_HIP_FIVE_LAUNCHES=1): no k_prep launch -- the cavity
+"""GPU box: the five-launch mode (the default for version 1; the fixture below pins it): no k_prep launch -- the cavity
 launch's trailing workgroups do its per-atom work, the tree accumulators / subtree shapes / per-evaluation status words
 alternate between two sets, the tree reads the caller's positions itself, the level-2 neighbour masks carry a skin and are
 laid down anew ON THE DEVICE when a heavy atom has used up a quarter of it.  Same numbers as the oracle, same contracts as the
