@@ -553,7 +553,7 @@ def drift_entry(dev, name, steps, sigma, warmup=20):
                     "more than half the 0.1 nm skin; finish() every 500 evaluations and the repeats of withheld evaluations inside the timed region"}
 
 
-def openmm_entry(dev, name, steps, warmup):
+def openmm_entry(dev, name, steps, warmup, shuffled=True):
     """ms per evaluation through agbnp_hip_execute_openmm (an OpenMM GPU context's conventions: posq in the context's atom
     order + atomIndex, fixed-point force planes, energy buffer) under the host protocols of the glue: a blocking finish()
     after every evaluation (the reference's own protocol: the stream is drained), wait_verdict() after every evaluation
@@ -569,7 +569,10 @@ def openmm_entry(dev, name, steps, warmup):
     kernel = dev.kernel()
     kernel.initialize(force)
     rng = np.random.default_rng(3)
-    perm = rng.permutation(n)  # context slot -> particle
+    # context slot -> particle.  OpenMM keeps its atoms in a spatially local order (reorderAtoms); a random permutation is the worst
+    # case for the fixed-point force planes (every add of a forest's atoms lands on a cache line of its own), particle order the
+    # friendly one (neighbours in the file are neighbours in space): both are reported
+    perm = rng.permutation(n) if shuffled else np.arange(n)
     geoms = [system.jittered(5000 + k) for k in range(steps + warmup)]
     posq = np.zeros((len(geoms), padded, 4))
     for k, g in enumerate(geoms):
@@ -587,7 +590,7 @@ def openmm_entry(dev, name, steps, warmup):
     for k in range(warmup):
         run(k)
     kernel.finish(stream)
-    out = {"workload": name, "entry_point": "agbnp_hip_execute_openmm (double precision context, shuffled atom order)"}
+    out = {"workload": name, "entry_point": "agbnp_hip_execute_openmm (double precision context, " + ("shuffled atom order)" if shuffled else "particle order)")}
     for label, after in (("finish_every_evaluation", lambda k: kernel.finish(stream)),
                          ("wait_verdict_every_evaluation", lambda k: kernel.wait_verdict()[1] and kernel.finish(stream)),
                          ("poll_every_evaluation", lambda k: kernel.poll()[1] and kernel.finish(stream)),
@@ -600,6 +603,28 @@ def openmm_entry(dev, name, steps, warmup):
         dev.synchronize()
         out["ms_per_eval_" + label] = 1e3 * (time.perf_counter() - t0) / steps
         kernel.finish(stream)
+    out["launches_per_evaluation"] = int(kernel.scalar("launches"))
+    # where the entry point's time goes: raw hipEvent intervals per kernel (each holds one event pair's overhead, the same on both
+    # sides) through this entry point and, same context, same geometries in particle order, through agbnp_hip_execute_device
+    d_pos = dev.tensor(np.stack(geoms), torch.float64)
+    d_f64 = dev.zeros((n, 3), torch.float64)
+    d_e64 = dev.zeros((1,), torch.float64)
+
+    def raw_kernel_us(run_one):
+        for k in range(warmup, warmup + 8):  # (a switch of the entry point rewrites the roots' position words once)
+            run_one(k)
+        kernel.finish(stream)
+        kernel.set_profiling(True)
+        for k in range(warmup, warmup + steps):
+            run_one(k)
+        kernel.finish(stream)
+        times = kernel.kernel_times()
+        kernel.set_profiling(False)
+        return {name: round(1e3 * v[0] / max(v[1], 1), 2) for name, v in times.items() if v[1] > 0}
+
+    out["kernel_event_us"] = raw_kernel_us(run)
+    out["kernel_event_us_execute_device_same_context"] = raw_kernel_us(
+        lambda k: kernel.execute_device(d_pos.data_ptr() + k * n * 24, d_f64.data_ptr(), d_e64.data_ptr(), stream))
     return out
 
 
@@ -1054,6 +1079,7 @@ def worker(args):
                                                         lambda: secondary_entry(dev, "1dwc", 1, 200, 20, 0))))
         line.put("concurrent_replicas_on_one_gpu", [line.optional(f"concurrent replicas x{r}", concurrent_replicas_entry, dev, "1dwc", r, 200, 20) for r in (2, 4)])
         line.put("openmm_entry", line.optional("openmm_entry", openmm_entry, dev, "1dwc", 200, 20))
+        line.put("openmm_entry_particle_order", line.optional("openmm_entry_particle_order", openmm_entry, dev, "1dwc", 200, 20, shuffled=False))
         line.put("md_loop", line.optional("md_loop", md_loop_entry, dev, "1dwc", 3000))
 
     line = Line(result)
