@@ -98,8 +98,8 @@ struct agbnp_hip_context {
   DevBuf<double> d_heavy;  // [kHvRows][hstride]: every per-heavy-atom double array of the tree and pair stages (tree_kernels.h)
                            // (five-launch mode: TWO such tables, see below)
   size_t hstride = 64;
-  // ---- five-launch mode (the default for version 1 since round 5; AGBNP_HIP_FIVE_LAUNCHES=0 keeps the k_prep launch; capacity
-  //      variants 0-1, the FP64 row form of the pair stages; the caller's FP64 [3n] positions or -- round 6 -- an OpenMM context's
+  // ---- five-launch mode (the default for version 1 since round 5; AGBNP_HIP_FIVE_LAUNCHES=0 keeps the k_prep launch; the LDS
+  //      stores (variants 0-3), the FP64 row form of the pair stages; the caller's FP64 [3n] positions or -- round 6 -- an OpenMM context's
   //      posq; inside stream captures the device names the evaluation's set): no k_prep launch.  The trailing workgroups of the
   //      cavity launch do k_prep's per-atom work; what the tree launch needs clean BEFORE it starts -- its accumulators, the
   //      subtree shapes, the per-evaluation status words -- exists twice and alternates with the evaluation's parity (the
@@ -109,7 +109,7 @@ struct agbnp_hip_context {
   //      include/agbnp_hip.h); a launch of their own (k_masks) lays them down for a fresh context and after an OpenMM context
   //      has reordered its atoms
   bool five = false;           // asked for
-  bool five_active = false;    // ... and in effect (switched off for good by a capacity variant beyond 1, pair stages other than the FP64 row form, the diagnostic pass-1 self volumes)
+  bool five_active = false;    // ... and in effect (switched off for good by the HBM-resident store of variant 4, pair stages other than the FP64 row form, the diagnostic pass-1 self volumes)
   int parity = 0;              // of the evaluation whose results the device holds (read back at every harvest)
   int five_evals = 0;          // evaluations enqueued in the mode so far: evaluation k works on set k & 1
   bool five_device = false;    // the device names the set (from the context's first stream capture on: see PairArgs::five)
@@ -895,10 +895,10 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
   c->P.tree_slots = c->tree_slots[c->variant];
   Timeline* tl = c->timeline.enabled ? &c->timeline : nullptr;
   if (c->five_active) {
-    // the mode ends for good where it cannot hold: a store beyond variant 1, pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
+    // the mode ends for good where it cannot hold: the 32 768-node store in HBM (variant 4), pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
     // diagnostic pass-1 self volumes (a kernel instantiation of the six-launch path only).  (A stream capture is fine: the
     // evaluation's parity lives on the device.)
-    if (c->variant > 1 || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
+    if (c->variant > 3 || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
       c->five_active = false;
       c->parity = 0;
       apply_parity(c);

@@ -430,8 +430,11 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   // store -- so that a system with a few subtrees beyond the smallest store (2clr: 479 nodes) stays on it
   // instead of moving every forest to the next larger one (four workgroups per CU instead of five).
   // (the heaviest item of a shared subtree is taken to hold 1.35 x its even share of the deeper nodes; the bound tightens with
-  // the level like everything else here, so repeated mispredictions walk the parts up to four -- beyond which the tree
-  // kernel asks for the next capacity variant)
+  // the level like everything else here.  An item that outgrows the store all the same is dealt with where it happens, round 6:
+  // the tree launch builds a whole or two-way-shared subtree again as the parts of a four-way share, at once, and this role then
+  // plans from the complete shapes of that evaluation; a three-way share records its subtree as "more than four stores' worth"
+  // (kStatSplitWanted; the evaluation is void) and is handed to four items here; a four-way share that does not fit asks for
+  // the next capacity variant)
   const float fit_nodes = 0.85f * (share * (1.0f / 0.9f)) * (float)P.tree_node_cap;
   auto parts_of = [&](int2 sz) {
     int p = min(max_parts, 1 + (sz.x >= split_nodes ? 1 : 0) + (sz.x >= 2 * split_nodes ? 1 : 0) + (sz.x >= 3 * split_nodes ? 1 : 0));

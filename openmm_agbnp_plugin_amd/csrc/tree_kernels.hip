@@ -847,28 +847,38 @@ hipError_t launch_tree_cavity(int variant, int global_grid, int slots, const Tre
 #undef AGBNP_CAVITY
 }
 
+template <class K>
+static hipError_t launch_five(K kernel, dim3 grid, size_t lds, const TreeArgs& A, const PairArgs& P, int slots, hipStream_t st) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(kBS), lds, st, A, P, slots);
+  return hipGetLastError();
+}
+
+// (round 6: every LDS variant -- rounds 5 left the mode for good at the first store beyond (512, 64))
 hipError_t launch_tree_cavity_five(int variant, int slots, const TreeArgs& A, const PairArgs& P, hipStream_t st) {
-  if (A.nh <= 0 || variant > 1) return hipErrorInvalidValue;  // (the engine leaves the mode before it gets here)
+  if (A.nh <= 0 || variant > 3) return hipErrorInvalidValue;  // (the engine leaves the mode before it gets here)
   const int work = std::max(std::max(P.n, P.nslots), (int)kStatEvalWords);
   const int prep_blocks = (work + kBS - 1) / kBS;
   const bool dev = A.five == 2, posq = A.posq != nullptr;
-  const dim3 grid(slots + prep_blocks), block(kBS);
-#define AGBNP_FIVE(NC, AC, lds)                                                                                                       \
-  do {                                                                                                                               \
-    if (dev && posq) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, true, true>), grid, block, lds, st, A, P, slots);            \
-    else if (dev) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, true, false>), grid, block, lds, st, A, P, slots);              \
-    else if (posq) hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, false, true>), grid, block, lds, st, A, P, slots);             \
-    else hipLaunchKernelGGL((k_tree_cavity_five<NC, AC, kBS, false, false>), grid, block, lds, st, A, P, slots);                      \
+  const dim3 grid(slots + prep_blocks);
+#define AGBNP_FIVE(NC, AC)                                                                                              \
+  do {                                                                                                                 \
+    const size_t lds = TreeStore<NC, AC>::kBytes;                                                                      \
+    if (dev && posq) return launch_five(k_tree_cavity_five<NC, AC, kBS, true, true>, grid, lds, A, P, slots, st);      \
+    if (dev) return launch_five(k_tree_cavity_five<NC, AC, kBS, true, false>, grid, lds, A, P, slots, st);             \
+    if (posq) return launch_five(k_tree_cavity_five<NC, AC, kBS, false, true>, grid, lds, A, P, slots, st);            \
+    return launch_five(k_tree_cavity_five<NC, AC, kBS, false, false>, grid, lds, A, P, slots, st);                     \
   } while (0)
-  if (variant == 0) {
-    const size_t lds = TreeStore<AGBNP_SMALL_STORE>::kBytes;
-    AGBNP_FIVE(kSmallNodes, kSmallAtoms, lds);
-  } else {
-    const size_t lds = TreeStore<512, 64>::kBytes;
-    AGBNP_FIVE(512, 64, lds);
+  switch (variant) {
+    case 0: AGBNP_FIVE(kSmallNodes, kSmallAtoms);
+    case 1: AGBNP_FIVE(512, 64);
+    case 2: AGBNP_FIVE(1024, 128);
+    default: AGBNP_FIVE(2048, 256);
   }
 #undef AGBNP_FIVE
-  return hipGetLastError();
 }
 
 hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const TreeArgs& A0, hipStream_t st) {
@@ -888,8 +898,12 @@ hipError_t launch_tree_pseudo(int variant, int global_grid, int slots, const Tre
       if (A.five == 2) return launch_tree(k_tree_pseudo<512, 64, kBS, false, true, true>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
       if (A.out.enabled) return launch_tree(k_tree_pseudo<512, 64, kBS, false, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
       return launch_tree(k_tree_pseudo<512, 64, kBS, false>, grid, TreeStore<512, 64>::kReplayBytes, A, st);
-    case 2: return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);
-    case 3: return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, grid, TreeStore<2048, 256>::kReplayBytes, A, st);
+    case 2:
+      if (A.five == 2) return launch_tree(k_tree_pseudo<1024, 128, kBS, false, true, true>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);
+      return launch_tree(k_tree_pseudo<1024, 128, kBS, false>, grid, TreeStore<1024, 128>::kReplayBytes, A, st);
+    case 3:
+      if (A.five == 2) return launch_tree(k_tree_pseudo<2048, 256, kBS, false, true, true>, grid, TreeStore<2048, 256>::kReplayBytes, A, st);
+      return launch_tree(k_tree_pseudo<2048, 256, kBS, false>, grid, TreeStore<2048, 256>::kReplayBytes, A, st);
     default: return launch_tree(k_tree_pseudo<kGlobalNodeCap, kGlobalAtomCap, kBS, true>, grid, 0, A, st);
   }
 }

@@ -931,6 +931,16 @@ def test_every_capacity_variant_is_exact(gpu_required, monkeypatch, n, spacing, 
     assert_close(e, f, eo, fo)
     assert int(ctx.kernel.scalar("variant")) == variant
     assert int(ctx.kernel.scalar("max_local_atoms")) >= min_local_atoms
+    # (round 6: the five-launch mode holds on every LDS store; only the 32 768-node store in HBM goes back to six launches)
+    assert int(ctx.kernel.scalar("launches")) == (5 if variant <= 3 else 6)
+    # a second, jittered evaluation on the variant the first one settled on (in the mode: its own kernels, its own masks)
+    pos2 = sysm.pos + np.random.default_rng(seed + 100).normal(0.0, 0.001, sysm.pos.shape)
+    ctx.setPositions(pos2)
+    e2, f2 = ctx.getState()
+    eo2, fo2 = Oracle(*sysm.params(), version=1).execute(pos2)
+    assert_close(e2, f2, eo2, fo2)
+    ctx.setPositions(sysm.pos)
+    ctx.getState()
     # same tree as the reference: heavy level-1 nodes + everything below (the oracle's level 1 also lists hydrogens)
     o = Oracle(*sysm.params(), version=0)
     o.execute(sysm.pos)
