@@ -65,12 +65,12 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * buffers, nothing is returned).  d_positions[3N], d_forces[3N], d_energy[1] are FP64 device
  * pointers on the context's device; `stream` is a hipStream_t (NULL = the context's own stream).
  * Asynchronous: FIVE kernel launches for version 1 (since round 5; six where the five-launch mode does not apply -- see
- * below --, one more on systems whose forests do not fit one round of resident tree workgroups, three for version 0), no
+ * below --, one more on systems whose forests do not fit one round of resident tree workgroups), TWO for version 0 (three), no
  * host synchronisation, no allocation once the context has run on its current capacity variant -- any number of
  * evaluations may be queued, or captured into a HIP graph and replayed, before agbnp_hip_finish().
  *
- * Five-launch mode (version 1, FP64 row form of the pair stages, capacity variants 0-1; AGBNP_HIP_FIVE_LAUNCHES=0 turns it
- * off).  There is no preparation launch: the tree launch reads d_positions itself and finds every heavy atom's level-2
+ * Five-launch mode (FP64 row form of the pair stages for version 1, every LDS-resident capacity variant, both device-resident
+ * entry points; AGBNP_HIP_FIVE_LAUNCHES=0 turns it off).  There is no preparation launch: the tree launch reads d_positions itself and finds every heavy atom's level-2
  * neighbours through masks that were laid down with a skin (0.08 nm, AGBNP_HIP_MASK_SKIN) at an earlier evaluation; the
  * device renews the masks by itself when a heavy atom has used up a QUARTER of the skin (that evaluation is still exact).
  * What a caller has to know: an evaluation whose positions differ from those of the evaluation before it by more than HALF
@@ -83,8 +83,16 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * works on, so a replayed evaluation alternates like eager ones do (agbnp_hip_generation() changes once, at that capture).
  * (Run one eager evaluation before the first capture, as for the capacity variant: a context that has never evaluated lays
  * its first masks down with a launch of its own, and a graph that captured that launch repeats it at every replay.)
- * The mode ends for good, silently, where it cannot hold: agbnp_hip_execute_openmm(), the diagnostic self volumes, the
- * deterministic / single-precision modes, a capacity variant beyond 1.  Scalar 16 says which path runs (5 or 6).
+ * The mode ends for good, silently, where it cannot hold: the diagnostic self volumes, the deterministic / single-precision
+ * modes, the 32 768-node store in HBM (capacity variant 4), a stream capture of a version-0 context.  Scalar 16 says which
+ * path runs (5 or 6 launches; version 0: 2 or 3).  Since round 6 agbnp_hip_execute_openmm() runs in the mode too (the tree
+ * launch reads the context's posq at the context's slots).
+ *
+ * Forests that outgrow their store are healed inside the tree launch (round 6): the packing of several subtrees into one
+ * LDS store is planned from an earlier evaluation's shapes; a forest that does not fit any more used to void the evaluation
+ * (withheld, see below) -- now its workgroup builds it again in smaller sets, the evaluation is complete, scalar 17 counts
+ * the sets.  What can still be withheld: a subtree that needs the next capacity variant, a neighbour row beyond its walk, a
+ * jump (above), a reordered OpenMM context.
  *
  * Overflow contract.  The overlap-tree stage works in fixed-capacity LDS stores; an evaluation whose trees
  * outgrow them (or whose forest packing mispredicted) is INCOMPLETE.  Such an evaluation adds NOTHING to
@@ -210,7 +218,7 @@ int agbnp_hip_get_mode(const agbnp_hip_context* ctx);
  *             4 a forest packing mispredicted, 8 a neighbour row outgrew its walk, 16 the context reordered its atoms,
  *             32 / 64 a forest of several work items outgrew its nodes / its local atoms (the two kinds of 4);
  *             bits 8.. the part count of a lone work item that asked for its subtree to be shared further
- *          16 kernel launches of a version-1 evaluation as the context runs now: 5 (five-launch mode) or 6
+ *          16 kernel launches of an evaluation as the context runs now: version 1: 5 (five-launch mode) or 6; version 0: 2 or 3
  *          17 forests that outgrew their store and were healed inside the tree launch (built again in smaller sets: the
  *             evaluation is complete, nothing is withheld for them) over the evaluations the last agbnp_hip_finish() covered
  *          14 forest packings planned so far (a packing in use is planned anew every AGBNP_HIP_REPLAN_EVERY-th evaluation,

@@ -898,7 +898,15 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     // the mode ends for good where it cannot hold: the 32 768-node store in HBM (variant 4), pair stages other than the FP64 row form (the renewal of the neighbour masks rides in the Born rows' launch), the
     // diagnostic pass-1 self volumes (a kernel instantiation of the six-launch path only).  (A stream capture is fine: the
     // evaluation's parity lives on the device.)
-    if (c->variant > 3 || c->nh <= 0 || !c->P.rows_on || c->P.single || c->diagnostics) {
+    // Version 0 (round 6: TWO launches -- the cavity launch with its trailing workgroups, the output launch, whose tail carries the
+    // masks' renewal) takes the host-named set only: its bookkeeping role, which advances the device's evaluation counter, runs
+    // INSIDE the output launch beside the workgroups that would have to read the counter, so a stream capture ends the mode there.
+    bool capturing = false;
+    if (c->version == 0 && !c->five_device) {
+      hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+      capturing = hipStreamIsCapturing(st, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
+    }
+    if (c->variant > 3 || c->nh <= 0 || (c->version == 1 && !c->P.rows_on) || c->P.single || c->diagnostics || capturing) {
       c->five_active = false;
       c->parity = 0;
       apply_parity(c);
@@ -988,7 +996,7 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
       return AGBNP_HIP_OK;
     }
   }
-  HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl));
+  HIP_TRY(c, launch_outputs(c->P, c->version, d_force, d_energy, c->d_components.p, st, tl, c->five_active && c->version == 0));
   return AGBNP_HIP_OK;
 }
 
@@ -1196,7 +1204,7 @@ int agbnp_hip_create(agbnp_hip_context** out, int n, const double* radius, const
   c->cutoff = cutoff;
   c->device = device;
   c->fused_outputs = getenv("AGBNP_HIP_OUTPUT_LAUNCH") == nullptr;
-  c->five = version == 1 && !(getenv("AGBNP_HIP_FIVE_LAUNCHES") && atoi(getenv("AGBNP_HIP_FIVE_LAUNCHES")) == 0);  // (default since round 5; 0: six launches)
+  c->five = (version == 0 || version == 1) && !(getenv("AGBNP_HIP_FIVE_LAUNCHES") && atoi(getenv("AGBNP_HIP_FIVE_LAUNCHES")) == 0);  // (default since round 5, version 0 since round 6; 0: with the k_prep launch)
   c->five_active = c->five;
   if (getenv("AGBNP_HIP_MASK_SKIN")) c->mask_skin = std::min(0.5, std::max(0.0, atof(getenv("AGBNP_HIP_MASK_SKIN"))));
   c->r_vdw.assign(radius, radius + n);
@@ -1475,7 +1483,7 @@ int agbnp_hip_get_scalar(agbnp_hip_context* c, int which, double* value) {
     case 11: *value = c->last_pack[0]; break;    // forest packing: how far the assumed store capacity is tightened (0 = not)
     case 12: *value = c->last_pack[1]; break;    // ... evaluations since the packing in use was planned
     case 14: *value = c->last_pack[3]; break;    // ... packings planned so far
-    case 16: *value = c->five_active ? 5 : 6; break;  // five-launch mode in effect (version 1; see agbnp_hip.h)
+    case 16: *value = c->version == 1 ? (c->five_active ? 5 : 6) : (c->five_active ? 2 : 3); break;  // launches of an evaluation as the context runs now (no k_prep launch in the five-launch mode; see agbnp_hip.h)
     default: return c->fail(AGBNP_HIP_ERR_INVALID_ARGUMENT, "unknown scalar id");
   }
   return AGBNP_HIP_OK;

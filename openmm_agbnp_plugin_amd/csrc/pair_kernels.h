@@ -244,7 +244,8 @@ struct Timeline {
 hipError_t launch_prep(const PairArgs& P, hipStream_t st, Timeline* tl);
 hipError_t launch_masks(const PairArgs& P, hipStream_t st, Timeline* tl);  // five-launch mode: the neighbour masks alone (with their skin) + their reference positions
 hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* components, hipStream_t st, Timeline* tl);
+// mask_tiles: version 0 in the five-launch mode -- the renewal of the level-2 neighbour masks rides at the tail of this launch
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
-                          Timeline* tl);
+                          Timeline* tl, bool mask_tiles = false);
 
 }  // namespace agbnp

@@ -1775,10 +1775,18 @@ __global__ __launch_bounds__(64 * row_waves(KIND), KIND == kGbRows ? 4 : 6) void
 //   block  nfb+1     bookkeeping for the NEXT evaluation: tree statistics and the largest-first subtree order
 
 __global__ __launch_bounds__(256) void k_outputs(PairArgs P, int version, double* __restrict__ force_out,
-                                                 double* __restrict__ energy_out, double* __restrict__ components, int role_bytes) {
+                                                 double* __restrict__ energy_out, double* __restrict__ components, int role_bytes,
+                                                 int mask_from) {
   // version 0 has no pair stages to carry the two single-workgroup roles: they are the first two workgroups here
   extern __shared__ char s_role[];  // role_bytes when version != 1
   int blk = blockIdx.x;
+  if (mask_from >= 0 && blk >= mask_from) {
+    // version 0 in the five-launch mode (round 6): the tiles that lay the level-2 neighbour masks down anew when this evaluation's
+    // trailing workgroups found a heavy atom a quarter of the masks' skin from where it was (or beyond half: the evaluation is
+    // void) -- what the tail of the Born-rows launch does for version 1 (k_rows, MASKS)
+    if (((P.estatus[kStatOrderStale] & 2) | P.estatus[kStatMaskAging]) == 0) return;
+    return neighbor_tile(P, blk - mask_from, true);
+  }
   rebase_for_parity(P, 1);  // (five-launch mode with an output launch of its own: behind the GB launch)
   if (version != 1) {
     if (blk == 0) return energy_role(P, version, energy_out, components, s_role);
@@ -1935,14 +1943,16 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
 }
 
 hipError_t launch_outputs(const PairArgs& P, int version, double* force_out, double* energy_out, double* components, hipStream_t st,
-                          Timeline* tl) {
+                          Timeline* tl, bool mask_tiles) {
   AGBNP_MARK(kKOutputs);
   // (version 0: the roles' LDS, with room for the packed shapes and as many forest times of up to 6 k subtrees -- or, where that
   // is more, for the rounds rule of the packing: shapes, a round of running sums, the sorted order of ~1.25 items per subtree)
   const int nh1 = std::max(P.nh, 1);
   const int classes_ints = std::min(2 * nh1 + 64, 12288), rounds_ints = std::min(nh1 + P.tree_slots + nh1 + nh1 / 4 + 64, 14000);
   const int role_bytes = version == 1 ? 0 : (int)kRoleScratchBytes + 4 * std::max(classes_ints, rounds_ints);
-  hipLaunchKernelGGL(k_outputs, dim3((P.n + 255) / 256 + (version == 1 ? 0 : 2)), dim3(256), role_bytes, st, P, version, force_out, energy_out, components, role_bytes);
+  const int blocks = (P.n + 255) / 256 + (version == 1 ? 0 : 2);
+  hipLaunchKernelGGL(k_outputs, dim3(blocks + (mask_tiles ? P.nb_tiles : 0)), dim3(256), role_bytes, st, P, version, force_out, energy_out, components, role_bytes,
+                     mask_tiles ? blocks : -1);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(-1);
   return hipSuccess;

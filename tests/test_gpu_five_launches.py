@@ -247,3 +247,45 @@ def test_the_openmm_entry_point_runs_in_the_mode(gpu_required, systems, five, pr
     assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
     assert int(k.scalar("launches")) == 5
     check(we, wf, 2)
+
+
+@pytest.mark.parametrize("name", ["trpcage", "1dwc", "fixture264"])
+def test_version_0_runs_in_two_launches(gpu_required, systems, five, name):
+    """Round 6: GaussVol / GVolSA (version 0, BASELINE.json configs[0]) without its k_prep launch -- the cavity launch with its
+    trailing workgroups, then the output launch (energy + bookkeeping roles, forces, the masks' renewal at its tail).  Unrelated
+    geometries through the host entry point (jumps: void, renewed, repeated), then a queue of small steps on the device path
+    that walks out of the first masks' skin with nothing withheld; the oracle's numbers (ReferenceAGBNPKernels.cpp:152-271)."""
+    torch = pytest.importorskip("torch")
+    s = systems(name)
+    k = _kernel(s, version=0)
+    oracle = Oracle(*s.params(), version=0)
+    centre = s.pos.mean(axis=0)
+    for pos in (s.pos, s.jittered(1), s.jittered(2, sigma=0.02), centre + 0.97 * (s.pos - centre), s.pos):
+        f = np.zeros((s.n, 3))
+        e = k.execute(pos, f)
+        eo, fo = oracle.execute(pos)
+        _close(e, f, eo, fo)
+    assert int(k.scalar("launches")) == 2
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    steps = 60
+    walk = s.pos + np.cumsum(rng.normal(0.0, 0.003, (steps,) + s.pos.shape), axis=0)  # ends ~0.04 nm per atom from where it began
+    pos = torch.tensor(walk, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    k.set_profiling(True)
+    for i in range(steps):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
+    times = {n for n, v in k.kernel_times().items() if v[1] > 0}
+    assert times == {"k_tree_cavity", "k_outputs"}, times
+    k.set_profiling(False)
+    sample = [0, 17, 38, steps - 1]
+    frc.zero_()
+    ene.zero_()
+    for i in sample:  # (jumps between the samples: through the host entry point, which repeats a voided evaluation by itself)
+        f = np.zeros((s.n, 3))
+        e = k.execute(walk[i], f)
+        eo, fo = oracle.execute(walk[i])
+        _close(e, f, eo, fo)
