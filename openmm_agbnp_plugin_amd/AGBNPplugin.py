@@ -203,7 +203,14 @@ class HipCalcAGBNPForceKernel:
 
     def execute_device(self, d_positions, d_forces, d_energy, stream=None):
         """GPU-platform convention (reference OpenCL platform): raw FP64 device pointers (ints), forces and
-        energy are ADDED on the device, nothing is returned.  Asynchronous; call finish()."""
+        energy are ADDED on the device, nothing is returned.  Asynchronous; call finish().
+
+        What a caller has to know (include/agbnp_hip.h, "Five-launch mode"): the tree launch finds every heavy atom's neighbours
+        through masks laid down at an earlier evaluation, with a skin.  Positions that differ from the PREVIOUS evaluation's by
+        more than 0.04 nm for some heavy atom (a minimiser's long step, a Monte-Carlo move, unrelated geometries one after the
+        other) cost one withheld evaluation: finish() reports it, withheld() names it, running it again is right (execute(), the
+        host-buffer entry point, repeats by itself).  MD steps are two orders of magnitude below that;
+        AGBNP_HIP_FIVE_LAUNCHES=0 lifts the restriction for the price of one more launch per evaluation."""
         self._need()
         rc = _lib.load().agbnp_hip_execute_device(self._h, C.c_void_p(d_positions), C.c_void_p(d_forces), C.c_void_p(d_energy),
                                                   C.c_void_p(stream or 0))

@@ -148,9 +148,13 @@ __device__ __forceinline__ void cavity_forests(const TreeArgs& A, const int tree
     // k_tree_cavity 1.6 us faster on 1dwc, A/B on one box -- same spill counts, different register allocation.)
     int my_item = first_item, my_atom = first_atom;
     if (slot != (int)blockIdx.x) {  // (a forest from the queue)
+      // (the lane number through an opaque move: otherwise the compiler forms the per-lane row address at the kernel's head, keeps
+      // it for this path alone and -- at the register limit -- parks it in scratch: 8 bytes of stores per lane and launch)
+      int lane_q = lane;
+      asm volatile("" : "+v"(lane_q));
       my_item = -1;
-      if (lane < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + lane];
-      if (FIVE && lane < kMaxRoots) my_atom = A.row_atoms[(size_t)kMaxItems * slot + lane];
+      if (lane_q < kMaxRoots) my_item = A.rows[(size_t)kRowStride * slot + lane_q];
+      if (FIVE && lane_q < kMaxRoots) my_atom = A.row_atoms[(size_t)kMaxItems * slot + lane_q];
     }
     // HEALING (round 6).  A forest that outgrows its store -- the packing was planned from an earlier geometry's shapes -- used
     // to void the whole evaluation (kStatPackOverflow: withheld, repeated by the host on one subtree per slot, the packing
