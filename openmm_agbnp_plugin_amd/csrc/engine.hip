@@ -1033,14 +1033,14 @@ int upload_identity_packing(agbnp_hip_context* c) {
   if (c->d_forest.p == nullptr) {
     forest.push_back(0);
     forest.push_back(no_plan);
-    forest.push_back(0);  // [slots+5] clean plans in a row since the assumed capacity was last tightened
+    forest.push_back(0);  // [slots+5] clean evaluations in a row since the assumed capacity was last tightened or relaxed
     forest.push_back(0);  // [slots+6] packings planned so far (diagnostic: bench.py counts the plans inside a timed region)
     forest.push_back(0);  // [slots+7] total nodes and
     forest.push_back(0);  // [slots+8] largest subtree of the evaluation the packing in use was planned from (drift trigger)
     forest.push_back(0);  // [slots+9] five-launch mode: the tree launches' copy of the device's evaluation counter (beside the
                           // forest count they read first: the same cache line, no cold round trip of its own)
     forest.push_back(0);  // [slots+10] the packing's `heat`: a leaky count of evaluations with healed forests (packing_role)
-    forest.push_back(0);  // [slots+11] ... and `need`: clean plans in a row before a tightened level is given back (its memory)
+    forest.push_back(0);  // [slots+11] ... and `need`: clean evaluations in a row before a tightened level is given back (its memory)
     return c->d_forest.upload(forest) == hipSuccess ? AGBNP_HIP_OK : c->fail(AGBNP_HIP_ERR_DEVICE, "upload of the forest packing failed");
   }
   HIP_TRY(c, hipMemcpy(c->d_forest.p, forest.data(), sizeof(int) * forest.size(), hipMemcpyHostToDevice));

@@ -85,10 +85,12 @@ struct PairArgs {
   int* forest_start;       // [nh+1] packing of the NEXT evaluation: slot s = order[forest_start[s] .. forest_start[s+1])
   int* nforests;           // [1] work slots of the NEXT evaluation
   const int* cur_nforests; // [1] work slots of THIS evaluation (energy partials are per slot)
-  int* pack_state;         // [6] persistent: [0] how often a packed forest has overflowed (tightens the packing; relaxes again after
-                           // clean plans: word [2] counts them); [1] evaluations since the packing in use was planned (huge = it
-                           // is no plan: one work item per slot); [3] packings planned so far (a diagnostic); [4], [5] total
-                           // nodes / largest subtree of the evaluation the packing was planned from (drift trigger)
+  int* pack_state;         // [9] persistent: [0] the level: how often the capacity the packing assumes has been tightened (relaxes again
+                           // after clean evaluations in a row: word [2] counts them, word [8] says how many are asked for -- the
+                           // level's memory); [1] evaluations since the packing in use was planned (huge = it is no plan: one
+                           // work item per slot); [3] packings planned so far (a diagnostic); [4], [5] total nodes / largest
+                           // subtree of the evaluation the packing was planned from (drift trigger); [6] the tree launches' copy
+                           // of the evaluation counter; [7] `heat`: leaky count of evaluations with healed forests
   int replan_every;        // a healthy packing is planned anew every so many evaluations (tuning knob, default 16), or when the trees have drifted
   int2* pack_items;        // [slots] packing_role's scratch: the work items in descending weight order {item, predicted time} (rounds rule)
   int* order;              // [kMaxItems * slots] the work items by FOREST (packing_role -> dealing_role): item k of forest f at kMaxItems * f + k

@@ -399,11 +399,12 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   // level 1: 139 -> 189 us).  So a healed forest only makes this role plan anew, from this evaluation's shapes, and adds to a
   // leaky counter (`heat`: + 16 per evaluation with healed forests, - 1 per evaluation); the level goes up when the counter says
   // that heals keep coming at more than about one evaluation in eight (128), or when a forest could NOT be healed (st_forest: no
-  // spare slot left).  The level has a MEMORY: the clean plans asked for before a step is given back (`need`, at least
-  // kPackRelax) double every time the level has to go up again (cap 64 plans = 1024 evaluations) and halve after four times
-  // that many clean plans in a row -- round 5 gave a step back after four plans whatever had happened before, and a packing
-  // that mispredicted was tried again, identically, 64 evaluations later.
-  constexpr int kPackRelax = 4;  // (x the replan period of 16 evaluations)
+  // spare slot left).  The level has a MEMORY: the clean EVALUATIONS asked for before a step is given back (`need`, at least
+  // kPackRelax = 64; evaluations, not plans: ADVICE r05 -- plans also come from drift and after every fallback, so four of them
+  // could be four evaluations) double every time the level has to go up again (cap 1024) and halve after four times that many
+  // clean evaluations in a row -- round 5 gave a step back after four plans whatever had happened before, and a packing that
+  // mispredicted was tried again, identically, 64 evaluations later.
+  constexpr int kPackRelax = 64;
   const int need = max(ps_need, kPackRelax);
   int heat = max(ps_heat - 1, 0) + (st_spare != 0 ? 16 : 0);
   const bool hot = heat >= 128;
@@ -411,7 +412,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
   const bool tighten = st_forest != 0 || hot;
   const bool relax = st_pack == 0 && st_spare == 0 && !tighten && ps_level > 0 && ps_clean >= need;
   const int level = min(6, ps_level + (tighten ? 1 : 0) - (relax ? 1 : 0));
-  const int need_next = tighten ? min(2 * need, 64) : (ps_clean >= 4 * need ? max(need / 2, kPackRelax) : need);
+  const int need_next = tighten ? min(2 * need, 1024) : (ps_clean >= 4 * need ? max(need / 2, kPackRelax) : need);
   const bool pack = P.pack_enabled && !overflow && level < 6;
   float share = 0.9f;
   for (int k = 0; k < level; k++) share *= 0.85f;
@@ -506,7 +507,7 @@ __device__ void packing_role(const PairArgs& P, char* scratch, int scratch_bytes
     P.pack_state[0] = level;
     // (after an overflow the fallback written below is no plan: the next clean evaluation plans anew)
     if (P.pack_enabled != 3) P.pack_state[1] = plan ? (overflow ? P.replan_every : 0) : age + 1;
-    if (plan) P.pack_state[2] = (tighten || relax || st_spare != 0) ? 0 : ps_clean + 1;
+    P.pack_state[2] = (tighten || relax || st_spare != 0 || overflow) ? 0 : min(ps_clean + 1, 1 << 20);  // clean evaluations in a row
     P.pack_state[7] = heat;
     P.pack_state[8] = need_next;
     if (plan) P.pack_state[3] += 1;  // (plans so far: a diagnostic)

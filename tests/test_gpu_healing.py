@@ -41,26 +41,27 @@ def _freeze_eight_subtrees_per_forest(k, nheavy):
     return nf
 
 
-@pytest.mark.parametrize("launches", ["six", "five"])
-def test_overfull_forests_are_healed_inside_the_tree_launch(gpu_required, systems, monkeypatch, launches):
+@pytest.mark.parametrize("launches,version", [("six", 1), ("five", 1), ("five", 0)])
+def test_overfull_forests_are_healed_inside_the_tree_launch(gpu_required, systems, monkeypatch, launches, version):
     """1dwc with a packing frozen at EIGHT whole subtrees per forest (261 forests of ~830 nodes for stores of 432): not one of
     them fits.  Every forest is built again in halves (and halves of halves), the later sets in spare work slots; nothing is
     withheld, energy and forces -- the pseudo-volume replay of the spare slots included -- are the oracle's on every one of a
     queue of jittered geometries, scalar 17 counts the healed sets, no capacity variant is raised.  Both launch chains: the
-    five-launch mode's forest workgroups read the caller's positions themselves, also for the sets they build again."""
+    five-launch mode's forest workgroups read the caller's positions themselves, also for the sets they build again; and
+    version 0 (no pseudo-volume replay: the spare slots only carry shapes and energies)."""
     torch = pytest.importorskip("torch")
     monkeypatch.setenv("AGBNP_HIP_FIVE_LAUNCHES", "0" if launches == "six" else "1")
     s = systems("1dwc")
-    oracle = Oracle(*s.params(), version=1)
+    oracle = Oracle(*s.params(), version=version)
     k = P.HipCalcAGBNPForceKernel()
-    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=1))
+    k.initialize(P.AGBNPForce.from_arrays(*s.params(), version=version))
     geoms = [s.jittered(step) for step in range(5)]
     want = [oracle.execute(g) for g in geoms]
     run, frc, ene, stream = _queue(k, torch, geoms, s.n)
     for i in (0, 1):  # settle on the engine's own packing
         run(i)
     assert k.finish(stream) == 0
-    assert int(k.scalar("launches")) == (5 if launches == "five" else 6)
+    assert int(k.scalar("launches")) == ((5 if launches == "five" else 6) if version == 1 else 2)
     nf = _freeze_eight_subtrees_per_forest(k, s.nheavy)
     frc.zero_()
     ene.zero_()

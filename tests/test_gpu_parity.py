@@ -1240,7 +1240,7 @@ def test_host_call_does_not_swallow_the_device_log(gpu_required, systems):
 
 def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
     """Every overflow of a packed forest that is NOT healed inside the tree launch tightens the capacity the packing assumes
-    (pack_level + 1); a few clean plans in a row (four, doubled by every tightening) give one step back, so occasional mispredictions do not push a long run to one subtree per slot for good.
+    (pack_level + 1); clean evaluations in a row (64, doubled by every tightening) give one step back, so occasional mispredictions do not push a long run to one subtree per slot for good.
     After an overflow the very next clean evaluation plans anew (the unpacked fallback is not kept for a replan period)."""
     s = systems("1dwc")
     monkeypatch.setenv("AGBNP_HIP_REPLAN_EVERY", "1")
@@ -1260,10 +1260,13 @@ def test_packing_back_off_relaxes_again(gpu_required, systems, monkeypatch):
     k.execute(s.jittered(4), f)
     k.execute(s.jittered(5), f)
     assert int(k.scalar("forests")) < s.nheavy  # packed again at once (tighter than before)
-    # (round 6: the level has a memory -- every tightening doubles the clean plans asked for before a step is given back, 4 -> 8
-    # -> 16: at most 16 per step here)
-    for step in range(16 * level + 4):
+    # (round 6: the level has a memory -- clean EVALUATIONS are counted, 64 of them at least, and every tightening doubles what is
+    # asked for before a step is given back: 128 after one tightening, 256 after two)
+    for step in range(40):
         k.execute(s.jittered(6 + step), f)
+    assert int(k.scalar("pack_level")) == level  # not yet: round 5 would have given a step back after four plans
+    for step in range(256 * level + 8):
+        k.execute(s.jittered(46 + step % 50), f)
     assert k.scalar("pack_level") == 0
     assert int(k.scalar("forests")) <= packed + 8  # back at the original packing density
 
