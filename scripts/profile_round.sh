@@ -39,5 +39,5 @@ write=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 scripts/summarize_pmc.py "$fetch" "$write" $tag 1dwc k_tree_cavity
 sq=$(find $out/pmc_sq -name "*counter_collection.csv" | head -1)
 python3 scripts/summarize_sq.py "$sq" profiles/$tag/pmc_utilization.csv
-cp profiles/$tag/*.csv profiles/$tag/*.json $out/ 2>/dev/null || true
+cp profiles/$tag/*.csv profiles/$tag/*.json profiles/$tag/*.txt $out/ 2>/dev/null || true
 cp profiles/traffic_pmc.json $out/
