@@ -109,7 +109,11 @@ constexpr int tree_waves_per_simd(int ncap, int bs) {
   return bs >= 256 ? (ncap <= 432 ? 5 : (ncap <= 512 ? 4 : 2)) : (ncap <= 192 ? 3 : 2);  // (one-wave workgroups: ~10 per CU for the small store)
 }
 
+#ifdef AGBNP_STAMPS  // (diagnostic build: the stamps take 136 bytes of the store's last LDS granule)
+constexpr int kPendCap = 4;
+#else
 constexpr int kPendCap = 16;  // work items that may wait while a forest that outgrew its store is built again in smaller sets
+#endif
 // SV1: the launch also collects the self volumes of pass 1 (enlarged radii; a diagnostic: agbnp_hip_set_diagnostics)
 // FIVE: the five-launch mode's instantiation (k_tree_cavity_five below): positions straight from the caller's array.
 // POSQ: FIVE with the positions in an OpenMM context's posq (TreeArgs::posq; row_atoms holds slots)
