@@ -708,6 +708,8 @@ class Line:
 
     def optional(self, name, fn, *a, **kw):
         try:
+            if os.environ.get("AGBNP_BENCH_FAIL_RECORD") == name:  # (test hook: this record fails, whatever it would have measured)
+                raise SystemExit(f"injected failure of the record '{name}' (AGBNP_BENCH_FAIL_RECORD)")
             return fn(*a, **kw)
         except KeyboardInterrupt:
             raise

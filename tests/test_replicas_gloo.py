@@ -308,3 +308,26 @@ def test_bench_main_prints_the_line_when_the_optional_records_overrun_their_budg
     r = lines[0]
     assert r["n_gpus"] == 1 and "roofline" in r and "cpu_baseline" in r and r["config"]["workload"].startswith("1dwc")
     assert r["optional_records_aborted"].startswith("watchdog") and "overran their budget" in p.stderr
+
+
+def test_bench_main_reports_a_failed_optional_record_inside_the_line():
+    """An optional record that dies (AGBNP_BENCH_FAIL_RECORD=drift: the hook raises SystemExit inside `Line.optional`, as the 2clr
+    entry of round 5 did on the driver's box): its entry in the line is {"error": ...}, the records behind it still run (until
+    the watchdog's budget here), exit code 0, one line with roofline and cpu_baseline."""
+    pytest.importorskip("torch")
+    import json
+    import subprocess
+
+    env = dict(os.environ, AGBNP_BENCH_BACKEND="gloo", AGBNP_BENCH_BACKEND_MODULE="tests.fake_bench_backend", AGBNP_BENCH_FAIL_RECORD="drift")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat-ms", "0",
+                        "--cpu-evals", "1", "--secondary-budget-s", "6"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = lines[0]
+    assert "roofline" in r and "cpu_baseline" in r
+    assert r["drift"]["error"].startswith("SystemExit: injected failure of the record 'drift'")
+    assert "record 'drift' failed and is reported inside the line" in p.stderr
+    assert "secondary" in r  # (the records behind the failed one were started)
