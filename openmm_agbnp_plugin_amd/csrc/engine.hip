@@ -901,12 +901,16 @@ int enqueue(agbnp_hip_context* c, const double* d_pos, double* d_force, double* 
     // Version 0 (round 6: TWO launches -- the cavity launch with its trailing workgroups, the output launch, whose tail carries the
     // masks' renewal) takes the host-named set only: its bookkeeping role, which advances the device's evaluation counter, runs
     // INSIDE the output launch beside the workgroups that would have to read the counter, so a stream capture ends the mode there.
+    // (Round 6 too: pair stages other than the FP64 row form -- the tile kernels of the deterministic mode and of AGBNP_HIP_ROWS=0, the
+    // single-precision rows of the fast mode -- stay in the mode with the host-named set: the masks' renewal rides at the tail of
+    // the GB tile launch / of the single-precision Born rows; a stream capture ends the mode for them as well.)
+    const bool host_set_only = c->version == 0 || !c->P.rows_on || c->P.single;
     bool capturing = false;
-    if (c->version == 0 && !c->five_device) {
+    if (host_set_only && !c->five_device) {
       hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
       capturing = hipStreamIsCapturing(st, &cap0) == hipSuccess && cap0 != hipStreamCaptureStatusNone;
     }
-    if (c->variant > 3 || c->nh <= 0 || (c->version == 1 && !c->P.rows_on) || c->P.single || c->diagnostics || capturing) {
+    if (c->variant > 3 || c->nh <= 0 || c->diagnostics || capturing || (host_set_only && c->five_device)) {
       c->five_active = false;
       c->parity = 0;
       apply_parity(c);

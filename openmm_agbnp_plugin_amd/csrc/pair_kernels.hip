@@ -1258,13 +1258,20 @@ __device__ __forceinline__ void gb_strip_f32(int n, int I0, int J, const double4
   if (threadIdx.x == 0) egb_out[0] = 2.0 * kDielFactor * ((s_e[0] + s_e[1]) + (s_e[2] + s_e[3]));
 }
 
-template <bool kCut, bool kSingle, bool kFar>
+// kMasks (round 6): the instantiations of the five-launch mode where the Born stage is not the FP64 row launch that carries the
+// masks' renewal (tile kernels: deterministic mode, AGBNP_HIP_ROWS=0): the workgroups behind the last work item are the tiles that
+// lay the level-2 neighbour masks down anew when the cavity launch's trailing workgroups asked for it (k_rows, MASKS)
+template <bool kCut, bool kSingle, bool kFar, bool kMasks = false>
 __global__ __launch_bounds__(256) void k_gb_tiles(int n, const int* __restrict__ items, const double4* __restrict__ aposq,
                                                   const double* __restrict__ born_part, const double* __restrict__ inv_rvdw,
                                                   const double* __restrict__ alpha, double* __restrict__ born,
                                                   double* __restrict__ born_fp, double* __restrict__ brw,
                                                   double* __restrict__ e_atom, double* __restrict__ gb_rows,
                                                   double* __restrict__ egb_part, PairArgs P) {
+  if (kMasks && (int)blockIdx.x > P.gb_items_count) {
+    if (((P.estatus[kStatOrderStale] & 2) | P.estatus[kStatMaskAging]) == 0) return;
+    return neighbor_tile(P, (int)blockIdx.x - 1 - P.gb_items_count, true);
+  }
   // one LDS area, two lives: the atom records during the walk, the sums of the four waves after it
   __shared__ __align__(16) char s_area[sizeof(StripSums)];
   static_assert(sizeof(StripSums) >= sizeof(TileSums) && sizeof(TileSums) >= kRoleScratchBytes, "the packing workgroup borrows the tile area");
@@ -1892,7 +1899,10 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
     const size_t table_lds = (size_t)2 * P.nti * P.ntj * kRowIntervals * sizeof(double2);
     const size_t born_lds = table_lds, chain_lds = std::max(table_lds, sizeof(TileSums));  // (>= what the two roles borrow)
     AGBNP_MARK(kKBornRows);
-    if (P.single)
+    if (P.single && P.five)  // (five-launch mode, the single-precision rows of the fast mode: + the conditional mask tiles; host-named set only)
+      hipLaunchKernelGGL((k_rows<kBornRows, true, true>), dim3(born_blocks + build_blocks + P.nb_tiles), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr,
+                         (double*)nullptr, born_blocks + build_blocks);
+    else if (P.single)
       hipLaunchKernelGGL((k_rows<kBornRows, true>), dim3(born_blocks + build_blocks), dim3(64 * kRowWaves), born_lds, st, P, (double*)nullptr, (double*)nullptr, 0);
     else if (P.five == 2)  // (five-launch mode, device-side parity: + the conditional mask tiles)
       hipLaunchKernelGGL((k_rows<kBornRows, false, true, true>), dim3(born_blocks + build_blocks + P.nb_tiles), dim3(64 * kRowWaves), born_lds, st, P,
@@ -1930,7 +1940,10 @@ hipError_t launch_pair_stages(const PairArgs& P, double* energy_out, double* com
   AGBNP_MARK(kKGbTiles);
   auto gb = P.fast ? (P.single ? k_gb_tiles<true, true, false> : k_gb_tiles<true, false, false>)
                    : (P.gb_far ? k_gb_tiles<false, false, true> : k_gb_tiles<false, false, false>);
-  hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
+  if (P.five)  // (five-launch mode on the tile kernels: the masks' renewal rides at the tail of this launch)
+    gb = P.fast ? (P.single ? k_gb_tiles<true, true, false, true> : k_gb_tiles<true, false, false, true>)
+                : (P.gb_far ? k_gb_tiles<false, false, true, true> : k_gb_tiles<false, false, false, true>);
+  hipLaunchKernelGGL(gb, dim3(P.gb_items_count + 1 + (P.five ? P.nb_tiles : 0)), dim3(256), 0, st, P.n, P.gb_items, (const double4*)P.aposq,
                      (const double*)P.born_part, P.inv_rvdw, P.alpha, P.born, P.born_fp, P.brw, P.e_atom, P.gb_fx, P.egb_part, P);
   AGBNP_CHECK_LAUNCH();
   AGBNP_MARK(kKDbornTiles);

@@ -289,3 +289,55 @@ def test_version_0_runs_in_two_launches(gpu_required, systems, five, name):
         e = k.execute(walk[i], f)
         eo, fo = oracle.execute(walk[i])
         _close(e, f, eo, fo)
+
+
+@pytest.mark.parametrize("flavour", ["deterministic", "tiles", "fast+single"])
+def test_the_other_pair_stage_forms_stay_in_the_mode(gpu_required, systems, five, monkeypatch, flavour):
+    """Round 6: pair stages other than the FP64 row form keep the five-launch chain -- the tile kernels (the deterministic mode,
+    AGBNP_HIP_ROWS=0: the masks' renewal rides at the tail of the GB tile launch) and the single-precision rows of the fast mode
+    (at the tail of its Born rows).  A queued walk of small steps that leaves the first masks' skin: five launches, nothing
+    withheld, and the mode's numbers -- the oracle's (tiles, deterministic; ReferenceAGBNPKernels.cpp:274-795), or the cutoff
+    oracle's at single-precision tolerances (fast+single; parity unpinned: DESIGN.md s.3)."""
+    torch = pytest.importorskip("torch")
+    s = systems("1dwc")
+    force = P.AGBNPForce.from_arrays(*s.params(), version=1)
+    if flavour == "tiles":
+        monkeypatch.setenv("AGBNP_HIP_ROWS", "0")
+    if flavour == "fast+single":
+        force.setNonbondedMethod(P.AGBNPForce.CutoffNonPeriodic)
+        force.setCutoffDistance(1.0)
+        oracle = Oracle(*s.params(), version=1, cutoff=1.0)
+    else:
+        oracle = Oracle(*s.params(), version=1)
+    k = P.HipCalcAGBNPForceKernel(device=0, mode=flavour) if flavour != "tiles" else P.HipCalcAGBNPForceKernel(device=0)
+    k.initialize(force)
+    rng = np.random.default_rng(4)
+    steps = 50
+    walk = s.pos + np.cumsum(rng.normal(0.0, 0.003, (steps,) + s.pos.shape), axis=0)
+    dev = torch.device("cuda:0")
+    pos = torch.tensor(walk, dtype=torch.float64, device=dev).contiguous()
+    frc = torch.zeros((s.n, 3), dtype=torch.float64, device=dev)
+    ene = torch.zeros((1,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    k.execute_device(pos[0].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)  # (a fresh context's first masks: a launch of their own)
+    assert k.finish(stream) == 0
+    k.set_profiling(True)
+    for i in range(1, steps):
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0, (list(k.withheld()), int(k.scalar("overflow_kinds")))
+    assert int(k.scalar("launches")) == 5
+    times = {n for n, v in k.kernel_times().items() if v[1] > 0}
+    assert "k_prep" not in times and len(times) == 5, times
+    k.set_profiling(False)
+    frc.zero_()
+    ene.zero_()
+    for i in (steps - 3, steps - 2, steps - 1):  # (consecutive steps of the walk: no jump)
+        k.execute_device(pos[i].data_ptr(), frc.data_ptr(), ene.data_ptr(), stream)
+    assert k.finish(stream) == 0
+    want = [oracle.execute(walk[i]) for i in (steps - 3, steps - 2, steps - 1)]
+    e_want, f_want = sum(w[0] for w in want), sum(w[1] for w in want)
+    if flavour == "fast+single":
+        assert abs(ene.item() - e_want) < 2e-6 * abs(e_want) + 6e-2
+        assert np.abs(frc.cpu().numpy() - f_want).max() < 6e-4 * np.abs(f_want).max() / 3
+    else:
+        _close(ene.item(), frc.cpu().numpy(), e_want, f_want, tol=3 * TIGHT)
