@@ -83,8 +83,9 @@ int agbnp_hip_execute_host(agbnp_hip_context* ctx, const double* positions, doub
  * works on, so a replayed evaluation alternates like eager ones do (agbnp_hip_generation() changes once, at that capture).
  * (Run one eager evaluation before the first capture, as for the capacity variant: a context that has never evaluated lays
  * its first masks down with a launch of its own, and a graph that captured that launch repeats it at every replay.)
- * The mode ends for good, silently, where it cannot hold: the diagnostic self volumes, the deterministic / single-precision
- * modes, the 32 768-node store in HBM (capacity variant 4), a stream capture of a version-0 context.  Scalar 16 says which
+ * The mode ends for good, silently, where it cannot hold: the diagnostic self volumes, the 32 768-node store in HBM (capacity
+ * variant 4), and a stream capture of a context whose pair stages are not the FP64 row form (version 0, the deterministic mode,
+ * AGBNP_HIP_ROWS=0, the fast mode's single-precision rows: those keep the mode in eager launches only).  Scalar 16 says which
  * path runs (5 or 6 launches; version 0: 2 or 3).  Since round 6 agbnp_hip_execute_openmm() runs in the mode too (the tree
  * launch reads the context's posq at the context's slots).
  *
